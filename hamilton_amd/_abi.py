@@ -1,0 +1,84 @@
+"""ctypes binding of libhamk.so -- exactly the entry points of include/hamk.h.
+
+This is the stub a maintainer of the reference would write in Haskell as
+`foreign import ccall` declarations; it contains no numerics.
+The library is built in-tree (hamilton_amd/libhamk.so) and the import fails
+loudly when it is missing: there is no CPU fallback for the product path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from .tracer import HamkOp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhamk.so")
+
+HAMK_OK = 0
+HAMK_ERR_INVALID, HAMK_ERR_TAPE, HAMK_ERR_COMPILE, HAMK_ERR_HIP, HAMK_ERR_NODEVICE, HAMK_ERR_UNSUPPORTED = \
+    -1, -2, -3, -4, -5, -6
+ST_SINGULAR, ST_NONFINITE, ST_UNDERFLOW, ST_MAXSTEPS = 1, 2, 4, 8
+MEM_HOST, MEM_DEVICE = 0, 1
+
+_dp = ctypes.c_void_p          # double*  (host or device address)
+_ip = ctypes.c_void_p          # int32_t*
+_h = ctypes.c_void_p           # hamk_system*
+_i32, _i64, _f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+
+# name -> (restype, argtypes); mirrors include/hamk.h declaration by declaration
+SIGNATURES = {
+    "hamk_system_create": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(ctypes.c_double),
+                                          ctypes.POINTER(HamkOp), _i32, ctypes.POINTER(ctypes.c_int32),
+                                          ctypes.POINTER(HamkOp), _i32, _i32, _i32, ctypes.POINTER(_h)]),
+    "hamk_system_destroy": (None, [_h]),
+    "hamk_system_dims": (ctypes.c_int, [_h, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
+    "hamk_set_stream": (ctypes.c_int, [_h, ctypes.c_void_p]),
+    "hamk_synchronize": (ctypes.c_int, [_h]),
+    "hamk_system_source": (ctypes.c_char_p, [_h]),
+    "hamk_system_code_size": (_i64, [_h]),
+    "hamk_coords_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _i32]),
+    "hamk_to_phase_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _dp, _i32]),
+    "hamk_from_phase_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _dp, _ip, _i32]),
+    "hamk_observe_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _dp, _dp, _dp, _ip, _i32]),
+    "hamk_observe_config_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _dp, _dp, _i32]),
+    "hamk_hameqs_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _dp, _dp, _ip, _i32]),
+    "hamk_rk4_steps": (ctypes.c_int, [_h, _i64, _dp, _dp, _f64, _i32, _ip, _i32]),
+    "hamk_step_ham_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _f64, _ip, _ip, _i32]),
+    "hamk_evolve_ham_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _i32, ctypes.POINTER(ctypes.c_double), _dp, _dp,
+                                             _f64, _f64, _f64, _ip, _ip, _i32]),
+    "hamk_last_error": (ctypes.c_char_p, []),
+    "hamk_version": (ctypes.c_char_p, []),
+    "hamk_device_count": (ctypes.c_int, []),
+}
+
+_lib = None
+
+
+class HamkError(RuntimeError):
+    """API / toolchain / HIP failure (the reference raises Haskell exceptions here)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libhamk error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C hamilton_amd/csrc`.  hamilton_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != HAMK_OK:
+        raise HamkError(rc, lib().hamk_last_error().decode("utf-8", "replace"))

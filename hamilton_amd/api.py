@@ -1,0 +1,387 @@
+"""Host-side mirror of `Numeric.Hamilton` over the C ABI of libhamk.so.
+
+Same names, argument order and meaning as the reference's export list
+(/root/reference/src/Numeric/Hamilton.hs:28-70); the one semantic extension is
+that every state may be an ENSEMBLE: positions/velocities/momenta are arrays of
+shape [n] (one trajectory, the reference's case) or [n, B] (B independent
+trajectories, structure-of-arrays).  numpy arrays take the host-staged path
+(HAMK_MEM_HOST); torch CUDA tensors are used in place on the GPU
+(HAMK_MEM_DEVICE, launched on torch's current stream).
+
+Python cannot spell a prime: `mkSystem'` is `mkSystem_`, `evolveHam'` is
+`evolveHam_`, `evolveHamC'` is `evolveHamC_`.
+
+Error behaviour: API misuse / toolchain / HIP failures raise `HamkError` (the
+reference raises Haskell exceptions: Hamilton.hs:425,444,462).  A singular mass
+matrix does NOT raise for ensembles: the per-trajectory status word is kept in
+`System.last_status` (bit HAMK_ST_SINGULAR) and the affected lanes hold NaN --
+for a single trajectory ([n]-shaped input) `SingularSystem` is raised, matching
+hmatrix's exception out of `inv` (Hamilton.hs:321,381).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from . import tracer as T
+from ._abi import HamkError, MEM_DEVICE, MEM_HOST, ST_SINGULAR
+
+try:  # torch is plumbing (device memory, streams); the package works without it on host arrays
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+U_GENERALIZED, U_CARTESIAN = 0, 1
+
+
+class SingularSystem(ArithmeticError):
+    """K = J^T M J not invertible for a single-trajectory call."""
+
+
+# ---------------------------------------------------------------------------------------
+# array plumbing
+# ---------------------------------------------------------------------------------------
+def _is_torch(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+class _Arr:
+    """A [rows, B] fp64 array on host (numpy) or device (torch.cuda)."""
+
+    def __init__(self, data, rows: int, name: str):
+        self.single = False
+        if _is_torch(data) and data.is_cuda:
+            t = data
+            if t.dtype != torch.float64:
+                t = t.to(torch.float64)
+            if t.dim() == 1:
+                t = t.reshape(rows, 1)
+                self.single = True
+            if t.dim() != 2 or t.shape[0] != rows:
+                raise ValueError(f"{name}: expected shape [{rows}] or [{rows}, B], got {tuple(data.shape)}")
+            self.a = t.contiguous()
+            self.device = True
+        else:
+            a = data.detach().cpu().numpy() if _is_torch(data) else np.asarray(data, dtype=np.float64)
+            if a.ndim == 1:
+                a = a.reshape(rows, 1)
+                self.single = True
+            if a.ndim != 2 or a.shape[0] != rows:
+                raise ValueError(f"{name}: expected shape [{rows}] or [{rows}, B], got {np.shape(data)}")
+            self.a = np.ascontiguousarray(a, dtype=np.float64)
+            self.device = False
+        self.B = int(self.a.shape[1])
+
+    @property
+    def ptr(self):
+        return self.a.data_ptr() if self.device else self.a.ctypes.data
+
+    @property
+    def mem(self):
+        return MEM_DEVICE if self.device else MEM_HOST
+
+    def like(self, rows: Optional[int] = None, dtype="f8", lead: Sequence[int] = ()):
+        shape = tuple(lead) + ((rows, self.B) if rows is not None else (self.B,))
+        if self.device:
+            dt = torch.float64 if dtype == "f8" else torch.int32
+            return torch.empty(shape, dtype=dt, device=self.a.device)
+        return np.empty(shape, dtype=np.float64 if dtype == "f8" else np.int32)
+
+    def clone(self):
+        return self.a.clone() if self.device else self.a.copy()
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    return x.data_ptr() if _is_torch(x) else x.ctypes.data
+
+
+def _shape_out(x, single: bool):
+    """[rows, 1] -> [rows] (and [1] -> scalar) when the caller passed one trajectory."""
+    if not single:
+        return x
+    if x.ndim == 1:
+        return float(x[0])
+    return x[..., 0]
+
+
+# ---------------------------------------------------------------------------------------
+# Systems and states                                              Hamilton.hs:103-169
+# ---------------------------------------------------------------------------------------
+class Config:
+    """`Cfg { cfgPositions, cfgVelocities }` (Hamilton.hs:103-115)."""
+
+    def __init__(self, positions, velocities):
+        self.positions = positions
+        self.velocities = velocities
+
+    cfgPositions = property(lambda self: self.positions)
+    cfgVelocities = property(lambda self: self.velocities)
+
+    def __repr__(self):
+        return f"Cfg {{cfgPositions = {self.positions!r}, cfgVelocities = {self.velocities!r}}}"
+
+
+class Phase:
+    """`Phs { phsPositions, phsMomenta }` (Hamilton.hs:133-145)."""
+
+    def __init__(self, positions, momenta):
+        self.positions = positions
+        self.momenta = momenta
+
+    phsPositions = property(lambda self: self.positions)
+    phsMomenta = property(lambda self: self.momenta)
+
+    def __repr__(self):
+        return f"Phs {{phsPositions = {self.positions!r}, phsMomenta = {self.momenta!r}}}"
+
+
+Cfg, Phs = Config, Phase
+
+
+class System:
+    """Opaque `System m n` (Hamilton.hs:160-169): owns a libhamk handle."""
+
+    def __init__(self, m: int, n: int, inertia, tape_f: T.Tape, tape_u: T.Tape, u_space: int):
+        self.m, self.n = int(m), int(n)
+        self.u_space = u_space
+        self.tape_f, self.tape_u = tape_f, tape_u
+        self.last_status = None
+        self.last_nsub = None
+        L = _abi.lib()
+        f_ops, f_n, f_outs = tape_f.as_ctypes()
+        u_ops, u_n, _ = tape_u.as_ctypes()
+        w = (ctypes.c_double * self.m)(*[float(v) for v in inertia])
+        h = ctypes.c_void_p()
+        _abi.check(L.hamk_system_create(self.m, self.n, w, f_ops, f_n, f_outs, u_ops, u_n, tape_u.outs[0],
+                                        u_space, ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _abi.lib().hamk_system_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def source(self) -> str:
+        return _abi.lib().hamk_system_source(self._h).decode()
+
+    @property
+    def code_size(self) -> int:
+        return int(_abi.lib().hamk_system_code_size(self._h))
+
+    def synchronize(self):
+        _abi.check(_abi.lib().hamk_synchronize(self._h))
+
+    def _use_stream_of(self, arr: _Arr):
+        if arr.device:
+            stream = torch.cuda.current_stream(arr.a.device).cuda_stream
+            _abi.check(_abi.lib().hamk_set_stream(self._h, ctypes.c_void_p(stream)))
+        else:
+            _abi.check(_abi.lib().hamk_set_stream(self._h, None))
+
+    def _after(self, status, single: bool, what: str):
+        self.last_status = status
+        if single and status is not None:
+            st = int(status[0])
+            if st & ST_SINGULAR:
+                raise SingularSystem(f"{what}: mass matrix J^T M J is singular")
+
+
+def mkSystem(inertia, f: Callable, u: Callable, n: int) -> System:
+    """mkSystem (Hamilton.hs:201-225): potential over GENERALIZED coordinates.
+
+    `f(q)` maps a list of n values to m values, `u(q)` to a scalar; both written
+    against hamilton_amd's traced arithmetic (the `RealFloat a` of the reference).
+    m = len(inertia); n cannot be read off a Python function and is explicit."""
+    m = len(inertia)
+    return System(m, n, inertia, T.trace(f, n, m), T.trace(u, n, None), U_GENERALIZED)
+
+
+def mkSystem_(inertia, f: Callable, u: Callable, n: int) -> System:
+    """mkSystem' (Hamilton.hs:238-254): potential over the underlying CARTESIAN coordinates."""
+    m = len(inertia)
+    return System(m, n, inertia, T.trace(f, n, m), T.trace(u, m, None), U_CARTESIAN)
+
+
+def system_from_spec(spec) -> System:
+    """Build a System from a hamilton_amd.examples.SystemSpec."""
+    tf, tu = spec.trace()
+    return System(spec.m, spec.n, spec.inertia, tf, tu, spec.u_space)
+
+
+# ---------------------------------------------------------------------------------------
+# state functions
+# ---------------------------------------------------------------------------------------
+def underlyingPos(s: System, q):
+    """underlyingPos (Hamilton.hs:174-178)."""
+    qa = _Arr(q, s.n, "positions")
+    x = qa.like(s.m)
+    s._use_stream_of(qa)
+    _abi.check(_abi.lib().hamk_coords_batch(s._h, qa.B, qa.ptr, _ptr(x), qa.mem))
+    return _shape_out(x, qa.single)
+
+
+def momenta(s: System, c: Config):
+    """momenta (Hamilton.hs:262-269)."""
+    qa, va = _Arr(c.positions, s.n, "positions"), _Arr(c.velocities, s.n, "velocities")
+    p = qa.like(s.n)
+    s._use_stream_of(qa)
+    _abi.check(_abi.lib().hamk_to_phase_batch(s._h, qa.B, qa.ptr, va.ptr, _ptr(p), qa.mem))
+    return _shape_out(p, qa.single)
+
+
+def toPhase(s: System, c: Config) -> Phase:
+    """toPhase (Hamilton.hs:279-284)."""
+    return Phase(c.positions, momenta(s, c))
+
+
+def velocities(s: System, ph: Phase):
+    """velocities (Hamilton.hs:316-324)."""
+    qa, pa = _Arr(ph.positions, s.n, "positions"), _Arr(ph.momenta, s.n, "momenta")
+    v, st = qa.like(s.n), qa.like(None, "i4")
+    s._use_stream_of(qa)
+    _abi.check(_abi.lib().hamk_from_phase_batch(s._h, qa.B, qa.ptr, pa.ptr, _ptr(v), _ptr(st), qa.mem))
+    s._after(st, qa.single, "velocities")
+    return _shape_out(v, qa.single)
+
+
+def fromPhase(s: System, ph: Phase) -> Config:
+    """fromPhase (Hamilton.hs:332-337)."""
+    return Config(ph.positions, velocities(s, ph))
+
+
+def _observe(s: System, q, p, which: str):
+    qa = _Arr(q, s.n, "positions")
+    pa = _Arr(p, s.n, "momenta") if p is not None else None
+    out, st = qa.like(None), qa.like(None, "i4")
+    ptrs = {"ke": None, "pe": None, "h": None}
+    ptrs[which] = _ptr(out)
+    s._use_stream_of(qa)
+    _abi.check(_abi.lib().hamk_observe_batch(s._h, qa.B, qa.ptr, pa.ptr if pa is not None else None,
+                                             ptrs["ke"], ptrs["pe"], ptrs["h"], _ptr(st), qa.mem))
+    if which != "pe":
+        s._after(st, qa.single, which)
+    return _shape_out(out, qa.single)
+
+
+def keP(s: System, ph: Phase):
+    """keP (Hamilton.hs:341-349)."""
+    return _observe(s, ph.positions, ph.momenta, "ke")
+
+
+def hamiltonian(s: System, ph: Phase):
+    """hamiltonian (Hamilton.hs:353-361)."""
+    return _observe(s, ph.positions, ph.momenta, "h")
+
+
+def pe(s: System, q):
+    """pe (Hamilton.hs:182-186)."""
+    return _observe(s, q, None, "pe")
+
+
+def _observe_config(s: System, c: Config, which: str):
+    qa, va = _Arr(c.positions, s.n, "positions"), _Arr(c.velocities, s.n, "velocities")
+    out = qa.like(None)
+    s._use_stream_of(qa)
+    _abi.check(_abi.lib().hamk_observe_config_batch(
+        s._h, qa.B, qa.ptr, va.ptr, _ptr(out) if which == "ke" else None, _ptr(out) if which == "lag" else None, qa.mem))
+    return _shape_out(out, qa.single)
+
+
+def keC(s: System, c: Config):
+    """keC (Hamilton.hs:288-296)."""
+    return _observe_config(s, c, "ke")
+
+
+def lagrangian(s: System, c: Config):
+    """lagrangian (Hamilton.hs:301-309)."""
+    return _observe_config(s, c, "lag")
+
+
+def hamEqs(s: System, ph: Phase):
+    """hamEqs (Hamilton.hs:370-387): returns (dH/dp, -dH/dq)."""
+    qa, pa = _Arr(ph.positions, s.n, "positions"), _Arr(ph.momenta, s.n, "momenta")
+    dq, dp, st = qa.like(s.n), qa.like(s.n), qa.like(None, "i4")
+    s._use_stream_of(qa)
+    _abi.check(_abi.lib().hamk_hameqs_batch(s._h, qa.B, qa.ptr, pa.ptr, _ptr(dq), _ptr(dp), _ptr(st), qa.mem))
+    s._after(st, qa.single, "hamEqs")
+    return _shape_out(dq, qa.single), _shape_out(dp, qa.single)
+
+
+# ---------------------------------------------------------------------------------------
+# time stepping
+# ---------------------------------------------------------------------------------------
+def stepHam(r: float, s: System, ph: Phase) -> Phase:
+    """stepHam (Hamilton.hs:390-402): adaptive RKF45 (GSL semantics) from 0 to r."""
+    qa, pa = _Arr(ph.positions, s.n, "positions"), _Arr(ph.momenta, s.n, "momenta")
+    q, p = qa.clone(), pa.clone()
+    st, ns = qa.like(None, "i4"), qa.like(None, "i4")
+    s._use_stream_of(qa)
+    _abi.check(_abi.lib().hamk_step_ham_batch(s._h, qa.B, _ptr(q), _ptr(p), float(r), _ptr(st), _ptr(ns), qa.mem))
+    s.last_nsub = ns
+    s._after(st, qa.single, "stepHam")
+    return Phase(_shape_out(q, qa.single), _shape_out(p, qa.single))
+
+
+def evolveHam(s: System, p0: Phase, ts, h0: float = 0.0, eps_abs: float = 0.0, eps_rel: float = 0.0) -> List[Phase]:
+    """evolveHam (Hamilton.hs:433-462): the state at each of the >= 2 times; element 0 is p0."""
+    ts = np.ascontiguousarray(np.asarray(ts, dtype=np.float64))
+    if ts.ndim != 1 or len(ts) < 2:
+        raise ValueError("evolveHam needs at least two solution times (2 <= s)")
+    qa, pa = _Arr(p0.positions, s.n, "positions"), _Arr(p0.momenta, s.n, "momenta")
+    nt = len(ts)
+    qo, po = qa.like(s.n, lead=(nt,)), qa.like(s.n, lead=(nt,))
+    st, ns = qa.like(None, "i4"), qa.like(None, "i4")
+    s._use_stream_of(qa)
+    _abi.check(_abi.lib().hamk_evolve_ham_batch(
+        s._h, qa.B, qa.ptr, pa.ptr, nt, ts.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _ptr(qo), _ptr(po),
+        float(h0), float(eps_abs), float(eps_rel), _ptr(st), _ptr(ns), qa.mem))
+    s.last_nsub = ns
+    s._after(st, qa.single, "evolveHam")
+    return [Phase(_shape_out(qo[r], qa.single), _shape_out(po[r], qa.single)) for r in range(nt)]
+
+
+def evolveHam_(s: System, p0: Phase, ts: Sequence[float]) -> List[Phase]:
+    """evolveHam' (Hamilton.hs:409-429): [] -> []; [x] -> evolve over [0, x] and drop the first."""
+    ts = list(ts)
+    if not ts:
+        return []
+    if len(ts) == 1:
+        return evolveHam(s, p0, [0.0, ts[0]])[1:]
+    return evolveHam(s, p0, ts)
+
+
+def stepHamC(r: float, s: System, c: Config) -> Config:
+    """stepHamC (Hamilton.hs:502-515)."""
+    return fromPhase(s, stepHam(r, s, toPhase(s, c)))
+
+
+def evolveHamC(s: System, c0: Config, ts) -> List[Config]:
+    """evolveHamC (Hamilton.hs:486-500)."""
+    return [fromPhase(s, ph) for ph in evolveHam(s, toPhase(s, c0), ts)]
+
+
+def evolveHamC_(s: System, c0: Config, ts: Sequence[float]) -> List[Config]:
+    """evolveHamC' (Hamilton.hs:470-484)."""
+    return [fromPhase(s, ph) for ph in evolveHam_(s, toPhase(s, c0), ts)]
+
+
+def rk4Steps(dt: float, nsteps: int, s: System, ph: Phase, inplace: bool = False) -> Phase:
+    """Classic fixed-step RK4 over hamEqs -- named by BASELINE.json's north_star; the
+    reference has no fixed-step integrator.  inplace=True advances the
+    given device/host arrays without copying (bench path)."""
+    qa, pa = _Arr(ph.positions, s.n, "positions"), _Arr(ph.momenta, s.n, "momenta")
+    q, p = (qa.a, pa.a) if inplace else (qa.clone(), pa.clone())
+    st = qa.like(None, "i4")
+    s._use_stream_of(qa)
+    _abi.check(_abi.lib().hamk_rk4_steps(s._h, qa.B, _ptr(q), _ptr(p), float(dt), int(nsteps), _ptr(st), qa.mem))
+    s.last_status = st
+    return Phase(_shape_out(q, qa.single), _shape_out(p, qa.single))

@@ -1,0 +1,463 @@
+// hamk_api.cpp -- C ABI of libhamk.so (include/hamk.h): system construction
+// (tape -> hiprtc-specialised gfx950 module) and ensemble launches.
+//
+// Host-side counterpart of the reference's `System` record and its callers
+// (Hamilton.hs:160-169, :201-254, :262-462): there a `System` is a bundle of
+// Haskell closures re-entering `ad` on every call; here it is an opaque handle
+// owning one compiled code object whose kernels evaluate the whole ensemble.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "hamk_internal.h"
+
+using namespace hamk_host;
+
+static const char kDeviceHeader[] =
+#include "hamk_device_src.inc"
+    ;
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(HAMK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+  } while (0)
+
+enum KernelId { K_RK4, K_HAMEQS, K_COORDS, K_TO_PHASE, K_FROM_PHASE, K_OBSERVE, K_OBSERVE_CFG, K_RKF45, K__COUNT };
+static const char* kKernelNames[K__COUNT] = {"hamk_rk4_steps_k", "hamk_hameqs_k",  "hamk_coords_k",         "hamk_to_phase_k",
+                                             "hamk_from_phase_k", "hamk_observe_k", "hamk_observe_config_k", "hamk_rkf45_k"};
+
+struct hamk_system {
+  SystemDesc desc;
+  std::string source;
+  std::vector<char> code;      // gfx950 code object
+  std::string build_log;
+  // lazily bound to a device
+  int device = -1;
+  hipModule_t module = nullptr;
+  hipFunction_t fn[K__COUNT] = {};
+  hipStream_t stream = nullptr;
+  // small device scratch for evolveHam's time grid
+  double* d_ts = nullptr;
+  size_t d_ts_cap = 0;
+  std::vector<double> h_ts;
+};
+
+// ---------------------------------------------------------------------------
+// specialisation
+// ---------------------------------------------------------------------------
+static int compile_module(hamk_system* s) {
+  hiprtcProgram prog = nullptr;
+  const char* hdr_src[] = {kDeviceHeader};
+  const char* hdr_name[] = {"hamk_device.hpp"};
+  hiprtcResult r = hiprtcCreateProgram(&prog, s->source.c_str(), "hamk_system.hip", 1, hdr_src, hdr_name);
+  if (r != HIPRTC_SUCCESS) return fail(HAMK_ERR_COMPILE, std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r));
+  std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast",
+                                   "-fno-honor-nans", "-fno-signed-zeros"};
+  std::string extra;                                   // experiments: HAMK_HIPRTC_FLAGS="-mllvm -foo ..."
+  std::vector<std::string> extra_tok;
+  if (const char* e = std::getenv("HAMK_HIPRTC_FLAGS")) {
+    extra = e;
+    size_t pos = 0;
+    while (pos < extra.size()) {
+      size_t sp = extra.find(' ', pos);
+      if (sp == std::string::npos) sp = extra.size();
+      if (sp > pos) extra_tok.push_back(extra.substr(pos, sp - pos));
+      pos = sp + 1;
+    }
+    for (auto& t : extra_tok) opts.push_back(t.c_str());
+  }
+  r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+  size_t logsz = 0;
+  hiprtcGetProgramLogSize(prog, &logsz);
+  if (logsz > 1) {
+    s->build_log.resize(logsz);
+    hiprtcGetProgramLog(prog, &s->build_log[0]);
+  }
+  if (r != HIPRTC_SUCCESS) {
+    std::string msg = std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(r) + "\n" + s->build_log;
+    hiprtcDestroyProgram(&prog);
+    return fail(HAMK_ERR_COMPILE, msg);
+  }
+  size_t sz = 0;
+  hiprtcGetCodeSize(prog, &sz);
+  s->code.resize(sz);
+  hiprtcGetCode(prog, s->code.data());
+  hiprtcDestroyProgram(&prog);
+  return HAMK_OK;
+}
+
+static int bind_device(hamk_system* s) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail(HAMK_ERR_NODEVICE, std::string("hipGetDevice: ") + hipGetErrorString(e));
+  if (s->module && dev == s->device) return HAMK_OK;
+  if (s->module) {
+    hipModuleUnload(s->module);
+    s->module = nullptr;
+    if (s->d_ts) { hipFree(s->d_ts); s->d_ts = nullptr; s->d_ts_cap = 0; }
+  }
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(HAMK_ERR_NODEVICE, std::string("device ") + prop.gcnArchName + " is not gfx950 (MI355X); libhamk has no other code path");
+  HIP_TRY(hipModuleLoadData(&s->module, s->code.data()));
+  for (int k = 0; k < K__COUNT; ++k) HIP_TRY(hipModuleGetFunction(&s->fn[k], s->module, kKernelNames[k]));
+  s->device = dev;
+  return HAMK_OK;
+}
+
+static int launch(hamk_system* s, KernelId k, int64_t B, void** args) {
+  const unsigned block = 256;
+  const int64_t grid = (B + block - 1) / block;
+  if (grid > 0x7fffffffLL) return fail(HAMK_ERR_INVALID, "ensemble too large for one launch");
+  HIP_TRY(hipModuleLaunchKernel(s->fn[k], (unsigned)grid, 1, 1, block, 1, 1, 0, s->stream, args, nullptr));
+  return HAMK_OK;
+}
+
+// ---- host-pointer staging -----------------------------------------------------
+namespace {
+struct Staged {
+  void* dev = nullptr;
+  void* host = nullptr;
+  size_t bytes = 0;
+  bool out = false;
+};
+class Stager {
+ public:
+  explicit Stager(hamk_system* s, int mem) : s_(s), host_(mem == HAMK_MEM_HOST) {}
+  ~Stager() { for (auto& b : bufs_) if (b.dev) hipFree(b.dev); }
+  // returns the device pointer to use for `p` (nullptr stays nullptr)
+  template <class T> int in(const T* p, size_t count, T** dev) { return add((void*)p, count * sizeof(T), true, false, (void**)dev); }
+  template <class T> int out(T* p, size_t count, T** dev) { return add((void*)p, count * sizeof(T), false, true, (void**)dev); }
+  template <class T> int inout(T* p, size_t count, T** dev) { return add((void*)p, count * sizeof(T), true, true, (void**)dev); }
+  int finish() {
+    if (!host_) return HAMK_OK;
+    for (auto& b : bufs_)
+      if (b.out) HIP_TRY(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, s_->stream));
+    HIP_TRY(hipStreamSynchronize(s_->stream));
+    return HAMK_OK;
+  }
+
+ private:
+  int add(void* p, size_t bytes, bool copy_in, bool copy_out, void** dev) {
+    if (!p || !host_ || bytes == 0) { *dev = p; return HAMK_OK; }
+    Staged b; b.host = p; b.bytes = bytes; b.out = copy_out;
+    HIP_TRY(hipMalloc(&b.dev, bytes));
+    bufs_.push_back(b);
+    if (copy_in) HIP_TRY(hipMemcpyAsync(b.dev, p, bytes, hipMemcpyHostToDevice, s_->stream));
+    *dev = b.dev;
+    return HAMK_OK;
+  }
+  hamk_system* s_;
+  bool host_;
+  std::vector<Staged> bufs_;
+};
+}  // namespace
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != HAMK_OK) return rc_; } while (0)
+
+static int check_call(hamk_system* s, int64_t B, int32_t mem) {
+  if (!s) return fail(HAMK_ERR_INVALID, "null system handle");
+  if (B < 0) return fail(HAMK_ERR_INVALID, "negative ensemble size");
+  if (mem != HAMK_MEM_HOST && mem != HAMK_MEM_DEVICE) return fail(HAMK_ERR_INVALID, "mem must be HAMK_MEM_HOST or HAMK_MEM_DEVICE");
+  return HAMK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* hamk_last_error(void) { return g_last_error.c_str(); }
+const char* hamk_version(void) { return "hamk 0.1 (gfx950; hiprtc-specialised jets; RK4 + GSL-semantics RKF45)"; }
+
+int hamk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_op* f_ops, int32_t f_nops,
+                       const int32_t* f_outs, const hamk_op* u_ops, int32_t u_nops, int32_t u_out, int32_t u_space,
+                       hamk_system** out) {
+  if (!out) return fail(HAMK_ERR_INVALID, "out is null");
+  *out = nullptr;
+  if (m <= 0 || n <= 0) return fail(HAMK_ERR_INVALID, "m and n must be positive");
+  if (!inertia || !f_outs) return fail(HAMK_ERR_INVALID, "null inertia / f_outs");
+  if (u_space != HAMK_U_GENERALIZED && u_space != HAMK_U_CARTESIAN) return fail(HAMK_ERR_INVALID, "bad u_space");
+  if (n > 16 || m > 64)
+    return fail(HAMK_ERR_UNSUPPORTED, "per-lane register kernels support n <= 16, m <= 64 (larger n: not implemented yet)");
+  std::string err = validate_tape(f_ops, f_nops, n, f_outs, m, "coordinate map");
+  if (!err.empty()) return fail(HAMK_ERR_TAPE, err);
+  const int nu = (u_space == HAMK_U_CARTESIAN) ? m : n;
+  err = validate_tape(u_ops, u_nops, nu, &u_out, 1, "potential");
+  if (!err.empty()) return fail(HAMK_ERR_TAPE, err);
+
+  hamk_system* s = new hamk_system();
+  s->desc.m = m; s->desc.n = n; s->desc.u_space = u_space;
+  s->desc.inertia.assign(inertia, inertia + m);
+  s->desc.f_ops.assign(f_ops, f_ops + f_nops);
+  s->desc.f_outs.assign(f_outs, f_outs + m);
+  s->desc.u_ops.assign(u_ops, u_ops + u_nops);
+  s->desc.u_out = u_out;
+  s->desc.mode_h = (n <= 2);
+  if (const char* e = std::getenv("HAMK_AD_MODE")) {          // experiments: force "H" or "D"
+    if (e[0] == 'H' || e[0] == 'h') s->desc.mode_h = true;
+    if (e[0] == 'D' || e[0] == 'd') s->desc.mode_h = false;
+  }
+  s->source = generate_source(s->desc);
+  int rc = compile_module(s);
+  if (rc != HAMK_OK) { delete s; return rc; }
+  *out = s;
+  return HAMK_OK;
+}
+
+void hamk_system_destroy(hamk_system* s) {
+  if (!s) return;
+  if (s->module) hipModuleUnload(s->module);
+  if (s->d_ts) hipFree(s->d_ts);
+  delete s;
+}
+
+int hamk_system_dims(const hamk_system* s, int32_t* m, int32_t* n) {
+  if (!s) return fail(HAMK_ERR_INVALID, "null system handle");
+  if (m) *m = s->desc.m;
+  if (n) *n = s->desc.n;
+  return HAMK_OK;
+}
+
+int hamk_set_stream(hamk_system* s, void* hip_stream) {
+  if (!s) return fail(HAMK_ERR_INVALID, "null system handle");
+  s->stream = (hipStream_t)hip_stream;
+  return HAMK_OK;
+}
+
+int hamk_synchronize(hamk_system* s) {
+  if (!s) return fail(HAMK_ERR_INVALID, "null system handle");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return HAMK_OK;
+}
+
+const char* hamk_system_source(const hamk_system* s) { return s ? s->source.c_str() : nullptr; }
+int64_t hamk_system_code_size(const hamk_system* s) { return s ? (int64_t)s->code.size() : 0; }
+
+int hamk_coords_batch(hamk_system* s, int64_t B, const double* q, double* x, int32_t mem) {
+  TRY(check_call(s, B, mem));
+  if (!q || !x) return fail(HAMK_ERR_INVALID, "null q / x");
+  if (B == 0) return HAMK_OK;
+  TRY(bind_device(s));
+  Stager st(s, mem);
+  const double* dq; double* dx;
+  TRY(st.in(q, (size_t)s->desc.n * B, (double**)&dq));
+  TRY(st.out(x, (size_t)s->desc.m * B, &dx));
+  long long b = B;
+  void* args[] = {&dq, &dx, &b};
+  TRY(launch(s, K_COORDS, B, args));
+  return st.finish();
+}
+
+int hamk_to_phase_batch(hamk_system* s, int64_t B, const double* q, const double* qd, double* p, int32_t mem) {
+  TRY(check_call(s, B, mem));
+  if (!q || !qd || !p) return fail(HAMK_ERR_INVALID, "null q / qd / p");
+  if (B == 0) return HAMK_OK;
+  TRY(bind_device(s));
+  Stager st(s, mem);
+  const size_t cnt = (size_t)s->desc.n * B;
+  const double *dq, *dqd; double* dp;
+  TRY(st.in(q, cnt, (double**)&dq));
+  TRY(st.in(qd, cnt, (double**)&dqd));
+  TRY(st.out(p, cnt, &dp));
+  long long b = B;
+  void* args[] = {&dq, &dqd, &dp, &b};
+  TRY(launch(s, K_TO_PHASE, B, args));
+  return st.finish();
+}
+
+int hamk_from_phase_batch(hamk_system* s, int64_t B, const double* q, const double* p, double* qd, int32_t* status,
+                          int32_t mem) {
+  TRY(check_call(s, B, mem));
+  if (!q || !p || !qd) return fail(HAMK_ERR_INVALID, "null q / p / qd");
+  if (B == 0) return HAMK_OK;
+  TRY(bind_device(s));
+  Stager st(s, mem);
+  const size_t cnt = (size_t)s->desc.n * B;
+  const double *dq, *dp; double* dqd; int32_t* dst;
+  TRY(st.in(q, cnt, (double**)&dq));
+  TRY(st.in(p, cnt, (double**)&dp));
+  TRY(st.out(qd, cnt, &dqd));
+  TRY(st.out(status, (size_t)B, &dst));
+  long long b = B;
+  void* args[] = {&dq, &dp, &dqd, &b, &dst};
+  TRY(launch(s, K_FROM_PHASE, B, args));
+  return st.finish();
+}
+
+int hamk_observe_batch(hamk_system* s, int64_t B, const double* q, const double* p, double* ke, double* pe, double* h,
+                       int32_t* status, int32_t mem) {
+  TRY(check_call(s, B, mem));
+  if (!q) return fail(HAMK_ERR_INVALID, "null q");
+  if (!p && (ke || h)) return fail(HAMK_ERR_INVALID, "ke / h need momenta p");
+  if (B == 0) return HAMK_OK;
+  TRY(bind_device(s));
+  Stager st(s, mem);
+  const size_t cnt = (size_t)s->desc.n * B;
+  const double *dq, *dp; double *dke, *dpe, *dh; int32_t* dst;
+  TRY(st.in(q, cnt, (double**)&dq));
+  TRY(st.in(p, cnt, (double**)&dp));
+  TRY(st.out(ke, (size_t)B, &dke));
+  TRY(st.out(pe, (size_t)B, &dpe));
+  TRY(st.out(h, (size_t)B, &dh));
+  TRY(st.out(status, (size_t)B, &dst));
+  long long b = B;
+  void* args[] = {&dq, &dp, &dke, &dpe, &dh, &b, &dst};
+  TRY(launch(s, K_OBSERVE, B, args));
+  return st.finish();
+}
+
+int hamk_observe_config_batch(hamk_system* s, int64_t B, const double* q, const double* qd, double* ke, double* lag,
+                              int32_t mem) {
+  TRY(check_call(s, B, mem));
+  if (!q || !qd) return fail(HAMK_ERR_INVALID, "null q / qd");
+  if (B == 0) return HAMK_OK;
+  TRY(bind_device(s));
+  Stager st(s, mem);
+  const size_t cnt = (size_t)s->desc.n * B;
+  const double *dq, *dqd; double *dke, *dlag;
+  TRY(st.in(q, cnt, (double**)&dq));
+  TRY(st.in(qd, cnt, (double**)&dqd));
+  TRY(st.out(ke, (size_t)B, &dke));
+  TRY(st.out(lag, (size_t)B, &dlag));
+  long long b = B;
+  void* args[] = {&dq, &dqd, &dke, &dlag, &b};
+  TRY(launch(s, K_OBSERVE_CFG, B, args));
+  return st.finish();
+}
+
+int hamk_hameqs_batch(hamk_system* s, int64_t B, const double* q, const double* p, double* dq, double* dp,
+                      int32_t* status, int32_t mem) {
+  TRY(check_call(s, B, mem));
+  if (!q || !p || !dq || !dp) return fail(HAMK_ERR_INVALID, "null q / p / dq / dp");
+  if (B == 0) return HAMK_OK;
+  TRY(bind_device(s));
+  Stager st(s, mem);
+  const size_t cnt = (size_t)s->desc.n * B;
+  const double *xq, *xp; double *xdq, *xdp; int32_t* dst;
+  TRY(st.in(q, cnt, (double**)&xq));
+  TRY(st.in(p, cnt, (double**)&xp));
+  TRY(st.out(dq, cnt, &xdq));
+  TRY(st.out(dp, cnt, &xdp));
+  TRY(st.out(status, (size_t)B, &dst));
+  long long b = B;
+  void* args[] = {&xq, &xp, &xdq, &xdp, &b, &dst};
+  TRY(launch(s, K_HAMEQS, B, args));
+  return st.finish();
+}
+
+int hamk_rk4_steps(hamk_system* s, int64_t B, double* q, double* p, double dt, int32_t nsteps, int32_t* status,
+                   int32_t mem) {
+  TRY(check_call(s, B, mem));
+  if (!q || !p) return fail(HAMK_ERR_INVALID, "null q / p");
+  if (nsteps < 0) return fail(HAMK_ERR_INVALID, "negative nsteps");
+  if (B == 0) return HAMK_OK;
+  TRY(bind_device(s));
+  Stager st(s, mem);
+  const size_t cnt = (size_t)s->desc.n * B;
+  double *xq, *xp; int32_t* dst;
+  TRY(st.inout(q, cnt, &xq));
+  TRY(st.inout(p, cnt, &xp));
+  TRY(st.out(status, (size_t)B, &dst));
+  long long b = B;
+  int ns = nsteps;
+  void* args[] = {&xq, &xp, &b, &dt, &ns, &dst};
+  TRY(launch(s, K_RK4, B, args));
+  return st.finish();
+}
+
+static int upload_times(hamk_system* s, int32_t nt, const double* ts) {
+  if ((size_t)nt > s->d_ts_cap) {
+    if (s->d_ts) hipFree(s->d_ts);
+    s->d_ts = nullptr; s->d_ts_cap = 0;
+    HIP_TRY(hipMalloc((void**)&s->d_ts, sizeof(double) * nt));
+    s->d_ts_cap = nt;
+  }
+  // the previous launch may still be reading d_ts / h_ts: order behind it on the stream
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->h_ts.assign(ts, ts + nt);
+  HIP_TRY(hipMemcpyAsync(s->d_ts, s->h_ts.data(), sizeof(double) * nt, hipMemcpyHostToDevice, s->stream));
+  return HAMK_OK;
+}
+
+static const double kRefEps = 1.49012e-08;   // Hamilton.hs:448
+static const int kMaxSub = 1 << 24;
+
+int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const double* p0, int32_t nt, const double* ts,
+                          double* qout, double* pout, double h0, double eps_abs, double eps_rel, int32_t* status,
+                          int32_t* nsub, int32_t mem) {
+  TRY(check_call(s, B, mem));
+  if (!q0 || !p0 || !qout || !pout || !ts) return fail(HAMK_ERR_INVALID, "null q0 / p0 / ts / qout / pout");
+  if (nt < 2) return fail(HAMK_ERR_INVALID, "evolveHam needs at least two times (2 <= s, Hamilton.hs:435)");
+  if (B == 0) return HAMK_OK;
+  TRY(bind_device(s));
+  TRY(upload_times(s, nt, ts));
+  if (!(h0 > 0.0)) h0 = (ts[1] - ts[0]) / 100.0;          // Hamilton.hs:447
+  if (!(eps_abs > 0.0)) eps_abs = kRefEps;
+  if (!(eps_rel > 0.0)) eps_rel = kRefEps;
+  Stager st(s, mem);
+  const size_t cnt = (size_t)s->desc.n * B;
+  const double *xq, *xp; double *xqo, *xpo; int32_t *dst, *dns;
+  TRY(st.in(q0, cnt, (double**)&xq));
+  TRY(st.in(p0, cnt, (double**)&xp));
+  TRY(st.out(qout, cnt * nt, &xqo));
+  TRY(st.out(pout, cnt * nt, &xpo));
+  TRY(st.out(status, (size_t)B, &dst));
+  TRY(st.out(nsub, (size_t)B, &dns));
+  long long b = B;
+  int nt_ = nt, row0 = 0, inplace = 0, max_sub = kMaxSub;
+  const double* dts = s->d_ts;
+  void* args[] = {&xq, &xp, &xqo, &xpo, &b, &nt_, &dts, &h0, &eps_abs, &eps_rel, &row0, &inplace, &max_sub, &dst, &dns};
+  TRY(launch(s, K_RKF45, B, args));
+  return st.finish();
+}
+
+int hamk_step_ham_batch(hamk_system* s, int64_t B, double* q, double* p, double dt, int32_t* status, int32_t* nsub,
+                        int32_t mem) {
+  TRY(check_call(s, B, mem));
+  if (!q || !p) return fail(HAMK_ERR_INVALID, "null q / p");
+  if (B == 0) return HAMK_OK;
+  TRY(bind_device(s));
+  const double ts[2] = {0.0, dt};                           // Hamilton.hs:401
+  TRY(upload_times(s, 2, ts));
+  double h0 = dt / 100.0, eps_abs = kRefEps, eps_rel = kRefEps;
+  Stager st(s, mem);
+  const size_t cnt = (size_t)s->desc.n * B;
+  double *xq, *xp; int32_t *dst, *dns;
+  TRY(st.inout(q, cnt, &xq));
+  TRY(st.inout(p, cnt, &xp));
+  TRY(st.out(status, (size_t)B, &dst));
+  TRY(st.out(nsub, (size_t)B, &dns));
+  long long b = B;
+  int nt_ = 2, row0 = 1, inplace = 1, max_sub = kMaxSub;
+  const double* dts = s->d_ts;
+  const double *cq = xq, *cp = xp;
+  void* args[] = {&cq, &cp, &xq, &xp, &b, &nt_, &dts, &h0, &eps_abs, &eps_rel, &row0, &inplace, &max_sub, &dst, &dns};
+  TRY(launch(s, K_RKF45, B, args));
+  return st.finish();
+}
+
+}  // extern "C"

@@ -1,0 +1,150 @@
+// hamk_codegen.cpp -- expression tape -> system struct for the device library.
+//
+// The reference builds a `System` by instantiating the user's polymorphic
+// functions at ad's number types (mkSystem, Hamilton.hs:217-225).  Here the
+// functions arrive already recorded (hamk_op[], include/hamk.h) and are
+// re-emitted as C++ member templates generic over the number type, so that
+// hamk_device.hpp can instantiate them at double / Jet1 / JetH / Jet2.  Only
+// the user's f and U are generated; every kernel around them is hand-written.
+#include "hamk_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+
+namespace hamk_host {
+
+static std::string lit(double c) {
+  if (std::isnan(c)) return "__builtin_nan(\"\")";
+  if (std::isinf(c)) return c > 0 ? "__builtin_inf()" : "(-__builtin_inf())";
+  char buf[64];
+  std::snprintf(buf, sizeof buf, "%a", c);       // hex float: exact round trip
+  std::string s(buf);
+  if (c < 0 || std::signbit(c)) s = "(" + s + ")";
+  return s;
+}
+
+static const char* unary_name(int op) {
+  switch (op) {
+    case HAMK_OP_RECIP: return "recip";
+    case HAMK_OP_SIN: return "sin";
+    case HAMK_OP_COS: return "cos";
+    case HAMK_OP_TAN: return "tan";
+    case HAMK_OP_ASIN: return "asin";
+    case HAMK_OP_ACOS: return "acos";
+    case HAMK_OP_ATAN: return "atan";
+    case HAMK_OP_SINH: return "sinh";
+    case HAMK_OP_COSH: return "cosh";
+    case HAMK_OP_TANH: return "tanh";
+    case HAMK_OP_ASINH: return "asinh";
+    case HAMK_OP_ACOSH: return "acosh";
+    case HAMK_OP_ATANH: return "atanh";
+    case HAMK_OP_EXP: return "exp";
+    case HAMK_OP_LOG: return "log";
+    case HAMK_OP_SQRT: return "sqrt";
+    default: return nullptr;
+  }
+}
+
+static bool is_binary(int op) {
+  return op == HAMK_OP_ADD || op == HAMK_OP_SUB || op == HAMK_OP_MUL || op == HAMK_OP_DIV || op == HAMK_OP_POW ||
+         op == HAMK_OP_ATAN2;
+}
+
+std::string validate_tape(const hamk_op* ops, int nops, int n_in, const int32_t* outs, int n_out, const char* what) {
+  std::ostringstream e;
+  if (nops < 0 || (nops > 0 && !ops)) { e << what << ": null tape"; return e.str(); }
+  for (int i = 0; i < nops; ++i) {
+    const hamk_op& o = ops[i];
+    if (o.op < 0 || o.op >= HAMK_OP__COUNT) { e << what << ": op " << i << " has unknown opcode " << o.op; return e.str(); }
+    if (o.op == HAMK_OP_CONST) continue;
+    if (o.op == HAMK_OP_INPUT) {
+      if (o.a < 0 || o.a >= n_in) { e << what << ": op " << i << " reads input " << o.a << " of " << n_in; return e.str(); }
+      continue;
+    }
+    if (o.a < 0 || o.a >= i) { e << what << ": op " << i << " operand a=" << o.a << " is not an earlier value"; return e.str(); }
+    if (is_binary(o.op) && (o.b < 0 || o.b >= i)) {
+      e << what << ": op " << i << " operand b=" << o.b << " is not an earlier value"; return e.str();
+    }
+    if (o.op == HAMK_OP_POWI && (o.b > 4096 || o.b < -4096)) { e << what << ": op " << i << " exponent out of range"; return e.str(); }
+  }
+  for (int k = 0; k < n_out; ++k)
+    if (outs[k] < 0 || outs[k] >= nops) { e << what << ": output " << k << " refers to value " << outs[k]; return e.str(); }
+  return std::string();
+}
+
+// Emit the body of one generic function.  Values are `const auto vI`; constants
+// stay plain doubles so the jet overloads never multiply by a lifted zero jet.
+static void emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const char* pfx) {
+  // pair SIN/COS of a shared operand: one sincos
+  std::vector<int> sin_of(nops, -1), cos_of(nops, -1);
+  for (int i = 0; i < nops; ++i) {
+    if (ops[i].op == HAMK_OP_SIN && sin_of[ops[i].a] < 0) sin_of[ops[i].a] = i;
+    if (ops[i].op == HAMK_OP_COS && cos_of[ops[i].a] < 0) cos_of[ops[i].a] = i;
+  }
+  std::vector<char> done(nops, 0);
+  auto v = [&](int i) { return std::string(pfx) + std::to_string(i); };
+  for (int i = 0; i < nops; ++i) {
+    if (done[i]) continue;
+    const hamk_op& p = ops[i];
+    o << "    ";
+    switch (p.op) {
+      case HAMK_OP_CONST: o << "const double " << v(i) << " = " << lit(p.c) << ";\n"; break;
+      case HAMK_OP_INPUT: o << "const A& " << v(i) << " = in[" << p.a << "];\n"; break;
+      case HAMK_OP_ADD: o << "const auto " << v(i) << " = " << v(p.a) << " + " << v(p.b) << ";\n"; break;
+      case HAMK_OP_SUB: o << "const auto " << v(i) << " = " << v(p.a) << " - " << v(p.b) << ";\n"; break;
+      case HAMK_OP_MUL: o << "const auto " << v(i) << " = " << v(p.a) << " * " << v(p.b) << ";\n"; break;
+      case HAMK_OP_DIV: o << "const auto " << v(i) << " = " << v(p.a) << " / " << v(p.b) << ";\n"; break;
+      case HAMK_OP_NEG: o << "const auto " << v(i) << " = -" << v(p.a) << ";\n"; break;
+      case HAMK_OP_POWC: o << "const auto " << v(i) << " = hamk::powc(" << v(p.a) << ", " << lit(p.c) << ");\n"; break;
+      case HAMK_OP_POWI: o << "const auto " << v(i) << " = hamk::powi<" << p.b << ">(" << v(p.a) << ");\n"; break;
+      case HAMK_OP_POW: o << "const auto " << v(i) << " = hamk::pow(" << v(p.a) << ", " << v(p.b) << ");\n"; break;
+      case HAMK_OP_ATAN2: o << "const auto " << v(i) << " = hamk::atan2(" << v(p.a) << ", " << v(p.b) << ");\n"; break;
+      case HAMK_OP_SIN:
+      case HAMK_OP_COS: {
+        const int si = sin_of[p.a], ci = cos_of[p.a];
+        if (si >= 0 && ci >= 0 && (si == i || ci == i) && !done[si] && !done[ci]) {
+          o << "decltype(hamk::sin(" << v(p.a) << ")) " << v(si) << ", " << v(ci) << "; hamk::sincos(" << v(p.a)
+            << ", " << v(si) << ", " << v(ci) << ");\n";
+          done[si] = done[ci] = 1;
+        } else {
+          o << "const auto " << v(i) << " = hamk::" << (p.op == HAMK_OP_SIN ? "sin" : "cos") << "(" << v(p.a) << ");\n";
+        }
+      } break;
+      default: o << "const auto " << v(i) << " = hamk::" << unary_name(p.op) << "(" << v(p.a) << ");\n"; break;
+    }
+    done[i] = 1;
+  }
+}
+
+std::string generate_source(const SystemDesc& d) {
+  std::ostringstream o;
+  o << "// generated by libhamk (hamk_codegen.cpp) from the expression tape of one System " << d.m << " " << d.n << "\n";
+  o << "#include \"hamk_device.hpp\"\n\n";
+  o << "struct HamkSys {\n";
+  o << "  static constexpr int N = " << d.n << ";\n";
+  o << "  static constexpr int M = " << d.m << ";\n";
+  o << "  static constexpr bool U_CART = " << (d.u_space == HAMK_U_CARTESIAN ? "true" : "false") << ";\n";
+  o << "  static constexpr bool MODE_H = " << (d.mode_h ? "true" : "false") << ";\n";
+  o << "  __device__ __forceinline__ static constexpr double inertia(int k) {\n";
+  o << "    constexpr double w[M] = {";
+  for (int k = 0; k < d.m; ++k) o << (k ? ", " : "") << lit(d.inertia[k]);
+  o << "};\n    return w[k];\n  }\n";
+  // coordinate map f: generalized -> cartesian                       (_sysCoords, Hamilton.hs:220)
+  o << "  template <class A> __device__ __forceinline__ static void coords(const A (&in)[N], A (&x)[M]) {\n";
+  emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f");
+  for (int k = 0; k < d.m; ++k) o << "    x[" << k << "] = hamk::lift<A>(f" << d.f_outs[k] << ");\n";
+  o << "  }\n";
+  // potential                                                         (_sysPotential, Hamilton.hs:223 / :254)
+  const int nu = d.u_space == HAMK_U_CARTESIAN ? d.m : d.n;
+  o << "  template <class A> __device__ __forceinline__ static A potential(const A (&in)[" << nu << "]) {\n";
+  emit_body(o, d.u_ops.data(), (int)d.u_ops.size(), "u");
+  o << "    return hamk::lift<A>(u" << d.u_out << ");\n";
+  o << "  }\n";
+  o << "};\n\n";
+  o << "HAMK_INSTANTIATE(HamkSys)\n";
+  return o.str();
+}
+
+}  // namespace hamk_host

@@ -1,0 +1,25 @@
+// hamk_internal.h -- shared between hamk_codegen.cpp and hamk_api.cpp (host side of libhamk.so)
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "hamk.h"
+
+namespace hamk_host {
+
+struct SystemDesc {
+  int m = 0, n = 0, u_space = 0;
+  bool mode_h = true;
+  std::vector<double> inertia;
+  std::vector<hamk_op> f_ops;
+  std::vector<int32_t> f_outs;
+  std::vector<hamk_op> u_ops;
+  int32_t u_out = 0;
+};
+
+// empty string = valid
+std::string validate_tape(const hamk_op* ops, int nops, int n_in, const int32_t* outs, int n_out, const char* what);
+std::string generate_source(const SystemDesc& d);
+
+}  // namespace hamk_host

@@ -1,0 +1,211 @@
+/*
+ * hamk.h -- C ABI of libhamk.so: the MI355X (gfx950) replacement for the
+ * equations-of-motion hot path of mstksg/hamilton (Numeric.Hamilton).
+ *
+ * Everything the reference does between "user hands over coordinate map f and
+ * potential U" and "here is the next Phase" is behind these entry points:
+ *
+ *   reference (src/Numeric/Hamilton.hs)                 this ABI
+ *   -------------------------------------------------   -------------------------
+ *   mkSystem  :201-225 / mkSystem' :238-254             hamk_system_create
+ *   System record :160-169 (opaque, GC-owned)           hamk_system (opaque handle) / hamk_system_destroy
+ *   underlyingPos :174-178                              hamk_coords_batch
+ *   pe            :182-186                              hamk_observe_batch (HAMK_OBS_PE)
+ *   momenta :262-269, toPhase :279-284                  hamk_to_phase_batch
+ *   velocities :316-324, fromPhase :332-337             hamk_from_phase_batch
+ *   keC :288-296, lagrangian :301-309                   hamk_observe_config_batch
+ *   keP :341-349, hamiltonian :353-361                  hamk_observe_batch
+ *   hamEqs :370-387                                     hamk_hameqs_batch
+ *   stepHam :390-402                                    hamk_step_ham_batch   (adaptive RKF45, GSL semantics)
+ *   evolveHam :433-462, evolveHam' :409-429             hamk_evolve_ham_batch (adaptive RKF45, GSL semantics)
+ *   (no counterpart; named by BASELINE.json north_star) hamk_rk4_steps        (classic fixed-step RK4)
+ *
+ * The reference evaluates ONE trajectory per call on the CPU through `ad`
+ * (AD), hmatrix (LAPACK/BLAS) and hmatrix-gsl (GSL odeiv).  This library
+ * evaluates an ENSEMBLE of B independent trajectories per call on the GPU,
+ * one trajectory per wavefront lane.  B = 1 reproduces the reference API.
+ *
+ * Data layout: every state array is structure-of-arrays, fp64, component
+ * major: q[j*B + i] is generalized coordinate j of trajectory i (j < n,
+ * i < B).  Arrays are caller-owned; nothing is retained after return.
+ * `mem` says where the caller's pointers live: HAMK_MEM_HOST (library stages
+ * through device memory, PCIe-inclusive) or HAMK_MEM_DEVICE (pointers are HIP
+ * device pointers on the current device; launch is asynchronous on the
+ * handle's stream, see hamk_set_stream).
+ *
+ * User functions cross the ABI as expression tapes (hamk_op[]): the host
+ * shim instantiates the reference's rank-2 polymorphic functions
+ * (`forall a. RealFloat a => Vector n a -> Vector m a`, Hamilton.hs:212,215)
+ * at a recording number type and ships the recording.  The library
+ * specialises its hand-written device kernels on the tape at
+ * hamk_system_create time (hiprtc, gfx950) -- the device-side AD that
+ * replaces `jacobianT`/`hessianF`/`grad` (Hamilton.hs:221-224).
+ *
+ * Error convention: every entry point returns 0 on success, <0 on API /
+ * toolchain / HIP failure (text via hamk_last_error(), thread-local).  This
+ * replaces the reference's `error`/`fromJust`/hmatrix exceptions
+ * (Hamilton.hs:425,444,462,321,381).  Numerical trouble is per trajectory in
+ * status[B] (bit mask, HAMK_ST_*), never an exception.
+ *
+ * Threading: one handle is used by one host thread at a time; distinct
+ * handles may be used concurrently.
+ */
+#ifndef HAMK_H
+#define HAMK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- return codes ------------------------------------------------------ */
+#define HAMK_OK               0
+#define HAMK_ERR_INVALID     -1   /* bad argument (null pointer, n<=0, ...)  */
+#define HAMK_ERR_TAPE        -2   /* malformed tape (forward ref, bad op)    */
+#define HAMK_ERR_COMPILE     -3   /* hiprtc specialisation failed            */
+#define HAMK_ERR_HIP         -4   /* HIP runtime error                       */
+#define HAMK_ERR_NODEVICE    -5   /* no gfx950 device visible                */
+#define HAMK_ERR_UNSUPPORTED -6   /* (m,n) outside what the kernels support  */
+
+/* ---- per-trajectory status bits --------------------------------------- */
+#define HAMK_ST_SINGULAR   1  /* mass matrix K = J^T M J not invertible (reference: hmatrix `inv` throws) */
+#define HAMK_ST_NONFINITE  2  /* state became NaN/Inf                          */
+#define HAMK_ST_UNDERFLOW  4  /* adaptive step could not advance time (h -> 0) */
+#define HAMK_ST_MAXSTEPS   8  /* adaptive stepper hit its sub-step budget      */
+
+/* ---- where caller pointers live ---------------------------------------- */
+#define HAMK_MEM_HOST    0
+#define HAMK_MEM_DEVICE  1
+
+/* ---- which space the potential's tape is written in --------------------- */
+#define HAMK_U_GENERALIZED 0   /* mkSystem : U(q), n inputs  (Hamilton.hs:201-225) */
+#define HAMK_U_CARTESIAN   1   /* mkSystem': U(x), m inputs  (Hamilton.hs:238-254) */
+
+/* ---- expression tape ----------------------------------------------------
+ * Op i defines value i; operands a,b are indices of EARLIER values (SSA).
+ * The set covers the Num/Fractional/Floating/RealFloat methods a traced
+ * Haskell function can emit without comparisons.                            */
+enum hamk_opcode {
+  HAMK_OP_CONST = 0,  /* c                                  */
+  HAMK_OP_INPUT = 1,  /* input[a]                           */
+  HAMK_OP_ADD   = 2,  /* v[a] + v[b]                        */
+  HAMK_OP_SUB   = 3,  /* v[a] - v[b]                        */
+  HAMK_OP_MUL   = 4,  /* v[a] * v[b]                        */
+  HAMK_OP_DIV   = 5,  /* v[a] / v[b]                        */
+  HAMK_OP_NEG   = 6,  /* -v[a]                              */
+  HAMK_OP_RECIP = 7,  /* 1 / v[a]                           */
+  HAMK_OP_SIN   = 8,
+  HAMK_OP_COS   = 9,
+  HAMK_OP_TAN   = 10,
+  HAMK_OP_ASIN  = 11,
+  HAMK_OP_ACOS  = 12,
+  HAMK_OP_ATAN  = 13,
+  HAMK_OP_SINH  = 14,
+  HAMK_OP_COSH  = 15,
+  HAMK_OP_TANH  = 16,
+  HAMK_OP_EXP   = 17,
+  HAMK_OP_LOG   = 18,
+  HAMK_OP_SQRT  = 19,
+  HAMK_OP_POWC  = 20, /* v[a] ** c   (constant real exponent; valid for v[a]<0 when c is integral) */
+  HAMK_OP_POWI  = 21, /* v[a] ^  b   (b = integer exponent, may be negative)                       */
+  HAMK_OP_POW   = 22, /* v[a] ** v[b] (both variable; requires v[a] > 0)                           */
+  HAMK_OP_ATAN2 = 23, /* atan2(v[a], v[b])                                                         */
+  HAMK_OP_ASINH = 24,
+  HAMK_OP_ACOSH = 25,
+  HAMK_OP_ATANH = 26,
+  HAMK_OP__COUNT
+};
+
+typedef struct hamk_op {
+  int32_t op;   /* enum hamk_opcode */
+  int32_t a;    /* first operand / input index */
+  int32_t b;    /* second operand / integer exponent */
+  int32_t _pad;
+  double  c;    /* constant (CONST, POWC) */
+} hamk_op;
+
+typedef struct hamk_system hamk_system;   /* opaque */
+
+/* ---- system construction (mkSystem / mkSystem') --------------------------
+ * inertia[m]; coordinate map f: n inputs -> m outputs f_outs[m] (value ids in
+ * f_ops); potential u: scalar output u_out (value id in u_ops) over n
+ * (HAMK_U_GENERALIZED) or m (HAMK_U_CARTESIAN) inputs.  Compiles the device
+ * module for gfx950; does not need a GPU until the first *_batch call.      */
+int hamk_system_create(int32_t m, int32_t n, const double* inertia,
+                       const hamk_op* f_ops, int32_t f_nops, const int32_t* f_outs,
+                       const hamk_op* u_ops, int32_t u_nops, int32_t u_out,
+                       int32_t u_space, hamk_system** out);
+void hamk_system_destroy(hamk_system* s);
+int  hamk_system_dims(const hamk_system* s, int32_t* m, int32_t* n);
+
+/* Launch on this HIP stream (hipStream_t as void*; NULL = default stream).  */
+int hamk_set_stream(hamk_system* s, void* hip_stream);
+/* Block until everything queued on the handle's stream has finished.        */
+int hamk_synchronize(hamk_system* s);
+
+/* Generated HIP source of the specialised module (for inspection/tests).    */
+const char* hamk_system_source(const hamk_system* s);
+/* Number of bytes of gfx950 code object produced by the specialisation.     */
+int64_t hamk_system_code_size(const hamk_system* s);
+
+/* ---- state functions ------------------------------------------------------ */
+
+/* underlyingPos: x[m][B] = f(q).                          Hamilton.hs:174-178 */
+int hamk_coords_batch(hamk_system* s, int64_t B, const double* q, double* x, int32_t mem);
+
+/* toPhase / momenta: p = J^T (M (J qd)).                  Hamilton.hs:262-284 */
+int hamk_to_phase_batch(hamk_system* s, int64_t B, const double* q, const double* qd,
+                        double* p, int32_t mem);
+
+/* fromPhase / velocities: qd = (J^T M J)^-1 p.            Hamilton.hs:316-337 */
+int hamk_from_phase_batch(hamk_system* s, int64_t B, const double* q, const double* p,
+                          double* qd, int32_t* status, int32_t mem);
+
+/* Phase-space observables; any output pointer may be NULL.
+ * ke = keP (:341-349), pe = pe (:182-186), h = hamiltonian (:353-361).      */
+int hamk_observe_batch(hamk_system* s, int64_t B, const double* q, const double* p,
+                       double* ke, double* pe, double* h, int32_t* status, int32_t mem);
+
+/* Config-space observables; any output pointer may be NULL.
+ * ke = keC (:288-296), lag = lagrangian (:301-309).                          */
+int hamk_observe_config_batch(hamk_system* s, int64_t B, const double* q, const double* qd,
+                              double* ke, double* lag, int32_t mem);
+
+/* hamEqs: (dq, dp) = (dH/dp, -dH/dq).                     Hamilton.hs:370-387 */
+int hamk_hameqs_batch(hamk_system* s, int64_t B, const double* q, const double* p,
+                      double* dq, double* dp, int32_t* status, int32_t mem);
+
+/* ---- time stepping ---------------------------------------------------------- */
+
+/* Classic fixed-step RK4 over hamEqs, nsteps steps of dt, IN PLACE on q,p.
+ * (BASELINE.json metric: "RK4 phase-space steps/sec".)  status may be NULL.  */
+int hamk_rk4_steps(hamk_system* s, int64_t B, double* q, double* p,
+                   double dt, int32_t nsteps, int32_t* status, int32_t mem);
+
+/* stepHam dt: adaptive RKF45 with GSL's standard controller from 0 to dt,
+ * h0 = dt/100, eps_abs = eps_rel = 1.49012e-08, IN PLACE.  Hamilton.hs:390-402,
+ * :445-448.  nsub (optional, [B]) receives accepted+rejected sub-step counts. */
+int hamk_step_ham_batch(hamk_system* s, int64_t B, double* q, double* p, double dt,
+                        int32_t* status, int32_t* nsub, int32_t mem);
+
+/* evolveHam: states at each of the nt >= 2 requested times ts[] (host array);
+ * qout/pout are [nt][n][B]; row 0 is the initial state (Hamilton.hs:443-462).
+ * h0 = (ts[1]-ts[0])/100 and the step size carries across output times, as in
+ * hmatrix-gsl's `odeSolveV`.  Pass h0 <= 0 / eps <= 0 for the reference
+ * defaults.                                                                    */
+int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const double* p0,
+                          int32_t nt, const double* ts, double* qout, double* pout,
+                          double h0, double eps_abs, double eps_rel,
+                          int32_t* status, int32_t* nsub, int32_t mem);
+
+/* ---- diagnostics ---------------------------------------------------------- */
+const char* hamk_last_error(void);
+const char* hamk_version(void);
+/* Number of visible HIP devices (0 if none / runtime missing).               */
+int hamk_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAMK_H */

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json: high-precision, independently derived vectors.
+
+TEST INFRASTRUCTURE.  The reference has no golden vectors, known-answer tests or
+fixtures for this path (/root/reference/test/Spec.hs:1-2 is a stub) and cannot
+be executed here (no ghc/cabal/GSL), so these fixtures are DERIVED, not
+recorded: parity stays "unpinned" in the sense of the task statement.  What they
+provide is an arithmetic-independent check of both the C oracle and the HIP
+path:
+
+  * sympy differentiates the restated example systems (hamilton_amd/examples.py,
+    following /root/reference/app/Examples.hs) symbolically: J, dJ/dq_i, grad U;
+  * mpmath (50 digits) evaluates the reference's formulas literally
+    (Hamilton.hs:262-269 momenta, :316-324 velocities, :341-361 energies,
+    :370-387 hamEqs with explicit inverse);
+  * the result is cross-checked IN THIS SCRIPT against (dH/dp, -dH/dq) obtained
+    by high-precision numerical differentiation of H(q,p) = p.K^-1.p/2 + U --
+    i.e. against Hamilton's equations themselves, not the reference's algebra;
+  * mpmath.odefun (Taylor series, 40 digits) integrates the ODE for trajectory
+    truth at a few times (truncation-level checks of RK4 / RKF45).
+
+Run:  python oracle/gen_golden.py      (takes ~1-2 min; output is committed)
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import mpmath as mp
+import numpy as np
+import sympy as sp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hamilton_amd import examples as E   # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+DIGITS = 50
+NPOINTS = 12
+
+
+def exactify(expr):
+    """Replace sympy Floats (fp64 constants of the definition) by exact rationals."""
+    reps = {f: sp.Rational(*float(f).as_integer_ratio()) for f in expr.atoms(sp.Float)}
+    return expr.xreplace(reps)
+
+
+def fmt(x) -> str:
+    return mp.nstr(mp.mpf(x), 30, min_fixed=0, max_fixed=0)
+
+
+def symbolic(spec: E.SystemSpec):
+    q = sp.symbols(f"q0:{spec.n}", real=True)
+    ops = E._Ops(sp)
+    x = [exactify(sp.sympify(e)) for e in spec.coords(q, ops)]
+    U = exactify(sp.sympify(spec.potential_of_q(q, ops)))
+    J = [[sp.diff(x[k], q[i]) for i in range(spec.n)] for k in range(spec.m)]
+    dJ = [[[sp.diff(J[k][j], q[i]) for j in range(spec.n)] for k in range(spec.m)] for i in range(spec.n)]
+    gU = [sp.diff(U, q[i]) for i in range(spec.n)]
+    lam = lambda e: sp.lambdify(q, e, modules="mpmath")
+    return dict(q=q, x=lam(x), U=lam(U), J=lam(J), dJ=lam(dJ), gU=lam(gU))
+
+
+def mat(rows):
+    return mp.matrix([[mp.mpf(v) for v in r] for r in rows])
+
+
+def evaluate_point(spec, S, qv, qdv):
+    """Everything the public API can return at one Config, via the reference's formulas."""
+    n, m = spec.n, spec.m
+    qv = [mp.mpf(v) for v in qv]
+    qdv = mp.matrix([mp.mpf(v) for v in qdv])
+    M = mp.diag([mp.mpf(v) for v in spec.inertia])
+    x = S["x"](*qv)
+    J = mat(S["J"](*qv))
+    dJ = [mat(r) for r in S["dJ"](*qv)]
+    gU = mp.matrix(S["gU"](*qv))
+    U = mp.mpf(S["U"](*qv))
+    # momenta: tr j #> diag m #> j #> qd                       Hamilton.hs:267
+    p = J.T * (M * (J * qdv))
+    # velocities: inv (tr j <> m <> j) #> p                     Hamilton.hs:321-324
+    K = J.T * M * J
+    Ki = K ** -1
+    vel = Ki * p
+    keC = (qdv.T * p)[0] / 2                                   # :288-296
+    keP = (vel.T * p)[0] / 2                                   # :341-349
+    # hamEqs                                                     :375-387
+    dHdp = Ki * p
+    dTdq = [-(p.T * (Ki * (J.T * (M * (dJ[i] * (Ki * p))))))[0] for i in range(n)]
+    dHdq = [dTdq[i] + gU[i] for i in range(n)]
+    dq = [dHdp[i] for i in range(n)]
+    dp = [-dHdq[i] for i in range(n)]
+
+    # independent cross-check: Hamilton's equations by numerical differentiation of H
+    def Hfun(*args):
+        qq, pp = args[:n], mp.matrix(args[n:])
+        Jq = mat(S["J"](*qq))
+        Kq = Jq.T * M * Jq
+        return (pp.T * mp.lu_solve(Kq, pp))[0] / 2 + S["U"](*qq)
+
+    at = tuple(qv) + tuple(p)
+    for i in range(n):
+        od = [0] * (2 * n)
+        od[n + i] = 1
+        ref_dq = mp.diff(Hfun, at, tuple(od))
+        od = [0] * (2 * n)
+        od[i] = 1
+        ref_dp = -mp.diff(Hfun, at, tuple(od))
+        scale = 1 + abs(ref_dq) + abs(ref_dp)
+        assert abs(ref_dq - dq[i]) < mp.mpf(10) ** -18 * scale, (spec.name, "dq", i, ref_dq, dq[i])
+        assert abs(ref_dp - dp[i]) < mp.mpf(10) ** -18 * scale, (spec.name, "dp", i, ref_dp, dp[i])
+
+    return dict(
+        q=[fmt(v) for v in qv], qd=[fmt(v) for v in qdv], p=[fmt(v) for v in p],
+        x=[fmt(v) for v in x], vel=[fmt(v) for v in vel],
+        jac=[[fmt(J[k, i]) for i in range(n)] for k in range(m)],
+        keC=fmt(keC), keP=fmt(keP), pe=fmt(U), lagrangian=fmt(keC - U), hamiltonian=fmt(keP + U),
+        dq=[fmt(v) for v in dq], dp=[fmt(v) for v in dp],
+        cond_hint=fmt(mp.norm(K, 1) * mp.norm(Ki, 1)),
+    )
+
+
+def trajectory_truth(spec, S, times):
+    """y(t) from the reference initial Config (Examples.hs seInit), Taylor-series ODE solve."""
+    n = spec.n
+    M = mp.diag([mp.mpf(v) for v in spec.inertia])
+
+    def rhs(t, y):
+        qq, pp = list(y[:n]), mp.matrix(y[n:])
+        J = mat(S["J"](*qq))
+        dJ = [mat(r) for r in S["dJ"](*qq)]
+        gU = S["gU"](*qq)
+        K = J.T * M * J
+        v = mp.lu_solve(K, pp)
+        u = M * (J * v)
+        out = [v[i] for i in range(n)]
+        for i in range(n):
+            dT = -(u.T * (dJ[i] * v))[0]
+            out.append(-(dT + gU[i]))
+        return out
+
+    q0 = [mp.mpf(v) for v in spec.q0]
+    qd0 = mp.matrix([mp.mpf(v) for v in spec.qd0])
+    J0 = mat(S["J"](*q0))
+    p0 = J0.T * (M * (J0 * qd0))
+    y0 = q0 + [p0[i] for i in range(n)]
+    sol = mp.odefun(rhs, 0, y0, tol=mp.mpf(10) ** -30, degree=30)
+    rows = []
+    for t in times:
+        y = sol(mp.mpf(t))
+        rows.append(dict(t=repr(float(t)), q=[fmt(v) for v in y[:n]], p=[fmt(v) for v in y[n:]]))
+    return dict(q0=[fmt(v) for v in q0], p0=[fmt(p0[i]) for i in range(n)], states=rows)
+
+
+SYSTEMS = [
+    ("pendulum", (0.01, 0.1, 1.0)),
+    ("doublePendulum", (0.01, 0.1, 1.0)),
+    ("room", (0.01, 0.1, 1.0)),
+    ("twoBody", (0.01, 0.1, 1.0)),
+    ("spring", (0.01, 0.1, 0.5)),
+    ("bezier", (0.01, 0.1, 1.0)),
+    ("threeBodyPolar", (0.002, 0.02)),
+    ("chain4", ()),
+]
+
+
+def main():
+    mp.mp.dps = DIGITS
+    os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])
+    for name, times in SYSTEMS:
+        if only and name not in only:
+            continue
+        spec = E.get(name)
+        S = symbolic(spec)
+        pts = [evaluate_point(spec, S, spec.q0, spec.qd0)]
+        q, qd = E.sample_config(spec, 0, NPOINTS)
+        for i in range(NPOINTS):
+            pts.append(evaluate_point(spec, S, q[:, i], qd[:, i]))
+        doc = dict(
+            system=name, m=spec.m, n=spec.n, inertia=list(spec.inertia), cite=spec.cite,
+            generator="oracle/gen_golden.py (sympy %s, mpmath %s, %d digits)" % (sp.__version__, mp.__version__, DIGITS),
+            note="derived fixtures: symbolic differentiation + 50-digit evaluation of Hamilton.hs:262-387; "
+                 "point 0 is the reference's initial Config; others from examples.sample_config(spec, 0, %d)" % NPOINTS,
+            points=pts,
+        )
+        if times:
+            mp.mp.dps = 40
+            doc["trajectory"] = trajectory_truth(spec, S, times)
+            mp.mp.dps = DIGITS
+        path = os.path.join(OUT, f"{name}.json")
+        with open(path, "w") as fh:
+            json.dump(doc, fh, indent=1)
+        print("wrote", path, len(pts), "points", flush=True)
+
+
+if __name__ == "__main__":
+    main()
