@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- RK4 phase-space steps/sec over an ensemble (BASELINE.json metric).
+
+One bench "step" = one launch of the hot path (`hamk_rk4_steps`) advancing this rank's
+whole ensemble shard by --rk4-per-step classic RK4 steps; inputs are resident in HBM
+before the timed region.  Workload at N=1 = BASELINE.json configs[1]: double pendulum
+(System 4 2, Examples.hs:75-94), 1,048,576 random Phase-2 initial conditions, fp64.
+
+  python bench.py --gpus 1 --steps 10 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: the ensemble shards by contiguous global index range (weak scaling: every rank
+owns --batch trajectories); there is no data-path collective; one RCCL all_gather of the
+final state runs after the timed region (reported as gather_ms).
+
+Prints ONE JSON line on rank 0.  `roofline.achieved` follows SURVEY.md section 8d: 32*n
+algorithmic bytes per trajectory-step (charged per RK4 step even though rk4-per-step steps
+are fused per launch; `roofline.launch_bytes` is the true per-launch read+write), divided by
+the kernel's average duration measured with HIP events on the launch stream.  The path is
+FP64-VALU bound, not HBM bound: the fp64 object next to it is the figure
+that says how good the kernel is.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from hamilton_amd import api, examples  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6        # vector fp64 = 1/2 of the 157.3 TF fp32 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--system", default="doublePendulum")
+    ap.add_argument("--batch", type=int, default=1 << 20, help="trajectories per GPU")
+    ap.add_argument("--rk4-per-step", type=int, default=100, help="RK4 steps fused into one launch")
+    ap.add_argument("--dt", type=float, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline_leg(spec, s, dt, target_seconds):
+    """Oracle (C restatement of the reference algorithm) on this box's host cores, on a bounded
+    sample of the same workload; also yields the metric's `max |dphase| vs CPU ref`."""
+    from oracle import oracle
+    o = oracle.OracleSystem(spec)
+    cores = oracle.max_threads()
+    nsteps = 100
+    probe_B = 256 * cores
+    q, qd = examples.sample_config(spec, 0, probe_B)
+    p = o.to_phase_batch(q, qd)
+    t0 = time.perf_counter()
+    o.rk4_steps_batch(q, p, dt, 10)
+    rate = probe_B * 10 / (time.perf_counter() - t0)
+    S = int(min(1 << 17, max(1024, rate * target_seconds / nsteps)))
+    S -= S % 256
+    q, qd = examples.sample_config(spec, 0, S)
+    p = o.to_phase_batch(q, qd)
+    t0 = time.perf_counter()
+    oq, op = o.rk4_steps_batch(q, p, dt, nsteps)
+    el = time.perf_counter() - t0
+    # same sample through the HIP path (outside any timed region)
+    tq, tp = torch.from_numpy(q).cuda(), torch.from_numpy(p).cuda()
+    one = api.rk4Steps(dt, 1, s, api.Phase(tq, tp))
+    o1q, o1p = o.rk4_steps_batch(q, p, dt, 1)
+    ph = api.rk4Steps(dt, nsteps, s, api.Phase(tq, tp))
+    torch.cuda.synchronize()
+    d1 = max(np.max(np.abs(one.positions.cpu().numpy() - o1q)), np.max(np.abs(one.momenta.cpu().numpy() - o1p)))
+    dN = max(np.max(np.abs(ph.positions.cpu().numpy() - oq)), np.max(np.abs(ph.momenta.cpu().numpy() - op)))
+    base = {"value": S * nsteps / el, "unit": "trajectory-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{S} trajectories x {nsteps} RK4 steps of the same seeded ensemble, "
+                      f"oracle/libhamk_oracle.so (OpenMP, {cores} threads), {el:.1f} s"}
+    parity = {"max_abs_dphase_1_step": float(d1), f"max_abs_dphase_{nsteps}_steps": float(dN),
+              "trajectories": S, "reference": "oracle (CPU restatement; reference Haskell toolchain absent)"}
+    return base, parity
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    spec = examples.get(a.system)
+    dt = a.dt if a.dt is not None else spec.dt
+    s = api.system_from_spec(spec)                       # tape -> hiprtc gfx950 module (outside timed region)
+    B, n = a.batch, spec.n
+
+    # this rank's shard of the global ensemble: indices [rank*B, (rank+1)*B), per-index RNG
+    q_h, qd_h = examples.sample_config(spec, rank * B, B)
+    q = torch.from_numpy(q_h).to(dev)
+    qd = torch.from_numpy(qd_h).to(dev)
+    ph = api.toPhase(s, api.Config(q, qd))               # momenta on device (Hamilton.hs:279-284)
+    q, p = ph.positions.clone(), ph.momenta.clone()
+    h0 = api.hamiltonian(s, api.Phase(q, p)).clone()
+    state = api.Phase(q, p)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        api.rk4Steps(dt, a.rk4_per_step, s, state, inplace=True)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                                          # kernels launch on torch's current stream
+    for _ in range(a.steps):
+        api.rk4Steps(dt, a.rk4_per_step, s, state, inplace=True)
+    ev1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    kernel_s = ev0.elapsed_time(ev1) * 1e-3 / max(1, a.steps)     # avg launch duration, HIP events
+    if dist is not None:
+        t = torch.tensor([elapsed, kernel_s], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_s = float(t[0]), float(t[1])
+
+    bad = int(torch.count_nonzero(s.last_status))
+    h1 = api.hamiltonian(s, state)
+    drift = float(((h1 - h0).abs() / h0.abs().clamp(min=1.0)).max())
+
+    gather_ms = None
+    if dist is not None:                                  # the path's only collective: final gather over xGMI
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        full = torch.empty((world, 2, n, B), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(full, torch.stack([state.positions, state.momenta]).contiguous())
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        t = torch.tensor([bad, 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        bad = int(t[0])
+        t = torch.tensor([drift], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        drift = float(t[0])
+
+    if rank == 0:
+        units = world * B * a.rk4_per_step * a.steps     # trajectory-steps in the timed region
+        value = units / elapsed
+        per_gpu_rate = B * a.rk4_per_step / kernel_s
+        alg_bytes = 32.0 * n                             # read + write one Phase n per step
+        achieved = per_gpu_rate * alg_bytes / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc) and a.system == "doublePendulum" and B == (1 << 20) and a.rk4_per_step == 100:
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "RK4 phase-space steps/sec (ensemble)", "value": value, "unit": "trajectory-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic (per-index splitmix64 initial conditions, seed 20241008)",
+            "config": {"workload": f"{a.system} (System {spec.m} {spec.n}) ensemble, BASELINE.json configs[1]",
+                       "trajectories_per_gpu": B, "rk4_steps_per_launch": a.rk4_per_step, "dt": dt,
+                       "parallelism": f"ensemble-shard x{world} (no data-path collective)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "hamk_rk4_steps_k", "kernel_ms": kernel_s * 1e3,
+                         "algorithmic_bytes_per_trajectory_step": alg_bytes,
+                         "launch_bytes": alg_bytes * B,
+                         "note": "charged 32n B per RK4 step (SURVEY 8d); fp64-VALU bound, see fp64"},
+            "fp64": {"per_gpu_steps_per_s": per_gpu_rate, "peak_tflops": FP64_PEAK_TFLOPS},
+            "status_flagged": bad, "max_rel_energy_drift": drift,
+        }
+        if gather_ms is not None:
+            out["gather_ms"] = gather_ms
+        if world == 1 and not a.no_cpu_baseline:
+            base, parity = cpu_baseline_leg(spec, s, dt, a.cpu_seconds)
+            out["cpu_baseline"] = base
+            out["parity"] = parity
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

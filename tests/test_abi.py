@@ -1,0 +1,88 @@
+"""CPU: the C-ABI library loads, exports every symbol include/hamk.h declares, specialises
+systems with hiprtc (no GPU needed for that), and rejects malformed input with the
+documented codes.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ALL_GOLDEN_SYSTEMS, ROOT
+from hamilton_amd import examples as E
+from hamilton_amd import tracer as T
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "hamk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hamk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(hamk_lib):
+    names = declared_symbols()
+    assert len(names) >= 19
+    for name in names:
+        assert hasattr(hamk_lib, name), f"{name} declared in include/hamk.h but not exported by libhamk.so"
+
+
+def test_binding_table_matches_header(hamk_lib):
+    from hamilton_amd import _abi
+    assert sorted(_abi.SIGNATURES) == declared_symbols()
+
+
+def test_op_struct_layout_and_numbering():
+    assert ctypes.sizeof(T.HamkOp) == 24
+    text = open(os.path.join(ROOT, "include", "hamk.h")).read()
+    enum = dict((k, int(v)) for k, v in re.findall(r"HAMK_OP_([A-Z0-9]+)\s*=\s*(\d+)", text))
+    for name, val in enum.items():
+        assert getattr(T, "OP_" + name) == val, name
+
+
+@pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS + ["chain8"])
+def test_specialisation_compiles_for_gfx950(hamk_lib, name):
+    """hamk_system_create = tape -> generated source -> hiprtc (gfx950); works without a GPU."""
+    from hamilton_amd import api
+    s = api.system_from_spec(E.get(name))
+    assert s.code_size > 1000
+    src = s.source
+    assert "HAMK_INSTANTIATE(HamkSys)" in src and f"N = {s.n};" in src and f"M = {s.m};" in src
+
+
+def test_malformed_tapes_are_rejected(hamk_lib):
+    from hamilton_amd import _abi
+    ops = (T.HamkOp * 2)()
+    ops[0].op, ops[0].a = T.OP_INPUT, 0
+    ops[1].op, ops[1].a = T.OP_SIN, 1          # forward reference to itself
+    outs = (ctypes.c_int32 * 1)(1)
+    w = (ctypes.c_double * 1)(1.0)
+    h = ctypes.c_void_p()
+    rc = hamk_lib.hamk_system_create(1, 1, w, ops, 2, outs, ops, 1, 0, 0, ctypes.byref(h))
+    assert rc == _abi.HAMK_ERR_TAPE and b"earlier value" in hamk_lib.hamk_last_error()
+    ops[1].op = 99
+    rc = hamk_lib.hamk_system_create(1, 1, w, ops, 2, outs, ops, 1, 0, 0, ctypes.byref(h))
+    assert rc == _abi.HAMK_ERR_TAPE
+    rc = hamk_lib.hamk_system_create(0, 1, w, ops, 1, outs, ops, 1, 0, 0, ctypes.byref(h))
+    assert rc == _abi.HAMK_ERR_INVALID
+    rc = hamk_lib.hamk_system_create(1, 1, w, ops, 1, outs, ops, 1, 0, 7, ctypes.byref(h))
+    assert rc == _abi.HAMK_ERR_INVALID
+
+
+def test_calls_fail_loudly_without_a_gpu(hamk_lib):
+    """There is no CPU fallback: on a box without a GPU a compute call returns an error code."""
+    from hamilton_amd import api
+    if hamk_lib.hamk_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    s = api.system_from_spec(E.get("pendulum"))
+    with pytest.raises(api.HamkError):
+        api.hamEqs(s, api.Phase(np.array([0.1]), np.array([0.2])))
+
+
+def test_argument_checks(hamk_lib):
+    from hamilton_amd import api
+    s = api.system_from_spec(E.get("pendulum"))
+    with pytest.raises(ValueError):
+        api.hamEqs(s, api.Phase(np.zeros((2, 3)), np.zeros((2, 3))))      # n = 1, not 2
+    with pytest.raises(ValueError):
+        api.evolveHam(s, api.Phase(np.zeros(1), np.zeros(1)), [0.0])       # needs 2 <= s
+    assert api.evolveHam_(s, api.Phase(np.zeros(1), np.zeros(1)), []) == []

@@ -1,0 +1,292 @@
+"""GPU: the HIP path (through the C ABI of libhamk.so) against the CPU oracle and the
+golden fixtures.  Tolerance ladder of SURVEY.md section 8c:
+  T1  state functions / hamEqs        <= 1e-12 * max(1,|y|) (scaled by cond(K) when ill-conditioned)
+  T2  one RK4 step, GPU vs oracle     <= 1e-13 relative
+  T3  N RK4 steps                     reported; bounded loosely (chaotic growth of roundoff)
+  T4  RK4 vs stepHam (RKF45)          truncation level, 1-step <= 1e-8
+The product path evaluates an algebraically equivalent form of Hamilton.hs:375-387 (solve
+instead of inverse, contraction instead of the Hessian tensor, FMA contraction), so fp64
+results agree to roundoff, not bitwise.
+"""
+import numpy as np
+import pytest
+
+from conftest import ALL_GOLDEN_SYSTEMS, REFERENCE_SYSTEMS, fvec, load_golden
+from hamilton_amd import examples as E
+
+pytestmark = pytest.mark.gpu
+
+T1 = 1e-12
+
+
+@pytest.fixture(scope="module")
+def api(hamk_lib):
+    from hamilton_amd import api as _api
+    if hamk_lib.hamk_device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests need a real MI355X")
+    return _api
+
+
+@pytest.fixture(scope="module")
+def systems(api, oracle_lib):
+    out = {}
+    for name in ALL_GOLDEN_SYSTEMS:
+        spec = E.get(name)
+        out[name] = (spec, api.system_from_spec(spec), oracle_lib.OracleSystem(spec))
+    return out
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.maximum(1.0, np.abs(np.asarray(b)))))
+
+
+# ---------------------------------------------------------------- T1: golden fixtures
+@pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS)
+def test_golden_points(api, systems, name):
+    spec, s, _ = systems[name]
+    g = load_golden(name)
+    pts = g["points"]
+    q = np.stack([fvec(p["q"]) for p in pts], axis=1)
+    qd = np.stack([fvec(p["qd"]) for p in pts], axis=1)
+    p = np.stack([fvec(pt["p"]) for pt in pts], axis=1)
+    cond = np.array([max(1.0, float(pt["cond_hint"])) for pt in pts])
+    tol = T1 * np.maximum(1.0, cond / 1e3)
+
+    def close(got, key, scale_rows=True):
+        want = np.stack([fvec(pt[key]) for pt in pts], axis=-1) if isinstance(pts[0][key], list) \
+            else np.array([float(pt[key]) for pt in pts])
+        err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+        assert np.all(err <= tol), (name, key, float(np.max(err / tol)))
+
+    close(api.underlyingPos(s, q), "x")
+    close(api.momenta(s, api.Config(q, qd)), "p")
+    close(api.velocities(s, api.Phase(q, p)), "vel")
+    close(api.keC(s, api.Config(q, qd)), "keC")
+    close(api.keP(s, api.Phase(q, p)), "keP")
+    close(api.pe(s, q), "pe")
+    close(api.lagrangian(s, api.Config(q, qd)), "lagrangian")
+    close(api.hamiltonian(s, api.Phase(q, p)), "hamiltonian")
+    dq, dp = api.hamEqs(s, api.Phase(q, p))
+    close(dq, "dq")
+    close(dp, "dp")
+    assert not np.any(s.last_status)
+
+
+# ---------------------------------------------------------------- T1: against the oracle on seeded ensembles
+@pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS)
+def test_hameqs_vs_oracle_ensemble(api, systems, name):
+    spec, s, o = systems[name]
+    B = 1000                                   # deliberately not a multiple of the 256-lane block
+    q, qd = E.sample_config(spec, 12345, B)
+    p = api.momenta(s, api.Config(q, qd))
+    assert relerr(p, o.to_phase_batch(q, qd)) < T1
+    dq, dp = api.hamEqs(s, api.Phase(q, p))
+    odq, odp, ost = o.hameqs_batch(q, p)
+    assert not ost.any() and not np.any(s.last_status)
+    assert relerr(dq, odq) < 1e-11 and relerr(dp, odp) < 1e-11, (relerr(dq, odq), relerr(dp, odp))
+    ke, pe_, h = o.observe_batch(q, p)
+    assert relerr(api.keP(s, api.Phase(q, p)), ke) < 1e-11
+    assert relerr(api.pe(s, q), pe_) < T1
+    assert relerr(api.hamiltonian(s, api.Phase(q, p)), h) < 1e-11
+    v, _ = o.from_phase_batch(q, p)
+    assert relerr(api.velocities(s, api.Phase(q, p)), v) < 1e-11
+    assert relerr(api.underlyingPos(s, q), o.coords_batch(q)) < T1
+
+
+# ---------------------------------------------------------------- T2/T3: RK4
+@pytest.mark.parametrize("name", REFERENCE_SYSTEMS + ["threeBodyPolar"])
+def test_rk4_vs_oracle(api, systems, name):
+    spec, s, o = systems[name]
+    B = 300
+    q, qd = E.sample_config(spec, 777, B)
+    p = o.to_phase_batch(q, qd)
+    one = api.rk4Steps(spec.dt, 1, s, api.Phase(q, p))
+    oq, op = o.rk4_steps_batch(q, p, spec.dt, 1)
+    assert relerr(one.positions, oq) < 1e-13 and relerr(one.momenta, op) < 1e-13            # T2
+    many = api.rk4Steps(spec.dt, 100, s, api.Phase(q, p))
+    oq, op = o.rk4_steps_batch(q, p, spec.dt, 100)
+    err = max(relerr(many.positions, oq), relerr(many.momenta, op))
+    assert err < 1e-8, (name, err)                                                            # T3 (bounded loosely)
+    assert not np.any(s.last_status)
+
+
+def test_rk4_matches_taylor_truth(api, systems):
+    spec, s, _ = systems["doublePendulum"]
+    tr = load_golden("doublePendulum")["trajectory"]
+    q0, p0 = fvec(tr["q0"]), fvec(tr["p0"])
+    for st in tr["states"]:
+        n = int(round(float(st["t"]) / spec.dt))
+        ph = api.rk4Steps(spec.dt, n, s, api.Phase(q0, p0))
+        err = max(np.max(np.abs(ph.positions - fvec(st["q"]))), np.max(np.abs(ph.momenta - fvec(st["p"]))))
+        assert err < 5e-6, (st["t"], err)
+
+
+# ---------------------------------------------------------------- stepHam / evolveHam (GSL RKF45 semantics)
+@pytest.mark.parametrize("name", REFERENCE_SYSTEMS)
+def test_stepham_vs_oracle(api, systems, name):
+    spec, s, o = systems[name]
+    B = 200
+    q, qd = E.sample_config(spec, 4242, B)
+    p = o.to_phase_batch(q, qd)
+    dt = 1.0 / 12.0                                    # the demo app's frame step (Examples.hs:415,429)
+    ph = api.stepHam(dt, s, api.Phase(q, p))
+    oq, op, ons = o.step_ham_batch(q, p, dt)
+    nsub = np.asarray(s.last_nsub)
+    same = nsub == ons                                  # identical accept/reject sequence
+    assert same.mean() > 0.95, (name, same.mean())      # a controller threshold can flip on a roundoff tie
+    assert relerr(ph.positions[:, same], oq[:, same]) < 1e-10
+    assert relerr(ph.momenta[:, same], op[:, same]) < 1e-10
+    # lanes whose step sequence differs still agree to the integrator's tolerance
+    assert relerr(ph.positions, oq) < 1e-6 and relerr(ph.momenta, op) < 1e-6
+    assert not np.any(s.last_status)
+
+
+def test_stepham_reference_initial_state(api, systems):
+    """C1: doublePendulum 1 1 from seInit, one trajectory, stepHam 0.01: 4 sub-steps like the CPU path."""
+    spec, s, o = systems["doublePendulum"]
+    q0, p0 = np.array(spec.q0), np.zeros(2)
+    ph = api.stepHam(0.01, s, api.Phase(q0, p0))
+    oq, op = o.step_ham(0.01, q0, p0)
+    assert int(np.asarray(s.last_nsub)[0]) == 4
+    assert relerr(ph.positions, oq) < 1e-13 and relerr(ph.momenta, op) < 1e-13
+    # 1000 x stepHam 0.01 (BASELINE config 1), GPU lane vs CPU oracle: chaotic growth of roundoff only
+    q, p, oq, op = q0, p0, q0, p0
+    for _ in range(100):
+        ph = api.stepHam(0.01, s, api.Phase(q, p)); q, p = ph.positions, ph.momenta
+        oq, op = o.step_ham(0.01, oq, op)
+    assert relerr(q, oq) < 1e-9 and relerr(p, op) < 1e-9
+
+
+def test_evolveham_rows(api, systems):
+    spec, s, o = systems["spring"]
+    B = 64
+    q, qd = E.sample_config(spec, 99, B)
+    p = o.to_phase_batch(q, qd)
+    ts = np.array([0.0, 0.05, 0.1, 0.3, 0.31])
+    rows = api.evolveHam(s, api.Phase(q, p), ts)
+    assert len(rows) == len(ts)
+    np.testing.assert_array_equal(rows[0].positions, q)      # row 0 = initial state (Hamilton.hs:443-462)
+    np.testing.assert_array_equal(rows[0].momenta, p)
+    oq, op, _ = o.evolve_ham_batch(q, p, ts)
+    for r in range(1, len(ts)):
+        assert relerr(rows[r].positions, oq[r]) < 1e-7 and relerr(rows[r].momenta, op[r]) < 1e-7
+    # evolveHam' list front-end (Hamilton.hs:409-429)
+    assert api.evolveHam_(s, api.Phase(q, p), []) == []
+    one = api.evolveHam_(s, api.Phase(q, p), [0.05])
+    assert len(one) == 1 and relerr(one[0].positions, oq[1]) < 1e-7
+    # config-space wrappers (Hamilton.hs:470-515)
+    c1 = api.stepHamC(0.05, s, api.Config(q, qd))
+    v, _ = o.from_phase_batch(oq[1], op[1])
+    assert relerr(c1.velocities, v) < 1e-7
+
+
+# ---------------------------------------------------------------- edge cases
+def test_edge_sizes(api, systems):
+    spec, s, o = systems["doublePendulum"]
+    for B in (1, 63, 64, 65, 255, 256, 257, 1025):
+        q, qd = E.sample_config(spec, 5, B)
+        p = o.to_phase_batch(q, qd)
+        dq, dp = api.hamEqs(s, api.Phase(q, p))
+        odq, odp, _ = o.hameqs_batch(q, p)
+        assert dq.shape == (2, B) and relerr(dq, odq) < 1e-11 and relerr(dp, odp) < 1e-11
+    # empty ensemble
+    e = np.empty((2, 0))
+    dq, dp = api.hamEqs(s, api.Phase(e, e))
+    assert dq.shape == (2, 0)
+    ph = api.rk4Steps(0.01, 3, s, api.Phase(e, e))
+    assert ph.positions.shape == (2, 0)
+    # single trajectory, reference-shaped [n] arrays
+    dq1, dp1 = api.hamEqs(s, api.Phase(np.array(spec.q0), np.zeros(2)))
+    np.testing.assert_allclose(dq1, [0, 0], atol=1e-15)
+    np.testing.assert_allclose(dp1, [-10, 0], atol=1e-14)
+    # zero steps is the identity
+    q, qd = E.sample_config(spec, 5, 10)
+    ph = api.rk4Steps(0.01, 0, s, api.Phase(q, qd))
+    np.testing.assert_array_equal(ph.positions, q)
+
+
+def test_singular_mass_matrix_is_flagged(api, oracle_lib):
+    """Zero inertias make K singular: the reference's `inv` throws (Hamilton.hs:321,381);
+    the ensemble path flags the lane, the single-trajectory call raises."""
+    from hamilton_amd import tracer as T
+    s = api.mkSystem_([0.0, 0.0], lambda q: [T.sin(q[0]), 0.5 - T.cos(q[0])], lambda x: x[1], n=1)
+    q = np.array([[0.1, 0.2, 0.3]]); p = np.array([[1.0, 1.0, 1.0]])
+    api.hamEqs(s, api.Phase(q, p))
+    st = np.asarray(s.last_status)
+    assert np.all(st & 1), st
+    with pytest.raises(api.SingularSystem):
+        api.velocities(s, api.Phase(np.array([0.1]), np.array([1.0])))
+
+
+def test_nonfinite_is_flagged(api, systems):
+    spec, s, _ = systems["twoBody"]
+    q = np.array([[2.0, 0.0, np.nan], [0.0, 0.0, 0.0]])     # r = 0 -> division by zero; NaN input
+    p = np.array([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0]])
+    ph = api.rk4Steps(0.01, 2, s, api.Phase(q, p))
+    st = np.asarray(s.last_status)
+    assert st[0] == 0 and (st[1] & 3) and (st[2] & 2), st
+    assert np.all(np.isfinite(ph.positions[:, 0]))
+
+
+def test_negative_base_constant_power(api, systems):
+    """spring's `x ** 2` must stay valid for x < 0 (Examples.hs:154; SURVEY.md hard parts)."""
+    spec, s, o = systems["spring"]
+    q = np.array([[0.1], [-0.15], [0.2]]); p = np.array([[0.3], [-0.2], [0.1]])
+    dq, dp = api.hamEqs(s, api.Phase(q, p))
+    odq, odp, _ = o.hameqs_batch(q, p)
+    assert np.all(np.isfinite(dp)) and relerr(dp, odp) < 1e-12 and relerr(dq, odq) < 1e-12
+
+
+def test_device_pointers_equal_host_staging(api, systems):
+    """HAMK_MEM_DEVICE (torch CUDA tensors, in place) and HAMK_MEM_HOST staging give identical bits."""
+    import torch
+    spec, s, o = systems["doublePendulum"]
+    B = 5000
+    q, qd = E.sample_config(spec, 31337, B)
+    p = o.to_phase_batch(q, qd)
+    host = api.rk4Steps(0.01, 20, s, api.Phase(q, p))
+    tq, tp = torch.from_numpy(q).cuda(), torch.from_numpy(p).cuda()
+    dev = api.rk4Steps(0.01, 20, s, api.Phase(tq, tp))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dev.positions.cpu().numpy(), host.positions)
+    np.testing.assert_array_equal(dev.momenta.cpu().numpy(), host.momenta)
+    # in-place variant advances the caller's tensors
+    api.rk4Steps(0.01, 20, s, api.Phase(tq, tp), inplace=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(tq.cpu().numpy(), host.positions)
+
+
+# ---------------------------------------------------------------- BASELINE.json full size: properties
+def test_full_size_properties(api, systems):
+    """Config 2 at full size (1,048,576 double-pendulum trajectories): size-independent properties.
+    (a) shard invariance: any sub-range computed alone is bit-identical to the same lanes of the full run;
+    (b) time reversal: RK4 forward then backward returns to the start to O(dt^5) per step;
+    (c) energy drift of RK4 is O(dt^4);  (d) the oracle agrees on a strided sample."""
+    import torch
+    spec, s, o = systems["doublePendulum"]
+    B = 1 << 20
+    q, qd = E.sample_config(spec, 0, B)
+    tq, tqd = torch.from_numpy(q).cuda(), torch.from_numpy(qd).cuda()
+    ph0 = api.toPhase(s, api.Config(tq, tqd))
+    h0 = api.hamiltonian(s, ph0)
+    ph1 = api.rk4Steps(0.01, 100, s, ph0)
+    torch.cuda.synchronize()
+    assert int(torch.count_nonzero(s.last_status)) == 0
+    # (a)
+    lo, hi = 300_001, 300_001 + 70_000
+    sub = api.rk4Steps(0.01, 100, s, api.Phase(ph0.positions[:, lo:hi], ph0.momenta[:, lo:hi]))
+    assert torch.equal(sub.positions, ph1.positions[:, lo:hi]) and torch.equal(sub.momenta, ph1.momenta[:, lo:hi])
+    # (b)
+    back = api.rk4Steps(-0.01, 100, s, ph1)
+    err = max(float((back.positions - ph0.positions).abs().max()), float((back.momenta - ph0.momenta).abs().max()))
+    assert err < 1e-6, err
+    # (c)
+    h1 = api.hamiltonian(s, ph1)
+    drift = float(((h1 - h0).abs() / h0.abs().clamp(min=1.0)).max())
+    assert drift < 1e-6, drift
+    # (d)
+    idx = np.arange(0, B, 4099)
+    qs, ps = ph0.positions[:, idx].cpu().numpy(), ph0.momenta[:, idx].cpu().numpy()
+    oq, op = o.rk4_steps_batch(qs, ps, 0.01, 100)
+    assert relerr(ph1.positions[:, idx].cpu().numpy(), oq) < 1e-8
+    assert relerr(ph1.momenta[:, idx].cpu().numpy(), op) < 1e-8
