@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from hamilton_amd import api, examples  # noqa: E402
+from hamilton_amd import api, ensemble, examples  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6        # vector fp64 = 1/2 of the 157.3 TF fp32 vector peak
@@ -69,7 +69,7 @@ def cpu_baseline_leg(spec, s, dt, target_seconds):
     t0 = time.perf_counter()
     o.rk4_steps_batch(q, p, dt, 10)
     rate = probe_B * 10 / (time.perf_counter() - t0)
-    S = int(min(1 << 17, max(1024, rate * target_seconds / nsteps)))
+    S = int(min(1 << 20, max(1024, rate * target_seconds / nsteps)))
     S -= S % 256
     q, qd = examples.sample_config(spec, 0, S)
     p = o.to_phase_batch(q, qd)
@@ -110,7 +110,8 @@ def main():
     B, n = a.batch, spec.n
 
     # this rank's shard of the global ensemble: indices [rank*B, (rank+1)*B), per-index RNG
-    q_h, qd_h = examples.sample_config(spec, rank * B, B)
+    lo, hi = ensemble.weak_bounds(B, rank)
+    q_h, qd_h = examples.sample_config(spec, lo, hi - lo)
     q = torch.from_numpy(q_h).to(dev)
     qd = torch.from_numpy(qd_h).to(dev)
     ph = api.toPhase(s, api.Config(q, qd))               # momenta on device (Hamilton.hs:279-284)
@@ -149,8 +150,8 @@ def main():
     if dist is not None:                                  # the path's only collective: final gather over xGMI
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        full = torch.empty((world, 2, n, B), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(full, torch.stack([state.positions, state.momenta]).contiguous())
+        gq, gp = ensemble.gather_state(state.positions, state.momenta, dist, world)
+        assert gq.shape == (n, world * B)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         t = torch.tensor([bad, 0], dtype=torch.int64, device=dev)

@@ -10,6 +10,15 @@ from __future__ import annotations
 import ctypes
 import os
 
+try:
+    # torch wheels bundle their own libamdhip64.so.7; it must be the first HIP runtime
+    # mapped into the process, otherwise libhamk.so's rpath copy (/opt/rocm) and torch's
+    # copy both initialise and the second one finds "No HIP GPUs".  With torch loaded
+    # first, libhamk.so binds to the already-mapped soname: one runtime, shared streams.
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional plumbing
+    torch = None
+
 from .tracer import HamkOp
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
