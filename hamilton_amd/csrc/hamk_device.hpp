@@ -297,8 +297,62 @@ HAMK_MIXED(Jet2)
 template <class A> HAMK_DEV double val(const A& a) { return a.v; }
 HAMK_DEV double val(double a) { return a; }
 
+// ---- fp64 sincos tuned for this path ----------------------------------------------
+// The double pendulum's right-hand side is two sincos + ~70 other fp64 operations, and
+// the kernels are FP64-VALU bound, so the library routine's ~60-instruction sincos
+// (double-double Cody-Waite + Payne-Hanek dispatch) would be two thirds of the step.
+// Here: k = rint(x * 2/pi); three-FMA Cody-Waite against pi/2 split into 33-bit pieces
+// (k * piece is exact for |k| < 2^20, so the reduced argument carries ~1e-16 relative
+// error); degree-13/12 minimax kernels on [-pi/4, pi/4] (coefficients as published in
+// fdlibm k_sin.c / k_cos.c); quadrant fix-up on integer bits.  ~20 fp64 instructions,
+// <= 1 ulp.  |x| >= 2^20 * pi/2, NaN and Inf take the library path (rare, divergent).
+HAMK_DEV void sincos_f64(double x, double& s, double& c) {
+  if (fabs(x) < 1.6e6) {
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, x);          // pi/2 bits  0..32
+    r = fma(-k, 6.07710050630396597660e-11, r);                  //          33..65
+    r = fma(-k, 2.02226624871116645580e-21, r);                  //          66..98
+    // power-basis accumulation (acc += coeff * z^k) instead of Horner: every step is a
+    // v_fmac with a dying accumulator, so no constant has to be copied into the
+    // accumulator register first, and the z^k chain runs beside the two sums.
+    const double z = r * r, z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z;
+    double ps = 1.58969099521155010221e-10 * z5;
+    ps = fma(-2.50507602534068634195e-08, z4, ps);
+    ps = fma(2.75573137070700676789e-06, z3, ps);
+    ps = fma(-1.98412698298579493134e-04, z2, ps);
+    ps = fma(8.33333333332248946124e-03, z, ps);
+    ps += -1.66666666666666324348e-01;
+    const double sr = fma(r * z, ps, r);
+    double pc = -1.13596475577881948265e-11 * z5;
+    pc = fma(2.08757232129817482790e-09, z4, pc);
+    pc = fma(-2.75573143513906633035e-07, z3, pc);
+    pc = fma(2.48015872894767294178e-05, z2, pc);
+    pc = fma(-1.38888888888741095749e-03, z, pc);
+    pc += 4.16666666666666019037e-02;
+    const double cr = fma(z, fma(z, pc, -0.5), 1.0);
+    const int q = (int)k;
+    const bool swap = (q & 1) != 0;
+    const double s0 = swap ? cr : sr;
+    const double c0 = swap ? sr : cr;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+  } else {
+    ::sincos(x, &s, &c);
+  }
+}
+
+// 1/d for normal-range d: hardware estimate + two Newton steps (5 instructions instead
+// of the ~11 of an IEEE divide with scaling/fix-up); <= 1 ulp.  Used for pivots and
+// derivative factors, never where the reference's semantics hinge on exact division.
+HAMK_DEV double frcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
 template <class A> HAMK_DEV A recip(const A& x) {
-  const double r = 1.0 / val(x);
+  const double r = frcp(val(x));
   const double r2 = r * r;
   return chain(x, r, -r2, 2.0 * r2 * r);
 }
@@ -311,12 +365,12 @@ template <int N> HAMK_DEV Jet2<N> operator/(double c, const Jet2<N>& b) { return
 // SIN/COS of a shared operand): one fp64 sincos feeds value, gradient and Hessian.
 template <class A> HAMK_DEV void sincos(const A& x, A& s, A& c) {
   double sv, cv;
-  ::sincos(val(x), &sv, &cv);
+  sincos_f64(val(x), sv, cv);
   s = chain(x, sv, cv, -sv);
   c = chain(x, cv, -sv, -cv);
 }
-template <class A> HAMK_DEV A sin(const A& x) { double s, c; ::sincos(val(x), &s, &c); return chain(x, s, c, -s); }
-template <class A> HAMK_DEV A cos(const A& x) { double s, c; ::sincos(val(x), &s, &c); return chain(x, c, -s, -c); }
+template <class A> HAMK_DEV A sin(const A& x) { double s, c; sincos_f64(val(x), s, c); return chain(x, s, c, -s); }
+template <class A> HAMK_DEV A cos(const A& x) { double s, c; sincos_f64(val(x), s, c); return chain(x, c, -s, -c); }
 template <class A> HAMK_DEV A tan(const A& x) {
   const double t = ::tan(val(x)); const double d = fma(t, t, 1.0);
   return chain(x, t, d, 2.0 * t * d);
@@ -470,7 +524,7 @@ template <int N> HAMK_DEV void solve_spd(const double (&K)[N][N], const double (
   for (int j = 0; j < N; ++j) {
     const double dj = a[j][j];
     ok = ok && (dj > 0.0);
-    const double inv = 1.0 / dj;
+    const double inv = frcp(dj);
     double col[N];
 #pragma unroll
     for (int i = j + 1; i < N; ++i) col[i] = a[i][j];
