@@ -127,6 +127,7 @@ std::string generate_source(const SystemDesc& d) {
   o << "  static constexpr int M = " << d.m << ";\n";
   o << "  static constexpr bool U_CART = " << (d.u_space == HAMK_U_CARTESIAN ? "true" : "false") << ";\n";
   o << "  static constexpr bool MODE_H = " << (d.mode_h ? "true" : "false") << ";\n";
+  o << "  static constexpr bool RK4_STAGE_LOOP = " << (d.rk4_stage_loop ? "true" : "false") << ";\n";
   o << "  __device__ __forceinline__ static constexpr double inertia(int k) {\n";
   o << "    constexpr double w[M] = {";
   for (int k = 0; k < d.m; ++k) o << (k ? ", " : "") << lit(d.inertia[k]);

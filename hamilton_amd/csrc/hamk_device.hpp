@@ -757,21 +757,45 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
   for (int j = 0; j < N; ++j) { y[j] = q[(i64)j * B + i]; y[N + j] = p[(i64)j * B + i]; }
   int st = 0;
   const double h2 = 0.5 * dt, h6 = dt * (1.0 / 6.0), h3 = dt * (1.0 / 3.0);
+  if constexpr (S::RK4_STAGE_LOOP) {
+    // one copy of the right-hand side, executed 4 x nsteps times: keeps the live set to a
+    // single hamEqs (n >= 3 would otherwise pay for four interleaved copies in VGPRs).
+    double k[D], acc[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) { k[j] = 0.0; acc[j] = y[j]; }
 #pragma unroll 1
-  for (int s = 0; s < nsteps; ++s) {
-    double k[D], yt[D], acc[D];
-    rhs<S>(y, k, st);
+    for (int it = 0; it < 4 * nsteps; ++it) {
+      const int sg = it & 3;                                    // wave-uniform: scalar selects
+      const double a = (sg == 0) ? 0.0 : ((sg == 3) ? dt : h2);
+      const double b = (sg == 0 || sg == 3) ? h6 : h3;
+      double yt[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) { acc[j] = fma(h6, k[j], y[j]); yt[j] = fma(h2, k[j], y[j]); }
-    rhs<S>(yt, k, st);
+      for (int j = 0; j < D; ++j) yt[j] = fma(a, k[j], y[j]);
+      rhs<S>(yt, k, st);
 #pragma unroll
-    for (int j = 0; j < D; ++j) { acc[j] = fma(h3, k[j], acc[j]); yt[j] = fma(h2, k[j], y[j]); }
-    rhs<S>(yt, k, st);
+      for (int j = 0; j < D; ++j) acc[j] = fma(b, k[j], acc[j]);
+      if (sg == 3) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) { acc[j] = fma(h3, k[j], acc[j]); yt[j] = fma(dt, k[j], y[j]); }
-    rhs<S>(yt, k, st);
+        for (int j = 0; j < D; ++j) y[j] = acc[j];
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+      double k[D], yt[D], acc[D];
+      rhs<S>(y, k, st);
 #pragma unroll
-    for (int j = 0; j < D; ++j) y[j] = fma(h6, k[j], acc[j]);
+      for (int j = 0; j < D; ++j) { acc[j] = fma(h6, k[j], y[j]); yt[j] = fma(h2, k[j], y[j]); }
+      rhs<S>(yt, k, st);
+#pragma unroll
+      for (int j = 0; j < D; ++j) { acc[j] = fma(h3, k[j], acc[j]); yt[j] = fma(h2, k[j], y[j]); }
+      rhs<S>(yt, k, st);
+#pragma unroll
+      for (int j = 0; j < D; ++j) { acc[j] = fma(h3, k[j], acc[j]); yt[j] = fma(dt, k[j], y[j]); }
+      rhs<S>(yt, k, st);
+#pragma unroll
+      for (int j = 0; j < D; ++j) y[j] = fma(h6, k[j], acc[j]);
+    }
   }
   bool bad = false;
 #pragma unroll

@@ -260,8 +260,8 @@ def test_device_pointers_equal_host_staging(api, systems):
 def test_full_size_properties(api, systems):
     """Config 2 at full size (1,048,576 double-pendulum trajectories): size-independent properties.
     (a) shard invariance: any sub-range computed alone is bit-identical to the same lanes of the full run;
-    (b) time reversal: RK4 forward then backward returns to the start to O(dt^5) per step;
-    (c) energy drift of RK4 is O(dt^4);  (d) the oracle agrees on a strided sample."""
+    (b) time reversal and (c) energy drift converge at RK4's order when dt is halved;
+    (d) the oracle agrees on a strided sample."""
     import torch
     spec, s, o = systems["doublePendulum"]
     B = 1 << 20
@@ -276,14 +276,22 @@ def test_full_size_properties(api, systems):
     lo, hi = 300_001, 300_001 + 70_000
     sub = api.rk4Steps(0.01, 100, s, api.Phase(ph0.positions[:, lo:hi], ph0.momenta[:, lo:hi]))
     assert torch.equal(sub.positions, ph1.positions[:, lo:hi]) and torch.equal(sub.momenta, ph1.momenta[:, lo:hi])
-    # (b)
-    back = api.rk4Steps(-0.01, 100, s, ph1)
-    err = max(float((back.positions - ph0.positions).abs().max()), float((back.momenta - ph0.momenta).abs().max()))
-    assert err < 1e-6, err
-    # (c)
-    h1 = api.hamiltonian(s, ph1)
-    drift = float(((h1 - h0).abs() / h0.abs().clamp(min=1.0)).max())
-    assert drift < 1e-6, drift
+    # (b) + (c): RK4 is a 4th-order method -- halving dt must shrink the ensemble-mean time-reversal
+    # error ~2^5 and the ensemble-mean energy drift ~2^4..2^5 (measured on MI355X: 31.8 and 24);
+    # absolute levels bound loosely (fast-swinging members have |theta'| dt ~ 0.1).
+    def rev_and_drift(dt, n):
+        fwd = api.rk4Steps(dt, n, s, ph0)
+        back = api.rk4Steps(-dt, n, s, fwd)
+        err = torch.maximum((back.positions - ph0.positions).abs().amax(0), (back.momenta - ph0.momenta).abs().amax(0))
+        drift = (api.hamiltonian(s, fwd) - h0).abs() / h0.abs().clamp(min=1.0)
+        return err, drift
+    e1, d1 = rev_and_drift(0.01, 100)
+    e2, d2 = rev_and_drift(0.005, 200)
+    assert float(e1.median()) < 2e-6 and float(e1.max()) < 1e-2, (float(e1.median()), float(e1.max()))
+    assert float(d1.median()) < 1e-6 and float(d1.max()) < 1e-3, (float(d1.median()), float(d1.max()))
+    r_rev, r_drift = float(e1.mean() / e2.mean()), float(d1.mean() / d2.mean())
+    assert 16.0 < r_rev < 64.0, r_rev
+    assert 8.0 < r_drift < 64.0, r_drift
     # (d)
     idx = np.arange(0, B, 4099)
     qs, ps = ph0.positions[:, idx].cpu().numpy(), ph0.momenta[:, idx].cpu().numpy()
