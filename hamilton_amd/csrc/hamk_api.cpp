@@ -221,7 +221,7 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
     if (e[0] == 'H' || e[0] == 'h') s->desc.mode_h = true;
     if (e[0] == 'D' || e[0] == 'd') s->desc.mode_h = false;
   }
-  s->desc.rk4_stage_loop = (n >= 3);
+  s->desc.rk4_stage_loop = (n >= 7);
   if (const char* e = std::getenv("HAMK_RK4_LOOP")) s->desc.rk4_stage_loop = (e[0] == '1');
   s->source = generate_source(s->desc);
   int rc = compile_module(s);

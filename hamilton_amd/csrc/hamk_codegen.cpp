@@ -16,7 +16,7 @@
 namespace hamk_host {
 
 static std::string lit(double c) {
-  if (std::isnan(c)) return "__builtin_nan(\"\")";
+  if (std::isnan(c)) return "hamk::quiet_nan()";
   if (std::isinf(c)) return c > 0 ? "__builtin_inf()" : "(-__builtin_inf())";
   char buf[64];
   std::snprintf(buf, sizeof buf, "%a", c);       // hex float: exact round trip
@@ -76,7 +76,8 @@ std::string validate_tape(const hamk_op* ops, int nops, int n_in, const int32_t*
 
 // Emit the body of one generic function.  Values are `const auto vI`; constants
 // stay plain doubles so the jet overloads never multiply by a lifted zero jet.
-static void emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const char* pfx) {
+// Returns the number of trig-cache slots (one per distinct sincos operand) the body uses.
+static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const char* pfx) {
   // pair SIN/COS of a shared operand: one sincos
   std::vector<int> sin_of(nops, -1), cos_of(nops, -1);
   for (int i = 0; i < nops; ++i) {
@@ -84,6 +85,12 @@ static void emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const
     if (ops[i].op == HAMK_OP_COS && cos_of[ops[i].a] < 0) cos_of[ops[i].a] = i;
   }
   std::vector<char> done(nops, 0);
+  std::vector<int> slot_of(nops, -1);          // operand value id -> trig cache slot
+  int nslots = 0;
+  auto slot = [&](int operand) {
+    if (slot_of[operand] < 0) slot_of[operand] = nslots++;
+    return std::string("tc.s[") + std::to_string(slot_of[operand]) + "], tc.c[" + std::to_string(slot_of[operand]) + "]";
+  };
   auto v = [&](int i) { return std::string(pfx) + std::to_string(i); };
   for (int i = 0; i < nops; ++i) {
     if (done[i]) continue;
@@ -105,17 +112,19 @@ static void emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const
       case HAMK_OP_COS: {
         const int si = sin_of[p.a], ci = cos_of[p.a];
         if (si >= 0 && ci >= 0 && (si == i || ci == i) && !done[si] && !done[ci]) {
-          o << "decltype(hamk::sin(" << v(p.a) << ")) " << v(si) << ", " << v(ci) << "; hamk::sincos(" << v(p.a)
-            << ", " << v(si) << ", " << v(ci) << ");\n";
+          o << "hamk::bare_t<decltype(" << v(p.a) << ")> " << v(si) << ", " << v(ci)
+            << "; hamk::sincos<FILL>(" << v(p.a) << ", " << v(si) << ", " << v(ci) << ", " << slot(p.a) << ");\n";
           done[si] = done[ci] = 1;
         } else {
-          o << "const auto " << v(i) << " = hamk::" << (p.op == HAMK_OP_SIN ? "sin" : "cos") << "(" << v(p.a) << ");\n";
+          o << "const auto " << v(i) << " = hamk::" << (p.op == HAMK_OP_SIN ? "sin" : "cos") << "<FILL>(" << v(p.a)
+            << ", " << slot(p.a) << ");\n";
         }
       } break;
       default: o << "const auto " << v(i) << " = hamk::" << unary_name(p.op) << "(" << v(p.a) << ");\n"; break;
     }
     done[i] = 1;
   }
+  return nslots;
 }
 
 std::string generate_source(const SystemDesc& d) {
@@ -133,16 +142,18 @@ std::string generate_source(const SystemDesc& d) {
   for (int k = 0; k < d.m; ++k) o << (k ? ", " : "") << lit(d.inertia[k]);
   o << "};\n    return w[k];\n  }\n";
   // coordinate map f: generalized -> cartesian                       (_sysCoords, Hamilton.hs:220)
-  o << "  template <class A> __device__ __forceinline__ static void coords(const A (&in)[N], A (&x)[M]) {\n";
-  emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f");
+  o << "  template <class A, bool FILL, class TC> __device__ __forceinline__ static void coords(const A (&in)[N], A (&x)[M], TC& tc) {\n";
+  const int ntrig_f = emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f");
   for (int k = 0; k < d.m; ++k) o << "    x[" << k << "] = hamk::lift<A>(f" << d.f_outs[k] << ");\n";
   o << "  }\n";
   // potential                                                         (_sysPotential, Hamilton.hs:223 / :254)
   const int nu = d.u_space == HAMK_U_CARTESIAN ? d.m : d.n;
-  o << "  template <class A> __device__ __forceinline__ static A potential(const A (&in)[" << nu << "]) {\n";
-  emit_body(o, d.u_ops.data(), (int)d.u_ops.size(), "u");
+  o << "  template <class A, bool FILL, class TC> __device__ __forceinline__ static A potential(const A (&in)[" << nu << "], TC& tc) {\n";
+  const int ntrig_u = emit_body(o, d.u_ops.data(), (int)d.u_ops.size(), "u");
   o << "    return hamk::lift<A>(u" << d.u_out << ");\n";
   o << "  }\n";
+  o << "  static constexpr int NTRIG_F = " << ntrig_f << ";\n";
+  o << "  static constexpr int NTRIG_U = " << ntrig_u << ";\n";
   o << "};\n\n";
   o << "HAMK_INSTANTIATE(HamkSys)\n";
   return o.str();

@@ -47,6 +47,15 @@ typedef long long i64;
 
 enum : int { ST_SINGULAR = 1, ST_NONFINITE = 2, ST_UNDERFLOW = 4, ST_MAXSTEPS = 8 };
 
+// hiprtc has no <type_traits>
+template <class T> struct bare { typedef T type; };
+template <class T> struct bare<const T> { typedef T type; };
+template <class T> struct bare<T&> { typedef typename bare<T>::type type; };
+template <class T> struct bare<const T&> { typedef T type; };
+template <class T> using bare_t = typename bare<T>::type;
+
+HAMK_DEV double quiet_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
+
 // ===========================================================================
 // Jets.  All are "value + derivatives along a fixed set of directions"; the
 // generated f/U code is generic over them.
@@ -363,14 +372,24 @@ template <int N> HAMK_DEV Jet2<N> operator/(double c, const Jet2<N>& b) { return
 
 // sin and cos of one argument always come as a pair (codegen fuses the tape's
 // SIN/COS of a shared operand): one fp64 sincos feeds value, gradient and Hessian.
-template <class A> HAMK_DEV void sincos(const A& x, A& s, A& c) {
-  double sv, cv;
-  sincos_f64(val(x), sv, cv);
-  s = chain(x, sv, cv, -sv);
-  c = chain(x, cv, -sv, -cv);
+// The primal pair lives in a per-evaluation TrigCache slot: the sweep that runs first
+// (FILL) computes it, later sweeps of the same point (the Jet2 sweep of MODE_D) reuse
+// it -- the compiler cannot merge two inlined copies of a routine that branches.
+template <int NS> struct TrigCache { double s[NS > 0 ? NS : 1], c[NS > 0 ? NS : 1]; };
+
+template <bool FILL, class A> HAMK_DEV void sincos(const A& x, A& s, A& c, double& cs, double& cc) {
+  if constexpr (FILL) sincos_f64(val(x), cs, cc);
+  s = chain(x, cs, cc, -cs);
+  c = chain(x, cc, -cs, -cc);
 }
-template <class A> HAMK_DEV A sin(const A& x) { double s, c; sincos_f64(val(x), s, c); return chain(x, s, c, -s); }
-template <class A> HAMK_DEV A cos(const A& x) { double s, c; sincos_f64(val(x), s, c); return chain(x, c, -s, -c); }
+template <bool FILL, class A> HAMK_DEV A sin(const A& x, double& cs, double& cc) {
+  if constexpr (FILL) sincos_f64(val(x), cs, cc);
+  return chain(x, cs, cc, -cs);
+}
+template <bool FILL, class A> HAMK_DEV A cos(const A& x, double& cs, double& cc) {
+  if constexpr (FILL) sincos_f64(val(x), cs, cc);
+  return chain(x, cc, -cs, -cc);
+}
 template <class A> HAMK_DEV A tan(const A& x) {
   const double t = ::tan(val(x)); const double d = fma(t, t, 1.0);
   return chain(x, t, d, 2.0 * t * d);
@@ -509,7 +528,7 @@ template <int N> HAMK_DEV void solve_lu(const double (&K)[N][N], const double (&
   if (singular) {
     st |= ST_SINGULAR;
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = __builtin_nan("");
+    for (int i = 0; i < N; ++i) v[i] = quiet_nan();
   }
 }
 
@@ -557,7 +576,8 @@ template <int N> HAMK_DEV void solve_spd(const double (&K)[N][N], const double (
 
 // ===========================================================================
 // The System record's closures on one trajectory (Hamilton.hs:160-169).
-// S (generated): N, M, U_CART, inertia(k), coords<A>(q, x), potential<A>(z).
+// S (generated): N, M, U_CART, MODE_H, RK4_STAGE_LOOP, NTRIG_F, NTRIG_U, inertia(k),
+// coords<A, FILL>(q, x, trig_cache), potential<A, FILL>(z, trig_cache).
 // ===========================================================================
 template <class S> HAMK_DEV void seed1(const double (&q)[S::N], Jet1<S::N> (&qa)[S::N]) {
 #pragma unroll
@@ -586,8 +606,9 @@ template <class S, class A> HAMK_DEV void mass_matrix(const A (&x)[S::M], double
 template <class S> HAMK_DEV void grad_potential(const Jet1<S::N> (&qj)[S::N], const Jet1<S::N> (&xj)[S::M],
                                                 double (&gU)[S::N], double& U) {
   Jet1<S::N> u;
-  if constexpr (S::U_CART) u = lift<Jet1<S::N>>(S::template potential<Jet1<S::N>>(xj));
-  else u = lift<Jet1<S::N>>(S::template potential<Jet1<S::N>>(qj));
+  TrigCache<S::NTRIG_U> tu;
+  if constexpr (S::U_CART) u = S::template potential<Jet1<S::N>, true>(xj, tu);
+  else u = S::template potential<Jet1<S::N>, true>(qj, tu);
   U = u.v;
 #pragma unroll
   for (int i = 0; i < S::N; ++i) gU[i] = u.d[i];
@@ -597,8 +618,9 @@ template <class S> HAMK_DEV void grad_potential(const Jet1<S::N> (&qj)[S::N], co
 template <class S> HAMK_DEV void momenta(const double (&q)[S::N], const double (&qd)[S::N], double (&p)[S::N]) {
   constexpr int N = S::N, M = S::M;
   Jet1<N> qj[N], xj[M];
+  TrigCache<S::NTRIG_F> tc;
   seed1<S>(q, qj);
-  S::template coords<Jet1<N>>(qj, xj);
+  S::template coords<Jet1<N>, true>(qj, xj, tc);
   double w[M];
 #pragma unroll
   for (int k = 0; k < M; ++k) {
@@ -620,20 +642,23 @@ template <class S> HAMK_DEV void momenta(const double (&q)[S::N], const double (
 template <class S> HAMK_DEV void velocities(const double (&q)[S::N], const double (&p)[S::N], double (&qd)[S::N], int& st) {
   constexpr int N = S::N, M = S::M;
   Jet1<N> qj[N], xj[M];
+  TrigCache<S::NTRIG_F> tc;
   seed1<S>(q, qj);
-  S::template coords<Jet1<N>>(qj, xj);
+  S::template coords<Jet1<N>, true>(qj, xj, tc);
   double K[N][N];
   mass_matrix<S>(xj, K);
   solve_spd<N>(K, p, qd, st);
 }
 
 template <class S> HAMK_DEV double potential_value(const double (&q)[S::N]) {
+  TrigCache<S::NTRIG_U> tu;
   if constexpr (S::U_CART) {
     double x[S::M];
-    S::template coords<double>(q, x);
-    return lift<double>(S::template potential<double>(x));
+    TrigCache<S::NTRIG_F> tc;
+    S::template coords<double, true>(q, x, tc);
+    return S::template potential<double, true>(x, tu);
   } else {
-    return lift<double>(S::template potential<double>(q));
+    return S::template potential<double, true>(q, tu);
   }
 }
 
@@ -653,6 +678,7 @@ template <class S, bool MODE_H>
 HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (&dq)[S::N], double (&dp)[S::N], int& st) {
   constexpr int N = S::N, M = S::M;
   double K[N][N], gU[N], U, v[N], dT[N];
+  TrigCache<S::NTRIG_F> tc;
   if constexpr (MODE_H) {
     JetH<N> qh[N], xh[M];
 #pragma unroll
@@ -660,7 +686,7 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
       qh[j] = lift<JetH<N>>(q[j]);
       qh[j].d[j] = 1.0;
     }
-    S::template coords<JetH<N>>(qh, xh);
+    S::template coords<JetH<N>, true>(qh, xh, tc);
     Jet1<N> qj[N], xj[M];
     seed1<S>(q, qj);
 #pragma unroll
@@ -691,7 +717,7 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
   } else {
     Jet1<N> qj[N], xj[M];
     seed1<S>(q, qj);
-    S::template coords<Jet1<N>>(qj, xj);
+    S::template coords<Jet1<N>, true>(qj, xj, tc);
     mass_matrix<S>(xj, K);
     solve_spd<N>(K, p, v, st);
     grad_potential<S>(qj, xj, gU, U);
@@ -702,7 +728,7 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
       q2[j].d[j] = 1.0;
       q2[j].dv = v[j];
     }
-    S::template coords<Jet2<N>>(q2, x2);
+    S::template coords<Jet2<N>, false>(q2, x2, tc);       // primal sincos pairs from the first sweep
 #pragma unroll
     for (int i = 0; i < N; ++i) dT[i] = 0.0;
 #pragma unroll
@@ -838,7 +864,8 @@ template <class S> HAMK_DEV void coords_body(const double* __restrict__ q, doubl
   double qq[S::N], xx[S::M];
 #pragma unroll
   for (int j = 0; j < S::N; ++j) qq[j] = q[(i64)j * B + i];
-  S::template coords<double>(qq, xx);
+  TrigCache<S::NTRIG_F> tc;
+  S::template coords<double, true>(qq, xx, tc);
 #pragma unroll
   for (int k = 0; k < S::M; ++k) x[(i64)k * B + i] = lift<double>(xx[k]);
 }

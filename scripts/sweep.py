@@ -30,7 +30,7 @@ if __name__ == "__main__":
     for name, B, ns in cfgs:
         if only and name not in only: continue
         for mode in ("H", "D"):
-            if mode == "H" and E.get(name).n > 4: continue
+            if mode == "H" and E.get(name).n > 6: continue
             for loop in ("0", "1"):
                 try:
                     print(json.dumps(run(name, B, ns, mode, loop)), flush=True)
