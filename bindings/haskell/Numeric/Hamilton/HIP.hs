@@ -1,0 +1,301 @@
+{-# LANGUAGE DataKinds #-}
+{-# LANGUAGE ForeignFunctionInterface #-}
+{-# LANGUAGE RankNTypes #-}
+{-# LANGUAGE ScopedTypeVariables #-}
+{-# LANGUAGE TypeApplications #-}
+
+-- |
+-- Module      : Numeric.Hamilton.HIP
+-- Description : FFI shim from Numeric.Hamilton onto libhamk.so (MI355X / gfx950)
+--
+-- SOURCE DELIVERABLE, NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no
+-- GHC/cabal (SURVEY.md F3).  It is the binding a maintainer of mstksg/hamilton adds
+-- next to src/Numeric/Hamilton.hs; see INTEGRATION.md for where it hooks in.
+--
+-- What it does:
+--
+--   * 'Traced' is a 'RealFloat' instance whose arithmetic records an expression
+--     tape.  'traceSystem' instantiates the user's rank-2 polymorphic functions
+--     (the arguments of 'mkSystem' / 'mkSystem'', Hamilton.hs:201-254) at 'Traced'
+--     once and ships the tapes to @hamk_system_create@.
+--   * the batched entry points ('hamEqsBatch', 'stepHamBatch', 'rk4StepsBatch',
+--     'evolveHamEnsemble', ...) run ensembles of phases on the GPU; an ensemble is a
+--     pair of storable vectors in structure-of-arrays order (q[j*B + i]).
+--   * comparisons on 'Traced' ('Ord', 'RealFrac', 'isNaN', ...) throw
+--     'UntraceableFunction': such systems keep the pure ad+hmatrix closures.
+module Numeric.Hamilton.HIP
+  ( HipSystem
+  , traceSystem
+  , traceSystem'
+  , Ensemble (..)
+  , toPhaseBatch
+  , fromPhaseBatch
+  , hamEqsBatch
+  , hamiltonianBatch
+  , stepHamBatch
+  , rk4StepsBatch
+  , evolveHamEnsemble
+  , UntraceableFunction (..)
+  ) where
+
+import Control.Exception
+import Control.Monad
+import Data.IORef
+import Data.Int
+import qualified Data.Vector.Sized as V
+import qualified Data.Vector.Storable as VS
+import qualified Data.Vector.Storable.Mutable as VSM
+import Foreign
+import Foreign.C.String
+import Foreign.C.Types
+import GHC.TypeLits
+import Data.Proxy
+import System.IO.Unsafe (unsafePerformIO)
+
+-- ---------------------------------------------------------------------------
+-- C ABI (include/hamk.h) -- one declaration per entry point used here
+-- ---------------------------------------------------------------------------
+data HamkSystem
+
+-- struct hamk_op { int32 op, a, b, _pad; double c; }  (24 bytes)
+data Op = Op !Int32 !Int32 !Int32 !Double
+
+instance Storable Op where
+  sizeOf _ = 24
+  alignment _ = 8
+  peek p = Op <$> peekByteOff p 0 <*> peekByteOff p 4 <*> peekByteOff p 8 <*> peekByteOff p 16
+  poke p (Op o a b c) = pokeByteOff p 0 o >> pokeByteOff p 4 a >> pokeByteOff p 8 b
+                     >> pokeByteOff p 12 (0 :: Int32) >> pokeByteOff p 16 c
+
+foreign import ccall safe "hamk_system_create"
+  c_system_create :: Int32 -> Int32 -> Ptr Double -> Ptr Op -> Int32 -> Ptr Int32
+                  -> Ptr Op -> Int32 -> Int32 -> Int32 -> Ptr (Ptr HamkSystem) -> IO CInt
+foreign import ccall "&hamk_system_destroy"
+  p_system_destroy :: FunPtr (Ptr HamkSystem -> IO ())
+foreign import ccall safe "hamk_to_phase_batch"
+  c_to_phase :: Ptr HamkSystem -> Int64 -> Ptr Double -> Ptr Double -> Ptr Double -> Int32 -> IO CInt
+foreign import ccall safe "hamk_from_phase_batch"
+  c_from_phase :: Ptr HamkSystem -> Int64 -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Int32 -> Int32 -> IO CInt
+foreign import ccall safe "hamk_observe_batch"
+  c_observe :: Ptr HamkSystem -> Int64 -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double
+            -> Ptr Int32 -> Int32 -> IO CInt
+foreign import ccall safe "hamk_hameqs_batch"
+  c_hameqs :: Ptr HamkSystem -> Int64 -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Int32
+           -> Int32 -> IO CInt
+foreign import ccall safe "hamk_rk4_steps"
+  c_rk4_steps :: Ptr HamkSystem -> Int64 -> Ptr Double -> Ptr Double -> Double -> Int32 -> Ptr Int32 -> Int32 -> IO CInt
+foreign import ccall safe "hamk_step_ham_batch"
+  c_step_ham :: Ptr HamkSystem -> Int64 -> Ptr Double -> Ptr Double -> Double -> Ptr Int32 -> Ptr Int32 -> Int32 -> IO CInt
+foreign import ccall safe "hamk_evolve_ham_batch"
+  c_evolve_ham :: Ptr HamkSystem -> Int64 -> Ptr Double -> Ptr Double -> Int32 -> Ptr Double -> Ptr Double -> Ptr Double
+               -> Double -> Double -> Double -> Ptr Int32 -> Ptr Int32 -> Int32 -> IO CInt
+foreign import ccall unsafe "hamk_last_error"
+  c_last_error :: IO CString
+
+memHost :: Int32
+memHost = 0
+
+check :: String -> CInt -> IO ()
+check what rc = when (rc /= 0) $ do
+  msg <- c_last_error >>= peekCString
+  -- the reference raises from pure code here (Hamilton.hs:425,444,462; hmatrix/GSL exceptions)
+  throwIO . ErrorCall $ what ++ ": libhamk error " ++ show rc ++ ": " ++ msg
+
+-- ---------------------------------------------------------------------------
+-- recording number type
+-- ---------------------------------------------------------------------------
+data UntraceableFunction = UntraceableFunction String deriving Show
+instance Exception UntraceableFunction
+
+-- | A traced value: either a late-bound constant or the id of a tape value.
+data Traced = K !Double | T !(IORef [Op]) !Int32
+
+opConst, opInput, opAdd, opSub, opMul, opDiv, opNeg, opRecip, opSin, opCos, opTan, opAsin, opAcos,
+  opAtan, opSinh, opCosh, opTanh, opExp, opLog, opSqrt, opPowC, opPowI, opPow, opAtan2, opAsinh,
+  opAcosh, opAtanh :: Int32
+[ opConst, opInput, opAdd, opSub, opMul, opDiv, opNeg, opRecip, opSin, opCos, opTan, opAsin, opAcos
+  , opAtan, opSinh, opCosh, opTanh, opExp, opLog, opSqrt, opPowC, opPowI, opPow, opAtan2, opAsinh
+  , opAcosh, opAtanh ] = [0 .. 26]
+
+emit :: IORef [Op] -> Op -> Int32
+emit ref o = unsafePerformIO $ atomicModifyIORef' ref $ \ops -> (ops ++ [o], fromIntegral (length ops))
+{-# NOINLINE emit #-}
+
+onTape :: IORef [Op] -> Traced -> Int32
+onTape ref (K c) = emit ref (Op opConst 0 0 c)
+onTape _ (T _ i) = i
+
+bin :: Int32 -> (Double -> Double -> Double) -> Traced -> Traced -> Traced
+bin _ f (K a) (K b) = K (f a b)
+bin o _ a b = let ref = tapeOf a b in T ref (emit ref (Op o (onTape ref a) (onTape ref b) 0))
+  where tapeOf (T r _) _ = r
+        tapeOf _ (T r _) = r
+        tapeOf _ _ = error "unreachable"
+
+un :: Int32 -> (Double -> Double) -> Traced -> Traced
+un _ f (K a) = K (f a)
+un o _ (T r i) = T r (emit r (Op o i 0 0))
+
+untraceable :: String -> a
+untraceable = throw . UntraceableFunction
+
+instance Num Traced where
+  (+) = bin opAdd (+)
+  (-) = bin opSub (-)
+  (*) = bin opMul (*)
+  negate = un opNeg negate
+  abs _ = untraceable "abs"
+  signum _ = untraceable "signum"
+  fromInteger = K . fromInteger
+
+instance Fractional Traced where
+  (/) = bin opDiv (/)
+  recip = un opRecip recip
+  fromRational = K . fromRational
+
+instance Floating Traced where
+  pi = K pi
+  exp = un opExp exp; log = un opLog log; sqrt = un opSqrt sqrt
+  sin = un opSin sin; cos = un opCos cos; tan = un opTan tan
+  asin = un opAsin asin; acos = un opAcos acos; atan = un opAtan atan
+  sinh = un opSinh sinh; cosh = un opCosh cosh; tanh = un opTanh tanh
+  asinh = un opAsinh asinh; acosh = un opAcosh acosh; atanh = un opAtanh atanh
+  K a ** K b = K (a ** b)
+  x@(T r i) ** K c
+    | c == fromIntegral (round c :: Int) && abs c <= 64 = T r (emit r (Op opPowI i (round c) 0))  -- x ** 2 with x < 0 (Examples.hs:154)
+    | otherwise = T r (emit r (Op opPowC i 0 c))
+  a ** b = bin opPow (**) a b
+
+instance Eq Traced where _ == _ = untraceable "(==)"
+instance Ord Traced where compare _ _ = untraceable "compare"
+instance Real Traced where toRational _ = untraceable "toRational"
+instance RealFrac Traced where properFraction _ = untraceable "properFraction"
+instance RealFloat Traced where
+  floatRadix _ = 2; floatDigits _ = 53; floatRange _ = (-1021, 1024)
+  decodeFloat _ = untraceable "decodeFloat"; encodeFloat m e = K (encodeFloat m e)
+  isNaN _ = untraceable "isNaN"; isInfinite _ = untraceable "isInfinite"
+  isDenormalized _ = untraceable "isDenormalized"; isNegativeZero _ = untraceable "isNegativeZero"
+  isIEEE _ = True
+  atan2 = bin opAtan2 atan2
+
+-- ---------------------------------------------------------------------------
+-- System construction
+-- ---------------------------------------------------------------------------
+-- | Opaque handle next to (not instead of) the reference's 'System' record.
+data HipSystem (m :: Nat) (n :: Nat) = HipSystem !(ForeignPtr HamkSystem)
+
+record :: Int -> ([Traced] -> [Traced]) -> IO ([Op], [Int32])
+record nIn fn = do
+  ref <- newIORef []
+  let ins = [T ref (emit ref (Op opInput (fromIntegral j) 0 0)) | j <- [0 .. nIn - 1]]
+  outs <- evaluate (map (onTape ref) (fn ins))
+  mapM_ evaluate outs
+  ops <- readIORef ref
+  return (ops, outs)
+
+create :: forall m n. (KnownNat m, KnownNat n)
+       => Int32 -> [Double] -> ([Traced] -> [Traced]) -> ([Traced] -> Traced) -> IO (HipSystem m n)
+create uSpace inertia f u = do
+  let m = fromIntegral (natVal (Proxy @m)); n = fromIntegral (natVal (Proxy @n))
+  (fOps, fOuts) <- record n f
+  (uOps, [uOut]) <- record (if uSpace == 1 then m else n) (pure . u)
+  withArrayLen inertia $ \_ pI -> withArrayLen fOps $ \nf pF -> withArray fOuts $ \pFO ->
+    withArrayLen uOps $ \nu pU -> alloca $ \pH -> do
+      c_system_create (fromIntegral m) (fromIntegral n) pI pF (fromIntegral nf) pFO
+                      pU (fromIntegral nu) uOut uSpace pH >>= check "mkSystem"
+      HipSystem <$> (peek pH >>= newForeignPtr p_system_destroy)
+
+-- | 'mkSystem' (Hamilton.hs:201-225): potential over generalized coordinates.
+traceSystem :: forall m n. (KnownNat m, KnownNat n)
+            => V.Vector m Double
+            -> (forall a. RealFloat a => V.Vector n a -> V.Vector m a)
+            -> (forall a. RealFloat a => V.Vector n a -> a)
+            -> IO (HipSystem m n)
+traceSystem w f u = create 0 (V.toList w) (V.toList . f . unsafeSized) (u . unsafeSized)
+
+-- | 'mkSystem'' (Hamilton.hs:238-254): potential over the underlying cartesian coordinates.
+traceSystem' :: forall m n. (KnownNat m, KnownNat n)
+             => V.Vector m Double
+             -> (forall a. RealFloat a => V.Vector n a -> V.Vector m a)
+             -> (forall a. RealFloat a => V.Vector m a -> a)
+             -> IO (HipSystem m n)
+traceSystem' w f u = create 1 (V.toList w) (V.toList . f . unsafeSized) (u . unsafeSized)
+
+unsafeSized :: forall k a. KnownNat k => [a] -> V.Vector k a
+unsafeSized xs = case V.fromList xs of
+  Just v -> v
+  Nothing -> error "Numeric.Hamilton.HIP: internal size mismatch"
+
+-- ---------------------------------------------------------------------------
+-- ensembles
+-- ---------------------------------------------------------------------------
+-- | B phases (or configs) of an n-coordinate system, structure of arrays:
+--   element (j*B + i) is coordinate j of trajectory i.
+data Ensemble (n :: Nat) = Ensemble
+  { ensSize :: !Int
+  , ensPositions :: !(VS.Vector Double)
+  , ensMomenta :: !(VS.Vector Double)   -- momenta of a phase / velocities of a config
+  }
+
+withEns :: Ensemble n -> (Int64 -> Ptr Double -> Ptr Double -> IO a) -> IO a
+withEns (Ensemble b q p) k = VS.unsafeWith q $ \pq -> VS.unsafeWith p $ \pp -> k (fromIntegral b) pq pp
+
+newOut :: Int -> IO (VSM.IOVector Double)
+newOut = VSM.new
+
+-- | 'toPhase' (Hamilton.hs:279-284) on an ensemble of configs.
+toPhaseBatch :: forall m n. KnownNat n => HipSystem m n -> Ensemble n -> IO (Ensemble n)
+toPhaseBatch (HipSystem h) e = withForeignPtr h $ \s -> withEns e $ \b pq pv -> do
+  out <- newOut (VS.length (ensPositions e))
+  VSM.unsafeWith out $ \po -> c_to_phase s b pq pv po memHost >>= check "toPhase"
+  Ensemble (ensSize e) (ensPositions e) <$> VS.unsafeFreeze out
+
+-- | 'fromPhase' (Hamilton.hs:332-337); also returns the per-trajectory status words.
+fromPhaseBatch :: forall m n. KnownNat n => HipSystem m n -> Ensemble n -> IO (Ensemble n, VS.Vector Int32)
+fromPhaseBatch (HipSystem h) e = withForeignPtr h $ \s -> withEns e $ \b pq pp -> do
+  out <- newOut (VS.length (ensPositions e)); st <- VSM.new (ensSize e)
+  VSM.unsafeWith out $ \po -> VSM.unsafeWith st $ \ps -> c_from_phase s b pq pp po ps memHost >>= check "fromPhase"
+  (,) <$> (Ensemble (ensSize e) (ensPositions e) <$> VS.unsafeFreeze out) <*> VS.unsafeFreeze st
+
+-- | 'hamEqs' (Hamilton.hs:370-387): (dH/dp, -dH/dq) for every member.
+hamEqsBatch :: forall m n. KnownNat n => HipSystem m n -> Ensemble n -> IO (VS.Vector Double, VS.Vector Double)
+hamEqsBatch (HipSystem h) e = withForeignPtr h $ \s -> withEns e $ \b pq pp -> do
+  dq <- newOut (VS.length (ensPositions e)); dp <- newOut (VS.length (ensPositions e))
+  VSM.unsafeWith dq $ \a -> VSM.unsafeWith dp $ \c -> c_hameqs s b pq pp a c nullPtr memHost >>= check "hamEqs"
+  (,) <$> VS.unsafeFreeze dq <*> VS.unsafeFreeze dp
+
+-- | 'hamiltonian' (Hamilton.hs:353-361).
+hamiltonianBatch :: forall m n. KnownNat n => HipSystem m n -> Ensemble n -> IO (VS.Vector Double)
+hamiltonianBatch (HipSystem h) e = withForeignPtr h $ \s -> withEns e $ \b pq pp -> do
+  out <- newOut (ensSize e)
+  VSM.unsafeWith out $ \po -> c_observe s b pq pp nullPtr nullPtr po nullPtr memHost >>= check "hamiltonian"
+  VS.unsafeFreeze out
+
+inPlace :: Ensemble n -> (Int64 -> Ptr Double -> Ptr Double -> IO CInt) -> String -> IO (Ensemble n)
+inPlace e k what = do
+  q <- VS.thaw (ensPositions e); p <- VS.thaw (ensMomenta e)
+  VSM.unsafeWith q $ \pq -> VSM.unsafeWith p $ \pp -> k (fromIntegral (ensSize e)) pq pp >>= check what
+  Ensemble (ensSize e) <$> VS.unsafeFreeze q <*> VS.unsafeFreeze p
+
+-- | 'stepHam' (Hamilton.hs:390-402) for every member: adaptive RKF45, GSL semantics.
+stepHamBatch :: forall m n. KnownNat n => Double -> HipSystem m n -> Ensemble n -> IO (Ensemble n)
+stepHamBatch r (HipSystem h) e = withForeignPtr h $ \s ->
+  inPlace e (\b pq pp -> c_step_ham s b pq pp r nullPtr nullPtr memHost) "stepHam"
+
+-- | Classic fixed-step RK4 (no counterpart in the reference; SURVEY.md F1).
+rk4StepsBatch :: forall m n. KnownNat n => Double -> Int -> HipSystem m n -> Ensemble n -> IO (Ensemble n)
+rk4StepsBatch dt k (HipSystem h) e = withForeignPtr h $ \s ->
+  inPlace e (\b pq pp -> c_rk4_steps s b pq pp dt (fromIntegral k) nullPtr memHost) "rk4Steps"
+
+-- | 'evolveHam' (Hamilton.hs:433-462) for every member: one ensemble per requested time,
+--   element 0 being the initial ensemble.
+evolveHamEnsemble :: forall m n. KnownNat n => HipSystem m n -> Ensemble n -> [Double] -> IO [Ensemble n]
+evolveHamEnsemble (HipSystem h) e ts
+  | length ts < 2 = throwIO (ErrorCall "evolveHam: at least two solution times required (2 <= s)")
+  | otherwise = withForeignPtr h $ \s -> withEns e $ \b pq pp -> withArrayLen ts $ \nt pts -> do
+      let cnt = VS.length (ensPositions e)
+      qo <- newOut (cnt * nt); po <- newOut (cnt * nt)
+      VSM.unsafeWith qo $ \a -> VSM.unsafeWith po $ \c ->
+        c_evolve_ham s b pq pp (fromIntegral nt) pts a c 0 0 0 nullPtr nullPtr memHost >>= check "evolveHam"
+      qf <- VS.unsafeFreeze qo; pf <- VS.unsafeFreeze po
+      return [Ensemble (ensSize e) (VS.slice (r * cnt) cnt qf) (VS.slice (r * cnt) cnt pf) | r <- [0 .. nt - 1]]

@@ -216,7 +216,7 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   s->desc.f_outs.assign(f_outs, f_outs + m);
   s->desc.u_ops.assign(u_ops, u_ops + u_nops);
   s->desc.u_out = u_out;
-  s->desc.mode_h = (n <= 2);
+  s->desc.mode_h = (n <= 3);     // measured on MI355X (scripts/sweep.py): H >= D up to n = 3, D ahead from n = 4
   if (const char* e = std::getenv("HAMK_AD_MODE")) {          // experiments: force "H" or "D"
     if (e[0] == 'H' || e[0] == 'h') s->desc.mode_h = true;
     if (e[0] == 'D' || e[0] == 'd') s->desc.mode_h = false;

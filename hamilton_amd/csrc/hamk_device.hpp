@@ -533,6 +533,19 @@ template <int N> HAMK_DEV void solve_lu(const double (&K)[N][N], const double (&
 }
 
 template <int N> HAMK_DEV void solve_spd(const double (&K)[N][N], const double (&p)[N], double (&v)[N], int& st) {
+  if constexpr (N == 1) {
+    v[0] = p[0] * frcp(K[0][0]);
+    if (!(K[0][0] > 0.0)) solve_lu<N>(K, p, v, st);
+    return;
+  } else if constexpr (N == 2) {
+    // adjugate form: one reciprocal instead of LDL^T's two (positive definite <=> K00 > 0, det > 0)
+    const double det = fma(K[0][0], K[1][1], -(K[0][1] * K[0][1]));
+    const double id = frcp(det);
+    v[0] = fma(K[1][1], p[0], -(K[0][1] * p[1])) * id;
+    v[1] = fma(K[0][0], p[1], -(K[0][1] * p[0])) * id;
+    if (!(K[0][0] > 0.0 && det > 0.0)) solve_lu<N>(K, p, v, st);
+    return;
+  }
   double a[N][N];   // lower triangle: L (unit diagonal implied); diagonal: 1/d_j
   bool ok = true;
 #pragma unroll

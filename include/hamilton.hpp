@@ -1,0 +1,364 @@
+// hamilton.hpp -- header-only C++17 host mirror of `Numeric.Hamilton` over the C ABI of
+// libhamk.so (include/hamk.h).
+//
+// The reference is compiled Haskell; its toolchain is absent from this image, so the host
+// side above the C ABI is written in C++ with the reference's own names and argument
+// meaning (src/Numeric/Hamilton.hs:28-70): mkSystem, mkSystem' (mkSystemP here), Config,
+// Phase, toPhase, fromPhase, momenta, velocities, keC, keP, pe, lagrangian, hamiltonian,
+// hamEqs, stepHam, evolveHam, evolveHam' (evolveHamL), stepHamC, evolveHamC, underlyingPos.
+// The extension over the reference: a Config/Phase holds an ENSEMBLE (B trajectories,
+// structure of arrays); B = 1 is the reference's case.
+//
+// User functions are written once against a generic number type `A` -- the C++ spelling of
+// `forall a. RealFloat a => V.Vector n a -> V.Vector m a` (Hamilton.hs:212):
+//
+//     auto f = [](const std::vector<hamilton::Var>& q) {            // generic lambda works too
+//       using hamilton::sin; using hamilton::cos;
+//       return std::vector<hamilton::Var>{sin(q[0]), 0.5 - cos(q[0])};
+//     };
+//
+// and are instantiated here at hamilton::Var, which records the expression tape that
+// crosses the ABI (the reference instantiates at ad's Forward/Sparse/Reverse types,
+// Hamilton.hs:220-224).
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "hamk.h"
+
+namespace hamilton {
+
+// ---------------------------------------------------------------------------------------
+// recording number type
+// ---------------------------------------------------------------------------------------
+class Tape {
+ public:
+  explicit Tape(int n_in) : n_in_(n_in) {}
+  int32_t emit(int32_t op, int32_t a = 0, int32_t b = 0, double c = 0.0) {
+    auto key = std::make_tuple(op, a, b, bits(c));
+    auto it = memo_.find(key);
+    if (it != memo_.end()) return it->second;           // hash-consing of identical subexpressions
+    hamk_op o{op, a, b, 0, c};
+    ops_.push_back(o);
+    int32_t id = (int32_t)ops_.size() - 1;
+    memo_[key] = id;
+    return id;
+  }
+  bool is_const(int32_t id, double* c = nullptr) const {
+    if (ops_[id].op != HAMK_OP_CONST) return false;
+    if (c) *c = ops_[id].c;
+    return true;
+  }
+  const std::vector<hamk_op>& ops() const { return ops_; }
+  int n_in() const { return n_in_; }
+
+ private:
+  static uint64_t bits(double c) { uint64_t u; std::memcpy(&u, &c, 8); return u; }
+  int n_in_;
+  std::vector<hamk_op> ops_;
+  std::map<std::tuple<int32_t, int32_t, int32_t, uint64_t>, int32_t> memo_;
+};
+
+class Var {
+ public:
+  Var() : tape_(nullptr), id_(-1), c_(0.0) {}
+  Var(double c) : tape_(nullptr), id_(-1), c_(c) {}          // realToFrac / fromInteger (late-bound constant)
+  Var(Tape* t, int32_t id) : tape_(t), id_(id), c_(0.0) {}
+  Tape* tape() const { return tape_; }
+  bool is_const(double* c = nullptr) const {
+    if (!tape_) { if (c) *c = c_; return true; }
+    return tape_->is_const(id_, c);
+  }
+  int32_t id_on(Tape* t) const {
+    if (!tape_) return t->emit(HAMK_OP_CONST, 0, 0, c_);
+    if (tape_ != t) throw std::logic_error("hamilton::Var: mixing values of two recordings");
+    return id_;
+  }
+
+ private:
+  Tape* tape_;
+  int32_t id_;
+  double c_;
+};
+
+namespace detail {
+inline Tape* tape_of(const Var& a, const Var& b) {
+  if (a.tape() && b.tape() && a.tape() != b.tape()) throw std::logic_error("hamilton::Var: mixing values of two recordings");
+  return a.tape() ? a.tape() : b.tape();
+}
+inline double powi(double x, int k) {
+  if (k < 0) return 1.0 / powi(x, -k);
+  double r = 1.0, b = x;
+  while (k) { if (k & 1) r *= b; b *= b; k >>= 1; }
+  return r;
+}
+inline Var binary(int32_t op, const Var& a, const Var& b) {
+  double ca, cb;
+  const bool ka = a.is_const(&ca), kb = b.is_const(&cb);
+  if (ka && kb) {
+    switch (op) {
+      case HAMK_OP_ADD: return Var(ca + cb);
+      case HAMK_OP_SUB: return Var(ca - cb);
+      case HAMK_OP_MUL: return Var(ca * cb);
+      default: return Var(ca / cb);
+    }
+  }
+  Tape* t = tape_of(a, b);
+  // exact identities only: never change a result bit
+  if (op == HAMK_OP_ADD) { if (ka && ca == 0.0) return b; if (kb && cb == 0.0) return a; }
+  if (op == HAMK_OP_SUB) { if (kb && cb == 0.0) return a; if (ka && ca == 0.0) return Var(t, t->emit(HAMK_OP_NEG, b.id_on(t))); }
+  if (op == HAMK_OP_MUL) {
+    if (ka && ca == 1.0) return b;
+    if (kb && cb == 1.0) return a;
+    if (ka && ca == -1.0) return Var(t, t->emit(HAMK_OP_NEG, b.id_on(t)));
+    if (kb && cb == -1.0) return Var(t, t->emit(HAMK_OP_NEG, a.id_on(t)));
+  }
+  if (op == HAMK_OP_DIV) {
+    if (kb && cb == 1.0) return a;
+    if (ka && ca == 1.0) return Var(t, t->emit(HAMK_OP_RECIP, b.id_on(t)));
+  }
+  int32_t ia = a.id_on(t), ib = b.id_on(t);
+  if ((op == HAMK_OP_ADD || op == HAMK_OP_MUL) && ia > ib) std::swap(ia, ib);
+  return Var(t, t->emit(op, ia, ib));
+}
+inline Var unary(int32_t op, const Var& x, double (*f)(double)) {
+  double c;
+  if (x.is_const(&c)) return Var(f(c));
+  return Var(x.tape(), x.tape()->emit(op, x.id_on(x.tape())));
+}
+}  // namespace detail
+
+inline Var operator+(const Var& a, const Var& b) { return detail::binary(HAMK_OP_ADD, a, b); }
+inline Var operator-(const Var& a, const Var& b) { return detail::binary(HAMK_OP_SUB, a, b); }
+inline Var operator*(const Var& a, const Var& b) { return detail::binary(HAMK_OP_MUL, a, b); }
+inline Var operator/(const Var& a, const Var& b) { return detail::binary(HAMK_OP_DIV, a, b); }
+inline Var operator-(const Var& a) { return detail::binary(HAMK_OP_SUB, Var(0.0), a); }
+inline Var operator+(const Var& a) { return a; }
+
+#define HAMILTON_UNARY(name, OP) \
+  inline Var name(const Var& x) { return detail::unary(OP, x, [](double v) { return std::name(v); }); }
+HAMILTON_UNARY(sin, HAMK_OP_SIN)
+HAMILTON_UNARY(cos, HAMK_OP_COS)
+HAMILTON_UNARY(tan, HAMK_OP_TAN)
+HAMILTON_UNARY(asin, HAMK_OP_ASIN)
+HAMILTON_UNARY(acos, HAMK_OP_ACOS)
+HAMILTON_UNARY(atan, HAMK_OP_ATAN)
+HAMILTON_UNARY(sinh, HAMK_OP_SINH)
+HAMILTON_UNARY(cosh, HAMK_OP_COSH)
+HAMILTON_UNARY(tanh, HAMK_OP_TANH)
+HAMILTON_UNARY(asinh, HAMK_OP_ASINH)
+HAMILTON_UNARY(acosh, HAMK_OP_ACOSH)
+HAMILTON_UNARY(atanh, HAMK_OP_ATANH)
+HAMILTON_UNARY(exp, HAMK_OP_EXP)
+HAMILTON_UNARY(log, HAMK_OP_LOG)
+HAMILTON_UNARY(sqrt, HAMK_OP_SQRT)
+#undef HAMILTON_UNARY
+
+// x ^ k (Haskell `^` / `^^`)
+inline Var powi(const Var& x, int k) {
+  double c;
+  if (x.is_const(&c)) return Var(detail::powi(c, k));
+  if (k == 0) return Var(1.0);
+  if (k == 1) return x;
+  return Var(x.tape(), x.tape()->emit(HAMK_OP_POWI, x.id_on(x.tape()), k));
+}
+// x ** y (Haskell `**`): constant integral exponents stay valid for negative bases (Examples.hs:154)
+inline Var pow(const Var& x, const Var& y) {
+  double cx, cy;
+  const bool kx = x.is_const(&cx), ky = y.is_const(&cy);
+  if (kx && ky) return Var(std::pow(cx, cy));
+  if (ky) {
+    if (cy == std::floor(cy) && std::fabs(cy) <= 64) return powi(x, (int)cy);
+    return Var(x.tape(), x.tape()->emit(HAMK_OP_POWC, x.id_on(x.tape()), 0, cy));
+  }
+  Tape* t = detail::tape_of(x, y);
+  return Var(t, t->emit(HAMK_OP_POW, x.id_on(t), y.id_on(t)));
+}
+inline Var atan2(const Var& y, const Var& x) {
+  double cy, cx;
+  if (y.is_const(&cy) && x.is_const(&cx)) return Var(std::atan2(cy, cx));
+  Tape* t = detail::tape_of(y, x);
+  return Var(t, t->emit(HAMK_OP_ATAN2, y.id_on(t), x.id_on(t)));
+}
+
+using VecFn = std::function<std::vector<Var>(const std::vector<Var>&)>;   // V.Vector n a -> V.Vector m a
+using ScalarFn = std::function<Var(const std::vector<Var>&)>;              // V.Vector k a -> a
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+struct HamkError : std::runtime_error {
+  int code;
+  HamkError(int c, const std::string& m) : std::runtime_error("libhamk error " + std::to_string(c) + ": " + m), code(c) {}
+};
+inline void check(int rc) { if (rc != HAMK_OK) throw HamkError(rc, hamk_last_error()); }
+
+// ---------------------------------------------------------------------------------------
+// states: SoA ensembles, host memory ([n][B])                      Hamilton.hs:103-145
+// ---------------------------------------------------------------------------------------
+struct Config { int n = 0; int64_t B = 0; std::vector<double> positions, velocities; };
+struct Phase  { int n = 0; int64_t B = 0; std::vector<double> positions, momenta; };
+
+inline Config Cfg(std::vector<double> q, std::vector<double> qd) {         // one trajectory
+  Config c; c.n = (int)q.size(); c.B = 1; c.positions = std::move(q); c.velocities = std::move(qd); return c;
+}
+inline Phase Phs(std::vector<double> q, std::vector<double> p) {
+  Phase s; s.n = (int)q.size(); s.B = 1; s.positions = std::move(q); s.momenta = std::move(p); return s;
+}
+
+// ---------------------------------------------------------------------------------------
+// System                                                            Hamilton.hs:160-254
+// ---------------------------------------------------------------------------------------
+class System {
+ public:
+  System(int m, int n, const std::vector<double>& inertia, const VecFn& f, const ScalarFn& u, int u_space)
+      : m_(m), n_(n) {
+    if ((int)inertia.size() != m) throw std::invalid_argument("inertia must have m entries");
+    Tape tf(n), tu(u_space == HAMK_U_CARTESIAN ? m : n);
+    std::vector<int32_t> f_outs = record(tf, n, [&](const std::vector<Var>& q) { return f(q); }, m);
+    std::vector<int32_t> u_outs = record(tu, tu.n_in(), [&](const std::vector<Var>& z) { return std::vector<Var>{u(z)}; }, 1);
+    hamk_system* h = nullptr;
+    check(hamk_system_create(m, n, inertia.data(), tf.ops().data(), (int32_t)tf.ops().size(), f_outs.data(),
+                             tu.ops().data(), (int32_t)tu.ops().size(), u_outs[0], u_space, &h));
+    h_.reset(h, hamk_system_destroy);
+  }
+  int m() const { return m_; }
+  int n() const { return n_; }
+  hamk_system* handle() const { return h_.get(); }
+  std::string source() const { return hamk_system_source(h_.get()); }
+  std::vector<int32_t> last_status;
+
+ private:
+  template <class F> static std::vector<int32_t> record(Tape& t, int n_in, F fn, int n_out) {
+    std::vector<Var> in;
+    for (int j = 0; j < n_in; ++j) in.emplace_back(&t, t.emit(HAMK_OP_INPUT, j));
+    std::vector<Var> out = fn(in);
+    if ((int)out.size() != n_out) throw std::invalid_argument("function returned the wrong number of values");
+    std::vector<int32_t> ids;
+    for (auto& v : out) ids.push_back(v.id_on(&t));
+    return ids;
+  }
+  int m_, n_;
+  std::shared_ptr<hamk_system> h_;
+};
+
+// mkSystem: potential over generalized coordinates                   Hamilton.hs:201-225
+inline System mkSystem(const std::vector<double>& inertia, int n, const VecFn& f, const ScalarFn& u) {
+  return System((int)inertia.size(), n, inertia, f, u, HAMK_U_GENERALIZED);
+}
+// mkSystem': potential over the underlying cartesian coordinates      Hamilton.hs:238-254
+inline System mkSystemP(const std::vector<double>& inertia, int n, const VecFn& f, const ScalarFn& u) {
+  return System((int)inertia.size(), n, inertia, f, u, HAMK_U_CARTESIAN);
+}
+
+// ---------------------------------------------------------------------------------------
+// state functions
+// ---------------------------------------------------------------------------------------
+inline std::vector<double> underlyingPos(const System& s, const std::vector<double>& q, int64_t B = 1) {   // :174-178
+  std::vector<double> x((size_t)s.m() * B);
+  check(hamk_coords_batch(s.handle(), B, q.data(), x.data(), HAMK_MEM_HOST));
+  return x;
+}
+inline std::vector<double> momenta(const System& s, const Config& c) {                                     // :262-269
+  std::vector<double> p((size_t)s.n() * c.B);
+  check(hamk_to_phase_batch(s.handle(), c.B, c.positions.data(), c.velocities.data(), p.data(), HAMK_MEM_HOST));
+  return p;
+}
+inline Phase toPhase(const System& s, const Config& c) {                                                   // :279-284
+  Phase ph; ph.n = c.n; ph.B = c.B; ph.positions = c.positions; ph.momenta = momenta(s, c); return ph;
+}
+inline std::vector<double> velocities(System& s, const Phase& ph) {                                        // :316-324
+  std::vector<double> v((size_t)s.n() * ph.B);
+  s.last_status.assign((size_t)ph.B, 0);
+  check(hamk_from_phase_batch(s.handle(), ph.B, ph.positions.data(), ph.momenta.data(), v.data(), s.last_status.data(), HAMK_MEM_HOST));
+  return v;
+}
+inline Config fromPhase(System& s, const Phase& ph) {                                                      // :332-337
+  Config c; c.n = ph.n; c.B = ph.B; c.positions = ph.positions; c.velocities = velocities(s, ph); return c;
+}
+namespace detail {
+inline std::vector<double> observe(System& s, const Phase& ph, int which) {
+  std::vector<double> out((size_t)ph.B);
+  s.last_status.assign((size_t)ph.B, 0);
+  check(hamk_observe_batch(s.handle(), ph.B, ph.positions.data(), which == 1 ? nullptr : ph.momenta.data(),
+                           which == 0 ? out.data() : nullptr, which == 1 ? out.data() : nullptr,
+                           which == 2 ? out.data() : nullptr, s.last_status.data(), HAMK_MEM_HOST));
+  return out;
+}
+inline std::vector<double> observe_config(const System& s, const Config& c, int which) {
+  std::vector<double> out((size_t)c.B);
+  check(hamk_observe_config_batch(s.handle(), c.B, c.positions.data(), c.velocities.data(),
+                                  which == 0 ? out.data() : nullptr, which == 1 ? out.data() : nullptr, HAMK_MEM_HOST));
+  return out;
+}
+}  // namespace detail
+inline std::vector<double> keP(System& s, const Phase& ph) { return detail::observe(s, ph, 0); }            // :341-349
+inline std::vector<double> pe(System& s, const std::vector<double>& q, int64_t B = 1) {                    // :182-186
+  Phase ph; ph.n = s.n(); ph.B = B; ph.positions = q; return detail::observe(s, ph, 1);
+}
+inline std::vector<double> hamiltonian(System& s, const Phase& ph) { return detail::observe(s, ph, 2); }    // :353-361
+inline std::vector<double> keC(const System& s, const Config& c) { return detail::observe_config(s, c, 0); }        // :288-296
+inline std::vector<double> lagrangian(const System& s, const Config& c) { return detail::observe_config(s, c, 1); } // :301-309
+
+// hamEqs: (dH/dp, -dH/dq)                                                                                  :370-387
+inline std::pair<std::vector<double>, std::vector<double>> hamEqs(System& s, const Phase& ph) {
+  std::vector<double> dq((size_t)s.n() * ph.B), dp((size_t)s.n() * ph.B);
+  s.last_status.assign((size_t)ph.B, 0);
+  check(hamk_hameqs_batch(s.handle(), ph.B, ph.positions.data(), ph.momenta.data(), dq.data(), dp.data(),
+                          s.last_status.data(), HAMK_MEM_HOST));
+  return {dq, dp};
+}
+
+// ---------------------------------------------------------------------------------------
+// time stepping
+// ---------------------------------------------------------------------------------------
+inline Phase stepHam(double r, System& s, const Phase& ph) {                                               // :390-402
+  Phase out = ph;
+  s.last_status.assign((size_t)ph.B, 0);
+  check(hamk_step_ham_batch(s.handle(), ph.B, out.positions.data(), out.momenta.data(), r, s.last_status.data(), nullptr, HAMK_MEM_HOST));
+  return out;
+}
+inline std::vector<Phase> evolveHam(System& s, const Phase& p0, const std::vector<double>& ts) {           // :433-462
+  if (ts.size() < 2) throw std::invalid_argument("evolveHam needs at least two solution times (2 <= s)");
+  const size_t cnt = (size_t)s.n() * p0.B;
+  std::vector<double> qo(cnt * ts.size()), po(cnt * ts.size());
+  s.last_status.assign((size_t)p0.B, 0);
+  check(hamk_evolve_ham_batch(s.handle(), p0.B, p0.positions.data(), p0.momenta.data(), (int32_t)ts.size(), ts.data(),
+                              qo.data(), po.data(), 0.0, 0.0, 0.0, s.last_status.data(), nullptr, HAMK_MEM_HOST));
+  std::vector<Phase> rows(ts.size());
+  for (size_t r = 0; r < ts.size(); ++r) {
+    rows[r].n = p0.n; rows[r].B = p0.B;
+    rows[r].positions.assign(qo.begin() + r * cnt, qo.begin() + (r + 1) * cnt);
+    rows[r].momenta.assign(po.begin() + r * cnt, po.begin() + (r + 1) * cnt);
+  }
+  return rows;
+}
+// evolveHam' (list front-end): [] -> []; [x] -> evolve over [0, x], drop the first        :409-429
+inline std::vector<Phase> evolveHamL(System& s, const Phase& p0, const std::vector<double>& ts) {
+  if (ts.empty()) return {};
+  if (ts.size() == 1) { auto rows = evolveHam(s, p0, {0.0, ts[0]}); rows.erase(rows.begin()); return rows; }
+  return evolveHam(s, p0, ts);
+}
+inline Config stepHamC(double r, System& s, const Config& c) { return fromPhase(s, stepHam(r, s, toPhase(s, c))); }   // :502-515
+inline std::vector<Config> evolveHamC(System& s, const Config& c0, const std::vector<double>& ts) {                    // :486-500
+  std::vector<Config> out;
+  for (auto& ph : evolveHam(s, toPhase(s, c0), ts)) out.push_back(fromPhase(s, ph));
+  return out;
+}
+// classic fixed-step RK4 (BASELINE.json north_star; no reference counterpart)
+inline Phase rk4Steps(double dt, int nsteps, System& s, const Phase& ph) {
+  Phase out = ph;
+  s.last_status.assign((size_t)ph.B, 0);
+  check(hamk_rk4_steps(s.handle(), ph.B, out.positions.data(), out.momenta.data(), dt, nsteps, s.last_status.data(), HAMK_MEM_HOST));
+  return out;
+}
+
+}  // namespace hamilton
