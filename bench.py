@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=1 << 20, help="trajectories per GPU")
     ap.add_argument("--rk4-per-step", type=int, default=100, help="RK4 steps fused into one launch")
     ap.add_argument("--dt", type=float, default=None)
+    ap.add_argument("--integrator", choices=["rk4", "stepham"], default="rk4",
+                    help="rk4: the BASELINE metric (hamk_rk4_steps).  stepham: the reference's own stepper "
+                         "(adaptive RKF45, Hamilton.hs:390-402), one stepHam(dt) per launch -- secondary figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the baseline leg")
     return ap.parse_args()
@@ -92,6 +95,32 @@ def cpu_baseline_leg(spec, s, dt, target_seconds):
     return base, parity
 
 
+def stepham_bench(a, s, spec, dt, state, dist, dev, rank, world):
+    """Secondary: stepHam(dt) calls/s over the ensemble (GSL-semantics adaptive RKF45 per lane)."""
+    ph = state
+    for _ in range(a.warmup):
+        ph = api.stepHam(dt, s, ph)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ph = api.stepHam(dt, s, ph)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    nsub = s.last_nsub.to(torch.float64)
+    if rank == 0:
+        B = a.batch
+        print(json.dumps({"metric": "stepHam calls/sec (ensemble, adaptive RKF45 GSL semantics)",
+                          "value": world * B * a.steps / el, "unit": "trajectory-stepHam/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+                          "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": f"{a.system} stepHam dt={dt}", "trajectories_per_gpu": B},
+                          "mean_substeps": float(nsub.mean()), "max_substeps": float(nsub.max()),
+                          "rhs_evals_per_s": world * B * a.steps * float(nsub.mean()) * 6 / el}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -124,6 +153,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.integrator == "stepham":
+        return stepham_bench(a, s, spec, dt, state, dist, dev, rank, world)
     for _ in range(a.warmup):
         api.rk4Steps(dt, a.rk4_per_step, s, state, inplace=True)
     barrier()

@@ -316,38 +316,39 @@ HAMK_DEV double val(double a) { return a; }
 // fdlibm k_sin.c / k_cos.c); quadrant fix-up on integer bits.  ~20 fp64 instructions,
 // <= 1 ulp.  |x| >= 2^20 * pi/2, NaN and Inf take the library path (rare, divergent).
 HAMK_DEV void sincos_f64(double x, double& s, double& c) {
-  if (fabs(x) < 1.6e6) {
-    const double k = rint(x * 6.36619772367581382433e-01);
-    double r = fma(-k, 1.57079632673412561417e+00, x);          // pi/2 bits  0..32
-    r = fma(-k, 6.07710050630396597660e-11, r);                  //          33..65
-    r = fma(-k, 2.02226624871116645580e-21, r);                  //          66..98
-    // power-basis accumulation (acc += coeff * z^k) instead of Horner: every step is a
-    // v_fmac with a dying accumulator, so no constant has to be copied into the
-    // accumulator register first, and the z^k chain runs beside the two sums.
-    const double z = r * r, z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z;
-    double ps = 1.58969099521155010221e-10 * z5;
-    ps = fma(-2.50507602534068634195e-08, z4, ps);
-    ps = fma(2.75573137070700676789e-06, z3, ps);
-    ps = fma(-1.98412698298579493134e-04, z2, ps);
-    ps = fma(8.33333333332248946124e-03, z, ps);
-    ps += -1.66666666666666324348e-01;
-    const double sr = fma(r * z, ps, r);
-    double pc = -1.13596475577881948265e-11 * z5;
-    pc = fma(2.08757232129817482790e-09, z4, pc);
-    pc = fma(-2.75573143513906633035e-07, z3, pc);
-    pc = fma(2.48015872894767294178e-05, z2, pc);
-    pc = fma(-1.38888888888741095749e-03, z, pc);
-    pc += 4.16666666666666019037e-02;
-    const double cr = fma(z, fma(z, pc, -0.5), 1.0);
-    const int q = (int)k;
-    const bool swap = (q & 1) != 0;
-    const double s0 = swap ? cr : sr;
-    const double c0 = swap ? sr : cr;
-    s = (q & 2) ? -s0 : s0;
-    c = ((q + 1) & 2) ? -c0 : c0;
-  } else {
-    ::sincos(x, &s, &c);
-  }
+  // fast path for every lane, unconditionally (one skip-branch around the rare slow path
+  // instead of an if/else diamond: half the scalar branch traffic in the inner loop)
+  const double k = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-k, 1.57079632673412561417e+00, x);          // pi/2 bits  0..32
+  r = fma(-k, 6.07710050630396597660e-11, r);                  //          33..65
+  r = fma(-k, 2.02226624871116645580e-21, r);                  //          66..98
+  // power-basis accumulation (acc += coeff * z^k) instead of Horner: every step is a
+  // v_fmac with a dying accumulator, so no constant has to be copied into the
+  // accumulator register first, and the z^k chain runs beside the two sums.
+  const double z = r * r, z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z;
+  double ps = 1.58969099521155010221e-10 * z5;
+  ps = fma(-2.50507602534068634195e-08, z4, ps);
+  ps = fma(2.75573137070700676789e-06, z3, ps);
+  ps = fma(-1.98412698298579493134e-04, z2, ps);
+  ps = fma(8.33333333332248946124e-03, z, ps);
+  ps += -1.66666666666666324348e-01;
+  const double sr = fma(r * z, ps, r);
+  double pc = -1.13596475577881948265e-11 * z5;
+  pc = fma(2.08757232129817482790e-09, z4, pc);
+  pc = fma(-2.75573143513906633035e-07, z3, pc);
+  pc = fma(2.48015872894767294178e-05, z2, pc);
+  pc = fma(-1.38888888888741095749e-03, z, pc);
+  pc += 4.16666666666666019037e-02;
+  const double cr = fma(z, fma(z, pc, -0.5), 1.0);
+  // quadrant: swap on bit 0; signs applied as XOR on the high dword (sin: bit 1 of q,
+  // cos: bit 1 of q+1) -- integer ops, no compares
+  const unsigned int q = (unsigned int)(int)k;
+  const bool swap = (q & 1u) != 0u;
+  const double s0 = swap ? cr : sr;
+  const double c0 = swap ? sr : cr;
+  s = __hiloint2double((int)((unsigned int)__double2hiint(s0) ^ ((q << 30) & 0x80000000u)), __double2loint(s0));
+  c = __hiloint2double((int)((unsigned int)__double2hiint(c0) ^ (((q + 1u) << 30) & 0x80000000u)), __double2loint(c0));
+  if (!(fabs(x) < 1.6e6)) ::sincos(x, &s, &c);                  // huge, NaN, Inf: library path
 }
 
 // 1/d for normal-range d: hardware estimate + two Newton steps (5 instructions instead
