@@ -346,3 +346,31 @@ def sample_config(spec: SystemSpec, start: int, count: int, seed: int = SEED):
         lo, hi = spec.qd_box[j]
         qd[j] = lo + (hi - lo) * uniform01(idx, 2 * j + 1, seed)
     return q, qd
+
+
+def opcode_zoo() -> SystemSpec:
+    """Not a physical example: a System 4 2 whose coordinate map and potential together use
+    EVERY tape opcode (include/hamk.h), so the parity tests exercise each derivative rule of
+    the device jets (value, gradient, second order) against the oracle's independent rules."""
+    def f(q, o):
+        a, b = q
+        e = o.exp(-(0.3 * a)) + o.log(2.0 + b * b)
+        t = o.tan(0.4 * a) + o.tanh(b) - o.atan(a * b)
+        h = o.sinh(0.5 * a) * o.cosh(0.25 * b) + o.sqrt(3.0 + a + b * b)
+        g = o.asin(0.3 * o.sin(a)) + o.acos(0.4 * o.cos(b)) + 1 / (2.5 + o.sin(a + b))
+        return [a + 0.1 * e, b + 0.1 * t, 0.2 * h + a * b / 3, 0.1 * g - b]
+
+    def u(q, o):
+        a, b = q
+        return (o.atan2(1.5 + a, 2.0 + b) + (2.0 + a) ** (1.3 + 0.1 * b) + (3.0 + b) ** 1.7 + (a - 0.2) ** 3
+                + (2.0 + a * a) ** (-2) + o.asinh(a - b) + o.acosh(2.0 + b * b) + o.atanh(0.3 * o.sin(a * b))
+                + 2.0 ** (0.5 * a) - a / (1.5 + b * b))
+
+    return SystemSpec(
+        name="opcodeZoo", m=4, n=2, inertia=(1.0, 2.0, 0.5, 1.5), f=f, u=u, u_space=U_GENERALIZED,
+        q0=(0.3, -0.2), qd0=(0.5, -0.4),
+        q_box=((-0.8, 0.8), (-0.8, 0.8)), qd_box=((-1.0, 1.0), (-1.0, 1.0)),
+        cite="build-defined (covers every hamk_opcode)")
+
+
+REGISTRY["opcodeZoo"] = opcode_zoo

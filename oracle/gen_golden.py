@@ -161,6 +161,7 @@ SYSTEMS = [
     ("bezier", (0.01, 0.1, 1.0)),
     ("threeBodyPolar", (0.002, 0.02)),
     ("chain4", ()),
+    ("opcodeZoo", ()),
 ]
 
 

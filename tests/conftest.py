@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 REFERENCE_SYSTEMS = ["pendulum", "doublePendulum", "room", "twoBody", "spring", "bezier"]
-ALL_GOLDEN_SYSTEMS = REFERENCE_SYSTEMS + ["threeBodyPolar", "chain4"]
+ALL_GOLDEN_SYSTEMS = REFERENCE_SYSTEMS + ["threeBodyPolar", "chain4", "opcodeZoo"]
 
 
 def pytest_configure(config):
