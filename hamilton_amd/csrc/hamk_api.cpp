@@ -223,6 +223,8 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   }
   s->desc.rk4_stage_loop = (n >= 7);
   if (const char* e = std::getenv("HAMK_RK4_LOOP")) s->desc.rk4_stage_loop = (e[0] == '1');
+  s->desc.rkf_stage_loop = (n >= 7);
+  if (const char* e = std::getenv("HAMK_RKF_LOOP")) s->desc.rkf_stage_loop = (e[0] == '1');
   s->source = generate_source(s->desc);
   int rc = compile_module(s);
   if (rc != HAMK_OK) { delete s; return rc; }

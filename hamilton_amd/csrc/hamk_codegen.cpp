@@ -137,6 +137,7 @@ std::string generate_source(const SystemDesc& d) {
   o << "  static constexpr bool U_CART = " << (d.u_space == HAMK_U_CARTESIAN ? "true" : "false") << ";\n";
   o << "  static constexpr bool MODE_H = " << (d.mode_h ? "true" : "false") << ";\n";
   o << "  static constexpr bool RK4_STAGE_LOOP = " << (d.rk4_stage_loop ? "true" : "false") << ";\n";
+  o << "  static constexpr bool RKF_STAGE_LOOP = " << (d.rkf_stage_loop ? "true" : "false") << ";\n";
   o << "  __device__ __forceinline__ static constexpr double inertia(int k) {\n";
   o << "    constexpr double w[M] = {";
   for (int k = 0; k < d.m; ++k) o << (k ? ", " : "") << lit(d.inertia[k]);

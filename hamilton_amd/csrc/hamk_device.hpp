@@ -348,7 +348,9 @@ HAMK_DEV void sincos_f64(double x, double& s, double& c) {
   const double c0 = swap ? sr : cr;
   s = __hiloint2double((int)((unsigned int)__double2hiint(s0) ^ ((q << 30) & 0x80000000u)), __double2loint(s0));
   c = __hiloint2double((int)((unsigned int)__double2hiint(c0) ^ (((q + 1u) << 30) & 0x80000000u)), __double2loint(c0));
-  if (!(fabs(x) < 1.6e6)) ::sincos(x, &s, &c);                  // huge, NaN, Inf: library path
+  // huge, NaN, Inf: library path.  Two calls, not ::sincos(x, &s, &c): the pointer form leaves an
+  // address-taken stack slot (scratch) in every kernel that inlines this.
+  if (!(fabs(x) < 1.6e6)) { s = ::sin(x); c = ::cos(x); }
 }
 
 // 1/d for normal-range d: hardware estimate + two Newton steps (5 instructions instead
@@ -590,7 +592,7 @@ template <int N> HAMK_DEV void solve_spd(const double (&K)[N][N], const double (
 
 // ===========================================================================
 // The System record's closures on one trajectory (Hamilton.hs:160-169).
-// S (generated): N, M, U_CART, MODE_H, RK4_STAGE_LOOP, NTRIG_F, NTRIG_U, inertia(k),
+// S (generated): N, M, U_CART, MODE_H, RK4_STAGE_LOOP, RKF_STAGE_LOOP, NTRIG_F, NTRIG_U, inertia(k),
 // coords<A, FILL>(q, x, trig_cache), potential<A, FILL>(z, trig_cache).
 // ===========================================================================
 template <class S> HAMK_DEV void seed1(const double (&q)[S::N], Jet1<S::N> (&qa)[S::N]) {
@@ -993,35 +995,113 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
       bool final_step = false;
       if ((dt >= 0.0 && hh > dt) || (dt < 0.0 && hh < dt)) { hh = dt; final_step = true; }
       // --- rkf45.c -----------------------------------------------------------
-      double k2[D], k3[D], k4[D], k5[D], k6[D], yt[D], yn[D], fn[D];
+      // RKF_STAGE_LOOP: one inlined copy of the right-hand side, run for the six evaluations of an
+      // attempt (k2..k6 and dydt_out) through a wave-uniform stage switch -- far less code for
+      // large systems; otherwise the six evaluations are unrolled (fewer registers for small n).
+      double k2[D], k3[D], k4[D], k5[D], k6[D], yn[D], fn[D];
 #pragma unroll
-      for (int j = 0; j < D; ++j) yt[j] = y[j] + (1.0 / 4.0) * hh * f0[j];
-      rhs<S>(yt, k2, st);
+      for (int j = 0; j < D; ++j) { k2[j] = k3[j] = k4[j] = k5[j] = k6[j] = 0.0; yn[j] = y[j]; fn[j] = 0.0; }
+      if constexpr (S::RKF_STAGE_LOOP) {
+#pragma unroll 1
+      for (int sg = 0; sg < 6; ++sg) {
+        double yt[D], out[D];
+        switch (sg) {
+          case 0:
 #pragma unroll
-      for (int j = 0; j < D; ++j) yt[j] = y[j] + hh * ((3.0 / 32.0) * f0[j] + (9.0 / 32.0) * k2[j]);
-      rhs<S>(yt, k3, st);
+            for (int j = 0; j < D; ++j) yt[j] = y[j] + (1.0 / 4.0) * hh * f0[j];
+            break;
+          case 1:
 #pragma unroll
-      for (int j = 0; j < D; ++j)
-        yt[j] = y[j] + hh * ((1932.0 / 2197.0) * f0[j] + (-7200.0 / 2197.0) * k2[j] + (7296.0 / 2197.0) * k3[j]);
-      rhs<S>(yt, k4, st);
+            for (int j = 0; j < D; ++j) yt[j] = y[j] + hh * ((3.0 / 32.0) * f0[j] + (9.0 / 32.0) * k2[j]);
+            break;
+          case 2:
 #pragma unroll
-      for (int j = 0; j < D; ++j)
-        yt[j] = y[j] + hh * ((8341.0 / 4104.0) * f0[j] + (-32832.0 / 4104.0) * k2[j] + (29440.0 / 4104.0) * k3[j] +
-                             (-845.0 / 4104.0) * k4[j]);
-      rhs<S>(yt, k5, st);
+            for (int j = 0; j < D; ++j)
+              yt[j] = y[j] + hh * ((1932.0 / 2197.0) * f0[j] + (-7200.0 / 2197.0) * k2[j] + (7296.0 / 2197.0) * k3[j]);
+            break;
+          case 3:
 #pragma unroll
-      for (int j = 0; j < D; ++j)
-        yt[j] = y[j] + hh * ((-6080.0 / 20520.0) * f0[j] + (41040.0 / 20520.0) * k2[j] + (-28352.0 / 20520.0) * k3[j] +
-                             (9295.0 / 20520.0) * k4[j] + (-5643.0 / 20520.0) * k5[j]);
-      rhs<S>(yt, k6, st);
+            for (int j = 0; j < D; ++j)
+              yt[j] = y[j] + hh * ((8341.0 / 4104.0) * f0[j] + (-32832.0 / 4104.0) * k2[j] +
+                                   (29440.0 / 4104.0) * k3[j] + (-845.0 / 4104.0) * k4[j]);
+            break;
+          case 4:
 #pragma unroll
-      for (int j = 0; j < D; ++j) {
-        const double di = (902880.0 / 7618050.0) * f0[j] + (3953664.0 / 7618050.0) * k3[j] +
-                          (3855735.0 / 7618050.0) * k4[j] + (-1371249.0 / 7618050.0) * k5[j] +
-                          (277020.0 / 7618050.0) * k6[j];
-        yn[j] = y[j] + hh * di;
+            for (int j = 0; j < D; ++j)
+              yt[j] = y[j] + hh * ((-6080.0 / 20520.0) * f0[j] + (41040.0 / 20520.0) * k2[j] +
+                                   (-28352.0 / 20520.0) * k3[j] + (9295.0 / 20520.0) * k4[j] +
+                                   (-5643.0 / 20520.0) * k5[j]);
+            break;
+          default:
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+              const double di = (902880.0 / 7618050.0) * f0[j] + (3953664.0 / 7618050.0) * k3[j] +
+                                (3855735.0 / 7618050.0) * k4[j] + (-1371249.0 / 7618050.0) * k5[j] +
+                                (277020.0 / 7618050.0) * k6[j];
+              yn[j] = y[j] + hh * di;
+              yt[j] = yn[j];
+            }
+            break;
+        }
+        rhs<S>(yt, out, st);
+        switch (sg) {
+          case 0:
+#pragma unroll
+            for (int j = 0; j < D; ++j) k2[j] = out[j];
+            break;
+          case 1:
+#pragma unroll
+            for (int j = 0; j < D; ++j) k3[j] = out[j];
+            break;
+          case 2:
+#pragma unroll
+            for (int j = 0; j < D; ++j) k4[j] = out[j];
+            break;
+          case 3:
+#pragma unroll
+            for (int j = 0; j < D; ++j) k5[j] = out[j];
+            break;
+          case 4:
+#pragma unroll
+            for (int j = 0; j < D; ++j) k6[j] = out[j];
+            break;
+          default:
+#pragma unroll
+            for (int j = 0; j < D; ++j) fn[j] = out[j];                  // dydt_out
+            break;
+        }
       }
-      rhs<S>(yn, fn, st);                              // dydt_out
+      } else {
+        double yt[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) yt[j] = y[j] + (1.0 / 4.0) * hh * f0[j];
+        rhs<S>(yt, k2, st);
+#pragma unroll
+        for (int j = 0; j < D; ++j) yt[j] = y[j] + hh * ((3.0 / 32.0) * f0[j] + (9.0 / 32.0) * k2[j]);
+        rhs<S>(yt, k3, st);
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+          yt[j] = y[j] + hh * ((1932.0 / 2197.0) * f0[j] + (-7200.0 / 2197.0) * k2[j] + (7296.0 / 2197.0) * k3[j]);
+        rhs<S>(yt, k4, st);
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+          yt[j] = y[j] + hh * ((8341.0 / 4104.0) * f0[j] + (-32832.0 / 4104.0) * k2[j] + (29440.0 / 4104.0) * k3[j] +
+                               (-845.0 / 4104.0) * k4[j]);
+        rhs<S>(yt, k5, st);
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+          yt[j] = y[j] + hh * ((-6080.0 / 20520.0) * f0[j] + (41040.0 / 20520.0) * k2[j] + (-28352.0 / 20520.0) * k3[j] +
+                               (9295.0 / 20520.0) * k4[j] + (-5643.0 / 20520.0) * k5[j]);
+        rhs<S>(yt, k6, st);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const double di = (902880.0 / 7618050.0) * f0[j] + (3953664.0 / 7618050.0) * k3[j] +
+                            (3855735.0 / 7618050.0) * k4[j] + (-1371249.0 / 7618050.0) * k5[j] +
+                            (277020.0 / 7618050.0) * k6[j];
+          yn[j] = y[j] + hh * di;
+        }
+        rhs<S>(yn, fn, st);                              // dydt_out
+      }
       // --- cstd.c: std_control_hadjust, ord = 5 ------------------------------
       double rmax = 2.2250738585072014e-308;
 #pragma unroll

@@ -12,6 +12,7 @@ struct SystemDesc {
   int m = 0, n = 0, u_space = 0;
   bool mode_h = true;
   bool rk4_stage_loop = false;
+  bool rkf_stage_loop = false;
   std::vector<double> inertia;
   std::vector<hamk_op> f_ops;
   std::vector<int32_t> f_outs;
