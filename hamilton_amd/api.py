@@ -177,6 +177,9 @@ class System:
     def code_size(self) -> int:
         return int(_abi.lib().hamk_system_code_size(self._h))
 
+    def kernel_bytes(self, kernel: str) -> int:
+        return int(_abi.lib().hamk_system_kernel_bytes(self._h, kernel.encode()))
+
     def synchronize(self):
         _abi.check(_abi.lib().hamk_synchronize(self._h))
 

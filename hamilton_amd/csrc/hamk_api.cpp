@@ -102,6 +102,33 @@ static int compile_module(hamk_system* s) {
   return HAMK_OK;
 }
 
+// Size in bytes of one kernel's machine code, read from the code object's ELF symbol table
+// (0 if not found).  Used to keep every kernel well inside the +-128 KiB reach of a SOPP
+// branch: beyond it the compiler must relax branches through s_setpc with spare SGPRs, and
+// the fully unrolled adaptive stepper of a large system was observed to misbehave there
+// (MI355X, ROCm 7.2: wrong sub-step counts on the 27-opcode test system).
+static size_t kernel_code_bytes(const std::vector<char>& elf, const char* name) {
+  struct Ehdr { unsigned char ident[16]; uint16_t type, machine; uint32_t version; uint64_t entry, phoff, shoff;
+                uint32_t flags; uint16_t ehsize, phentsize, phnum, shentsize, shnum, shstrndx; };
+  struct Shdr { uint32_t name, type; uint64_t flags, addr, offset, size; uint32_t link, info; uint64_t addralign, entsize; };
+  struct Sym { uint32_t name; unsigned char info, other; uint16_t shndx; uint64_t value, size; };
+  if (elf.size() < sizeof(Ehdr) || std::memcmp(elf.data(), "\177ELF", 4) != 0) return 0;
+  Ehdr eh; std::memcpy(&eh, elf.data(), sizeof eh);
+  if (eh.shoff == 0 || eh.shentsize != sizeof(Shdr)) return 0;
+  for (unsigned i = 0; i < eh.shnum; ++i) {
+    Shdr sh; std::memcpy(&sh, elf.data() + eh.shoff + (size_t)i * sizeof(Shdr), sizeof sh);
+    if (sh.type != 2 /* SHT_SYMTAB */ || sh.entsize != sizeof(Sym)) continue;
+    Shdr str; std::memcpy(&str, elf.data() + eh.shoff + (size_t)sh.link * sizeof(Shdr), sizeof str);
+    for (uint64_t k = 0; k < sh.size / sizeof(Sym); ++k) {
+      Sym sy; std::memcpy(&sy, elf.data() + sh.offset + k * sizeof(Sym), sizeof sy);
+      if ((sy.info & 0xf) != 2 /* STT_FUNC */) continue;
+      const char* nm = elf.data() + str.offset + sy.name;
+      if (std::strcmp(nm, name) == 0) return (size_t)sy.size;
+    }
+  }
+  return 0;
+}
+
 static int bind_device(hamk_system* s) {
   int dev = -1;
   hipError_t e = hipGetDevice(&dev);
@@ -223,11 +250,23 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   }
   s->desc.rk4_stage_loop = (n >= 7);
   if (const char* e = std::getenv("HAMK_RK4_LOOP")) s->desc.rk4_stage_loop = (e[0] == '1');
-  s->desc.rkf_stage_loop = (n >= 7);
+  s->desc.rkf_stage_loop = (n >= 4);
   if (const char* e = std::getenv("HAMK_RKF_LOOP")) s->desc.rkf_stage_loop = (e[0] == '1');
+  const bool forced_rk4 = std::getenv("HAMK_RK4_LOOP") != nullptr, forced_rkf = std::getenv("HAMK_RKF_LOOP") != nullptr;
   s->source = generate_source(s->desc);
   int rc = compile_module(s);
   if (rc != HAMK_OK) { delete s; return rc; }
+  // keep every kernel comfortably inside SOPP branch reach: fall back to the stage-loop bodies
+  const size_t kLimit = 64 * 1024;
+  const bool big_rkf = !forced_rkf && !s->desc.rkf_stage_loop && kernel_code_bytes(s->code, "hamk_rkf45_k") > kLimit;
+  const bool big_rk4 = !forced_rk4 && !s->desc.rk4_stage_loop && kernel_code_bytes(s->code, "hamk_rk4_steps_k") > kLimit;
+  if (big_rkf || big_rk4) {
+    if (big_rkf) s->desc.rkf_stage_loop = true;
+    if (big_rk4) s->desc.rk4_stage_loop = true;
+    s->source = generate_source(s->desc);
+    rc = compile_module(s);
+    if (rc != HAMK_OK) { delete s; return rc; }
+  }
   *out = s;
   return HAMK_OK;
 }
@@ -260,6 +299,9 @@ int hamk_synchronize(hamk_system* s) {
 
 const char* hamk_system_source(const hamk_system* s) { return s ? s->source.c_str() : nullptr; }
 int64_t hamk_system_code_size(const hamk_system* s) { return s ? (int64_t)s->code.size() : 0; }
+int64_t hamk_system_kernel_bytes(const hamk_system* s, const char* kernel_name) {
+  return (s && kernel_name) ? (int64_t)kernel_code_bytes(s->code, kernel_name) : 0;
+}
 
 int hamk_coords_batch(hamk_system* s, int64_t B, const double* q, double* x, int32_t mem) {
   TRY(check_call(s, B, mem));

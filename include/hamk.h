@@ -10,7 +10,7 @@
  *   mkSystem  :201-225 / mkSystem' :238-254             hamk_system_create
  *   System record :160-169 (opaque, GC-owned)           hamk_system (opaque handle) / hamk_system_destroy
  *   underlyingPos :174-178                              hamk_coords_batch
- *   pe            :182-186                              hamk_observe_batch (HAMK_OBS_PE)
+ *   pe            :182-186                              hamk_observe_batch (pe output)
  *   momenta :262-269, toPhase :279-284                  hamk_to_phase_batch
  *   velocities :316-324, fromPhase :332-337             hamk_from_phase_batch
  *   keC :288-296, lagrangian :301-309                   hamk_observe_config_batch
@@ -148,6 +148,8 @@ int hamk_synchronize(hamk_system* s);
 const char* hamk_system_source(const hamk_system* s);
 /* Number of bytes of gfx950 code object produced by the specialisation.     */
 int64_t hamk_system_code_size(const hamk_system* s);
+/* Machine-code bytes of one kernel of the module ("hamk_rk4_steps_k", ...); 0 if unknown. */
+int64_t hamk_system_kernel_bytes(const hamk_system* s, const char* kernel_name);
 
 /* ---- state functions ------------------------------------------------------ */
 

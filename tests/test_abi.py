@@ -86,3 +86,14 @@ def test_argument_checks(hamk_lib):
     with pytest.raises(ValueError):
         api.evolveHam(s, api.Phase(np.zeros(1), np.zeros(1)), [0.0])       # needs 2 <= s
     assert api.evolveHam_(s, api.Phase(np.zeros(1), np.zeros(1)), []) == []
+
+
+@pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS + ["chain8"])
+def test_kernels_stay_within_branch_reach(hamk_lib, name):
+    """Every kernel's machine code stays well inside the +-128 KiB reach of a SOPP branch
+    (libhamk falls back to the stage-loop bodies above 64 KiB; see hamk_api.cpp)."""
+    from hamilton_amd import api
+    s = api.system_from_spec(E.get(name))
+    for k in ("hamk_rk4_steps_k", "hamk_rkf45_k", "hamk_hameqs_k"):
+        nbytes = s.kernel_bytes(k)
+        assert 0 < nbytes < 100 * 1024, (name, k, nbytes)
