@@ -180,6 +180,10 @@ class System:
     def kernel_bytes(self, kernel: str) -> int:
         return int(_abi.lib().hamk_system_kernel_bytes(self._h, kernel.encode()))
 
+    @property
+    def num_device_functions(self) -> int:
+        return int(_abi.lib().hamk_system_kernel_bytes(self._h, None))
+
     def synchronize(self):
         _abi.check(_abi.lib().hamk_synchronize(self._h))
 

@@ -107,7 +107,10 @@ static int compile_module(hamk_system* s) {
 // branch: beyond it the compiler must relax branches through s_setpc with spare SGPRs, and
 // the fully unrolled adaptive stepper of a large system was observed to misbehave there
 // (MI355X, ROCm 7.2: wrong sub-step counts on the 27-opcode test system).
+// name == nullptr: returns the NUMBER of function symbols instead (8 kernels; more means a
+// device function was not inlined and is reached through a real call).
 static size_t kernel_code_bytes(const std::vector<char>& elf, const char* name) {
+  size_t nfunc = 0;
   struct Ehdr { unsigned char ident[16]; uint16_t type, machine; uint32_t version; uint64_t entry, phoff, shoff;
                 uint32_t flags; uint16_t ehsize, phentsize, phnum, shentsize, shnum, shstrndx; };
   struct Shdr { uint32_t name, type; uint64_t flags, addr, offset, size; uint32_t link, info; uint64_t addralign, entsize; };
@@ -122,11 +125,12 @@ static size_t kernel_code_bytes(const std::vector<char>& elf, const char* name) 
     for (uint64_t k = 0; k < sh.size / sizeof(Sym); ++k) {
       Sym sy; std::memcpy(&sy, elf.data() + sh.offset + k * sizeof(Sym), sizeof sy);
       if ((sy.info & 0xf) != 2 /* STT_FUNC */) continue;
+      ++nfunc;
       const char* nm = elf.data() + str.offset + sy.name;
-      if (std::strcmp(nm, name) == 0) return (size_t)sy.size;
+      if (name && std::strcmp(nm, name) == 0) return (size_t)sy.size;
     }
   }
-  return 0;
+  return name ? 0 : nfunc;
 }
 
 static int bind_device(hamk_system* s) {
@@ -300,7 +304,7 @@ int hamk_synchronize(hamk_system* s) {
 const char* hamk_system_source(const hamk_system* s) { return s ? s->source.c_str() : nullptr; }
 int64_t hamk_system_code_size(const hamk_system* s) { return s ? (int64_t)s->code.size() : 0; }
 int64_t hamk_system_kernel_bytes(const hamk_system* s, const char* kernel_name) {
-  return (s && kernel_name) ? (int64_t)kernel_code_bytes(s->code, kernel_name) : 0;
+  return s ? (int64_t)kernel_code_bytes(s->code, kernel_name) : 0;
 }
 
 int hamk_coords_batch(hamk_system* s, int64_t B, const double* q, double* x, int32_t mem) {

@@ -443,11 +443,13 @@ template <class A> HAMK_DEV A sqrt(const A& x) {
   return chain(x, r, g1, -0.5 * g1 / val(x));
 }
 
-HAMK_DEV double ipow(double x, int k) {     // k is a literal after inlining: folds to a multiply chain
-  if (k < 0) return 1.0 / ipow(x, -k);
+// k is a literal after inlining: folds to a multiply chain.  No recursion -- a recursive helper
+// is not inlined and becomes a real device function call (call frame in scratch).
+HAMK_DEV double ipow(double x, int k) {
+  unsigned int e = (k < 0) ? (unsigned int)(-(long long)k) : (unsigned int)k;
   double r = 1.0, b = x;
-  while (k) { if (k & 1) r *= b; b *= b; k >>= 1; }
-  return r;
+  while (e) { if (e & 1u) r *= b; b *= b; e >>= 1; }
+  return (k < 0) ? frcp(r) : r;
 }
 // x ^ K, integral K: valid for negative x (Examples.hs:154 `x ** 2` with x < 0)
 template <int K, class A> HAMK_DEV A powi(const A& x) {

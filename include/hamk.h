@@ -148,7 +148,9 @@ int hamk_synchronize(hamk_system* s);
 const char* hamk_system_source(const hamk_system* s);
 /* Number of bytes of gfx950 code object produced by the specialisation.     */
 int64_t hamk_system_code_size(const hamk_system* s);
-/* Machine-code bytes of one kernel of the module ("hamk_rk4_steps_k", ...); 0 if unknown. */
+/* Machine-code bytes of one kernel of the module ("hamk_rk4_steps_k", ...); 0 if unknown.
+ * kernel_name == NULL: number of function symbols in the module (8 = every device function
+ * was inlined into the 8 kernels).                                                          */
 int64_t hamk_system_kernel_bytes(const hamk_system* s, const char* kernel_name);
 
 /* ---- state functions ------------------------------------------------------ */

@@ -97,3 +97,6 @@ def test_kernels_stay_within_branch_reach(hamk_lib, name):
     for k in ("hamk_rk4_steps_k", "hamk_rkf45_k", "hamk_hameqs_k"):
         nbytes = s.kernel_bytes(k)
         assert 0 < nbytes < 100 * 1024, (name, k, nbytes)
+    # every device function inlined: no call frames, no scratch for calls (a recursive helper
+    # once slipped through as a real call and cost 120 VGPRs + spills in the adaptive stepper)
+    assert s.num_device_functions == 8, (name, s.num_device_functions)

@@ -323,7 +323,7 @@ def test_all_codegen_variants_agree(api, oracle_lib, name, monkeypatch):
             dq, dp = api.hamEqs(s, api.Phase(q, p))
             assert relerr(dq, odq) < 1e-11 and relerr(dp, odp) < 1e-11, (name, mode, loop, relerr(dp, odp))
             ph = api.rk4Steps(spec.dt, 3, s, api.Phase(q, p))
-            assert relerr(ph.positions, oq) < 1e-12 and relerr(ph.momenta, op) < 1e-12, (name, mode, loop)
+            assert relerr(ph.positions, oq) < 1e-11 and relerr(ph.momenta, op) < 1e-11, (name, mode, loop)
             st = api.stepHam(0.01, s, api.Phase(q, p))
             same = np.asarray(s.last_nsub) == sns          # identical accept/reject sequence as the oracle
             assert same.mean() > 0.9, (name, mode, loop, same.mean())
