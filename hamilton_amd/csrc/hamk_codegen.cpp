@@ -89,7 +89,7 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
   int nslots = 0;
   auto slot = [&](int operand) {
     if (slot_of[operand] < 0) slot_of[operand] = nslots++;
-    return std::string("tc.s[") + std::to_string(slot_of[operand]) + "], tc.c[" + std::to_string(slot_of[operand]) + "]";
+    return std::string("tc, ") + std::to_string(slot_of[operand]);
   };
   auto v = [&](int i) { return std::string(pfx) + std::to_string(i); };
   for (int i = 0; i < nops; ++i) {
@@ -113,10 +113,10 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
         const int si = sin_of[p.a], ci = cos_of[p.a];
         if (si >= 0 && ci >= 0 && (si == i || ci == i) && !done[si] && !done[ci]) {
           o << "hamk::bare_t<decltype(" << v(p.a) << ")> " << v(si) << ", " << v(ci)
-            << "; hamk::sincos<FILL>(" << v(p.a) << ", " << v(si) << ", " << v(ci) << ", " << slot(p.a) << ");\n";
+            << "; hamk::sincos<TRIG>(" << v(p.a) << ", " << v(si) << ", " << v(ci) << ", " << slot(p.a) << ");\n";
           done[si] = done[ci] = 1;
         } else {
-          o << "const auto " << v(i) << " = hamk::" << (p.op == HAMK_OP_SIN ? "sin" : "cos") << "<FILL>(" << v(p.a)
+          o << "const auto " << v(i) << " = hamk::" << (p.op == HAMK_OP_SIN ? "sin" : "cos") << "<TRIG>(" << v(p.a)
             << ", " << slot(p.a) << ");\n";
         }
       } break;
@@ -143,13 +143,13 @@ std::string generate_source(const SystemDesc& d) {
   for (int k = 0; k < d.m; ++k) o << (k ? ", " : "") << lit(d.inertia[k]);
   o << "};\n    return w[k];\n  }\n";
   // coordinate map f: generalized -> cartesian                       (_sysCoords, Hamilton.hs:220)
-  o << "  template <class A, bool FILL, class TC> __device__ __forceinline__ static void coords(const A (&in)[N], A (&x)[M], TC& tc) {\n";
+  o << "  template <class A, int TRIG, class TC> __device__ __forceinline__ static void coords(const A (&in)[N], A (&x)[M], TC& tc) {\n";
   const int ntrig_f = emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f");
   for (int k = 0; k < d.m; ++k) o << "    x[" << k << "] = hamk::lift<A>(f" << d.f_outs[k] << ");\n";
   o << "  }\n";
   // potential                                                         (_sysPotential, Hamilton.hs:223 / :254)
   const int nu = d.u_space == HAMK_U_CARTESIAN ? d.m : d.n;
-  o << "  template <class A, bool FILL, class TC> __device__ __forceinline__ static A potential(const A (&in)[" << nu << "], TC& tc) {\n";
+  o << "  template <class A, int TRIG, class TC> __device__ __forceinline__ static A potential(const A (&in)[" << nu << "], TC& tc) {\n";
   const int ntrig_u = emit_body(o, d.u_ops.data(), (int)d.u_ops.size(), "u");
   o << "    return hamk::lift<A>(u" << d.u_out << ");\n";
   o << "  }\n";

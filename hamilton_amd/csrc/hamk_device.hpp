@@ -375,23 +375,65 @@ template <int N> HAMK_DEV Jet2<N> operator/(double c, const Jet2<N>& b) { return
 
 // sin and cos of one argument always come as a pair (codegen fuses the tape's
 // SIN/COS of a shared operand): one fp64 sincos feeds value, gradient and Hessian.
-// The primal pair lives in a per-evaluation TrigCache slot: the sweep that runs first
-// (FILL) computes it, later sweeps of the same point (the Jet2 sweep of MODE_D) reuse
-// it -- the compiler cannot merge two inlined copies of a routine that branches.
-template <int NS> struct TrigCache { double s[NS > 0 ? NS : 1], c[NS > 0 ? NS : 1]; };
+// The primal pair lives in a TrigCache slot, filled according to the sweep's TRIG mode:
+//   TRIG_FULL    evaluate sincos_f64 at the operand, keep the pair for later sweeps
+//   TRIG_REUSE   same point as the previous sweep (the Jet2 sweep of MODE_D): read the pair;
+//                the compiler cannot merge two inlined copies of a branching routine
+//   TRIG_ANCHOR  as FULL, and remember (operand, sin, cos) as this site's anchor
+//   TRIG_INCR    the operand is close to the anchor (an RK stage point y + a h k next to y):
+//                rotate the anchor pair by delta = operand - anchor with short Taylor kernels
+//                (|delta| < 1/8: 23 fp64 instructions, no range reduction, no integer
+//                quadrant logic, absolute error < 3e-18 + rounding); otherwise as FULL.
+//                Always relative to the anchor of the current step, so nothing accumulates.
+enum : int { TRIG_FULL = 0, TRIG_REUSE = 1, TRIG_ANCHOR = 2, TRIG_INCR = 3 };
 
-template <bool FILL, class A> HAMK_DEV void sincos(const A& x, A& s, A& c, double& cs, double& cc) {
-  if constexpr (FILL) sincos_f64(val(x), cs, cc);
-  s = chain(x, cs, cc, -cs);
-  c = chain(x, cc, -cs, -cc);
+template <int NS> struct TrigCache {
+  double s[NS > 0 ? NS : 1], c[NS > 0 ? NS : 1];                           // current point
+  double ax[NS > 0 ? NS : 1], as[NS > 0 ? NS : 1], ac[NS > 0 ? NS : 1];    // anchor
+};
+
+HAMK_DEV void sincos_incr(double x, double xa, double sa, double ca, double& s, double& c) {
+  const double d = x - xa;
+  const double z = d * d, z2 = z * z, z3 = z2 * z, z4 = z2 * z2;
+  double ps = (1.0 / 362880.0) * z3;
+  ps = fma(-1.0 / 5040.0, z2, ps);
+  ps = fma(1.0 / 120.0, z, ps);
+  ps += -1.0 / 6.0;
+  const double sd = fma(d * z, ps, d);                    // sin(delta)
+  double pc = (-1.0 / 3628800.0) * z4;
+  pc = fma(1.0 / 40320.0, z3, pc);
+  pc = fma(-1.0 / 720.0, z2, pc);
+  pc = fma(1.0 / 24.0, z, pc);
+  pc += -0.5;
+  const double cm1 = z * pc;                              // cos(delta) - 1
+  s = sa + fma(sa, cm1, ca * sd);
+  c = ca + fma(ca, cm1, -(sa * sd));
+  if (!(fabs(d) < 0.125)) sincos_f64(x, s, c);            // far from the anchor (or NaN): full evaluation
 }
-template <bool FILL, class A> HAMK_DEV A sin(const A& x, double& cs, double& cc) {
-  if constexpr (FILL) sincos_f64(val(x), cs, cc);
-  return chain(x, cs, cc, -cs);
+
+template <int MODE, class TC> HAMK_DEV void trig_pair(double x, TC& tc, int k) {
+  if constexpr (MODE == TRIG_FULL) {
+    sincos_f64(x, tc.s[k], tc.c[k]);
+  } else if constexpr (MODE == TRIG_ANCHOR) {
+    sincos_f64(x, tc.s[k], tc.c[k]);
+    tc.ax[k] = x; tc.as[k] = tc.s[k]; tc.ac[k] = tc.c[k];
+  } else if constexpr (MODE == TRIG_INCR) {
+    sincos_incr(x, tc.ax[k], tc.as[k], tc.ac[k], tc.s[k], tc.c[k]);
+  }
 }
-template <bool FILL, class A> HAMK_DEV A cos(const A& x, double& cs, double& cc) {
-  if constexpr (FILL) sincos_f64(val(x), cs, cc);
-  return chain(x, cc, -cs, -cc);
+
+template <int MODE, class A, class TC> HAMK_DEV void sincos(const A& x, A& s, A& c, TC& tc, int k) {
+  trig_pair<MODE>(val(x), tc, k);
+  s = chain(x, tc.s[k], tc.c[k], -tc.s[k]);
+  c = chain(x, tc.c[k], -tc.s[k], -tc.c[k]);
+}
+template <int MODE, class A, class TC> HAMK_DEV A sin(const A& x, TC& tc, int k) {
+  trig_pair<MODE>(val(x), tc, k);
+  return chain(x, tc.s[k], tc.c[k], -tc.s[k]);
+}
+template <int MODE, class A, class TC> HAMK_DEV A cos(const A& x, TC& tc, int k) {
+  trig_pair<MODE>(val(x), tc, k);
+  return chain(x, tc.c[k], -tc.s[k], -tc.c[k]);
 }
 template <class A> HAMK_DEV A tan(const A& x) {
   const double t = ::tan(val(x)); const double d = fma(t, t, 1.0);
@@ -595,7 +637,7 @@ template <int N> HAMK_DEV void solve_spd(const double (&K)[N][N], const double (
 // ===========================================================================
 // The System record's closures on one trajectory (Hamilton.hs:160-169).
 // S (generated): N, M, U_CART, MODE_H, RK4_STAGE_LOOP, RKF_STAGE_LOOP, NTRIG_F, NTRIG_U, inertia(k),
-// coords<A, FILL>(q, x, trig_cache), potential<A, FILL>(z, trig_cache).
+// coords<A, TRIG>(q, x, trig_cache), potential<A, TRIG>(z, trig_cache).
 // ===========================================================================
 template <class S> HAMK_DEV void seed1(const double (&q)[S::N], Jet1<S::N> (&qa)[S::N]) {
 #pragma unroll
@@ -625,8 +667,8 @@ template <class S> HAMK_DEV void grad_potential(const Jet1<S::N> (&qj)[S::N], co
                                                 double (&gU)[S::N], double& U) {
   Jet1<S::N> u;
   TrigCache<S::NTRIG_U> tu;
-  if constexpr (S::U_CART) u = S::template potential<Jet1<S::N>, true>(xj, tu);
-  else u = S::template potential<Jet1<S::N>, true>(qj, tu);
+  if constexpr (S::U_CART) u = S::template potential<Jet1<S::N>, TRIG_FULL>(xj, tu);
+  else u = S::template potential<Jet1<S::N>, TRIG_FULL>(qj, tu);
   U = u.v;
 #pragma unroll
   for (int i = 0; i < S::N; ++i) gU[i] = u.d[i];
@@ -638,7 +680,7 @@ template <class S> HAMK_DEV void momenta(const double (&q)[S::N], const double (
   Jet1<N> qj[N], xj[M];
   TrigCache<S::NTRIG_F> tc;
   seed1<S>(q, qj);
-  S::template coords<Jet1<N>, true>(qj, xj, tc);
+  S::template coords<Jet1<N>, TRIG_FULL>(qj, xj, tc);
   double w[M];
 #pragma unroll
   for (int k = 0; k < M; ++k) {
@@ -662,7 +704,7 @@ template <class S> HAMK_DEV void velocities(const double (&q)[S::N], const doubl
   Jet1<N> qj[N], xj[M];
   TrigCache<S::NTRIG_F> tc;
   seed1<S>(q, qj);
-  S::template coords<Jet1<N>, true>(qj, xj, tc);
+  S::template coords<Jet1<N>, TRIG_FULL>(qj, xj, tc);
   double K[N][N];
   mass_matrix<S>(xj, K);
   solve_spd<N>(K, p, qd, st);
@@ -673,10 +715,10 @@ template <class S> HAMK_DEV double potential_value(const double (&q)[S::N]) {
   if constexpr (S::U_CART) {
     double x[S::M];
     TrigCache<S::NTRIG_F> tc;
-    S::template coords<double, true>(q, x, tc);
-    return S::template potential<double, true>(x, tu);
+    S::template coords<double, TRIG_FULL>(q, x, tc);
+    return S::template potential<double, TRIG_FULL>(x, tu);
   } else {
-    return S::template potential<double, true>(q, tu);
+    return S::template potential<double, TRIG_FULL>(q, tu);
   }
 }
 
@@ -692,11 +734,11 @@ template <class S> HAMK_DEV double potential_value(const double (&q)[S::N]) {
 // Both use dT/dq_i = -(M J qd) . ((dJ/dq_i) qd), which equals the reference's
 // -(p . K^-1 J^T M (dJ/dq_i) K^-1 p) because K^-1 is symmetric and qd = K^-1 p.
 // ---------------------------------------------------------------------------
-template <class S, bool MODE_H>
-HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (&dq)[S::N], double (&dp)[S::N], int& st) {
+template <class S, bool MODE_H, int TRIG = TRIG_FULL>
+HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (&dq)[S::N], double (&dp)[S::N], int& st,
+                      TrigCache<S::NTRIG_F>& tc) {
   constexpr int N = S::N, M = S::M;
   double K[N][N], gU[N], U, v[N], dT[N];
-  TrigCache<S::NTRIG_F> tc;
   if constexpr (MODE_H) {
     JetH<N> qh[N], xh[M];
 #pragma unroll
@@ -704,7 +746,7 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
       qh[j] = lift<JetH<N>>(q[j]);
       qh[j].d[j] = 1.0;
     }
-    S::template coords<JetH<N>, true>(qh, xh, tc);
+    S::template coords<JetH<N>, TRIG>(qh, xh, tc);
     Jet1<N> qj[N], xj[M];
     seed1<S>(q, qj);
 #pragma unroll
@@ -735,7 +777,7 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
   } else {
     Jet1<N> qj[N], xj[M];
     seed1<S>(q, qj);
-    S::template coords<Jet1<N>, true>(qj, xj, tc);
+    S::template coords<Jet1<N>, TRIG>(qj, xj, tc);
     mass_matrix<S>(xj, K);
     solve_spd<N>(K, p, v, st);
     grad_potential<S>(qj, xj, gU, U);
@@ -746,7 +788,7 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
       q2[j].d[j] = 1.0;
       q2[j].dv = v[j];
     }
-    S::template coords<Jet2<N>, false>(q2, x2, tc);       // primal sincos pairs from the first sweep
+    S::template coords<Jet2<N>, TRIG_REUSE>(q2, x2, tc);  // primal sincos pairs from the first sweep
 #pragma unroll
     for (int i = 0; i < N; ++i) dT[i] = 0.0;
 #pragma unroll
@@ -763,12 +805,21 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
   }
 }
 
-template <class S> HAMK_DEV void rhs(const double (&y)[2 * S::N], double (&dy)[2 * S::N], int& st) {
+// TRIG_INCR pays only where sincos is a large share of the right-hand side and the anchors fit
+// in registers; elsewhere the stage evaluations stay TRIG_FULL.
+template <class S> struct StageTrig {
+  static constexpr bool on = (S::NTRIG_F >= 1 && S::NTRIG_F <= 4);
+  static constexpr int anchor = on ? TRIG_ANCHOR : TRIG_FULL;
+  static constexpr int incr = on ? TRIG_INCR : TRIG_FULL;
+};
+
+template <class S, int TRIG = TRIG_FULL>
+HAMK_DEV void rhs(const double (&y)[2 * S::N], double (&dy)[2 * S::N], int& st, TrigCache<S::NTRIG_F>& tc) {
   constexpr int N = S::N;
   double q[N], p[N], dq[N], dp[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) { q[i] = y[i]; p[i] = y[N + i]; }
-  ham_eqs<S, S::MODE_H>(q, p, dq, dp, st);
+  ham_eqs<S, S::MODE_H, TRIG>(q, p, dq, dp, st, tc);
 #pragma unroll
   for (int i = 0; i < N; ++i) { dy[i] = dq[i]; dy[N + i] = dp[i]; }
 }
@@ -800,6 +851,7 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
 #pragma unroll
   for (int j = 0; j < N; ++j) { y[j] = q[(i64)j * B + i]; y[N + j] = p[(i64)j * B + i]; }
   int st = 0;
+  TrigCache<S::NTRIG_F> tc;
   const double h2 = 0.5 * dt, h6 = dt * (1.0 / 6.0), h3 = dt * (1.0 / 3.0);
   if constexpr (S::RK4_STAGE_LOOP) {
     // one copy of the right-hand side, executed 4 x nsteps times: keeps the live set to a
@@ -815,7 +867,7 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
       double yt[D];
 #pragma unroll
       for (int j = 0; j < D; ++j) yt[j] = fma(a, k[j], y[j]);
-      rhs<S>(yt, k, st);
+      rhs<S>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) acc[j] = fma(b, k[j], acc[j]);
       if (sg == 3) {
@@ -827,16 +879,18 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
       double k[D], yt[D], acc[D];
-      rhs<S>(y, k, st);
+      // stage 1 evaluates sincos in full and anchors it; stages 2-4 sit at y + a dt k, a few
+      // hundredths of a radian away, and rotate the anchor pair instead (TRIG_INCR)
+      rhs<S, StageTrig<S>::anchor>(y, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) { acc[j] = fma(h6, k[j], y[j]); yt[j] = fma(h2, k[j], y[j]); }
-      rhs<S>(yt, k, st);
+      rhs<S, StageTrig<S>::incr>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) { acc[j] = fma(h3, k[j], acc[j]); yt[j] = fma(h2, k[j], y[j]); }
-      rhs<S>(yt, k, st);
+      rhs<S, StageTrig<S>::incr>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) { acc[j] = fma(h3, k[j], acc[j]); yt[j] = fma(dt, k[j], y[j]); }
-      rhs<S>(yt, k, st);
+      rhs<S, StageTrig<S>::incr>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) y[j] = fma(h6, k[j], acc[j]);
     }
@@ -863,7 +917,8 @@ HAMK_DEV void hameqs_body(const double* __restrict__ q, const double* __restrict
 #pragma unroll
   for (int j = 0; j < N; ++j) { qq[j] = q[(i64)j * B + i]; pp[j] = p[(i64)j * B + i]; }
   int st = 0;
-  ham_eqs<S, S::MODE_H>(qq, pp, a, b, st);
+  TrigCache<S::NTRIG_F> tc;
+  ham_eqs<S, S::MODE_H>(qq, pp, a, b, st, tc);
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -883,7 +938,7 @@ template <class S> HAMK_DEV void coords_body(const double* __restrict__ q, doubl
 #pragma unroll
   for (int j = 0; j < S::N; ++j) qq[j] = q[(i64)j * B + i];
   TrigCache<S::NTRIG_F> tc;
-  S::template coords<double, true>(qq, xx, tc);
+  S::template coords<double, TRIG_FULL>(qq, xx, tc);
 #pragma unroll
   for (int k = 0; k < S::M; ++k) x[(i64)k * B + i] = lift<double>(xx[k]);
 }
@@ -987,7 +1042,11 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
   }
   int st = 0, attempts = 0;
   double t = ts[0], h = h0;
-  rhs<S>(y, f0, st);                                   // dydt_in at the initial state
+  TrigCache<S::NTRIG_F> tc;
+  // sincos anchors follow dydt_in/dydt_out: the stage points of an attempt sit within h |f| of
+  // the point where dydt_in was evaluated (after a rejection: of the rejected end point, still
+  // close; TRIG_INCR falls back to the full evaluation when it is not)
+  rhs<S, StageTrig<S>::anchor>(y, f0, st, tc);        // dydt_in at the initial state
   for (int r = 1; r < nt; ++r) {
     const double ti = ts[r];
     while (t < ti && attempts < max_sub) {
@@ -1045,7 +1104,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
             }
             break;
         }
-        rhs<S>(yt, out, st);
+        rhs<S>(yt, out, st, tc);
         switch (sg) {
           case 0:
 #pragma unroll
@@ -1077,24 +1136,24 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
         double yt[D];
 #pragma unroll
         for (int j = 0; j < D; ++j) yt[j] = y[j] + (1.0 / 4.0) * hh * f0[j];
-        rhs<S>(yt, k2, st);
+        rhs<S, StageTrig<S>::incr>(yt, k2, st, tc);
 #pragma unroll
         for (int j = 0; j < D; ++j) yt[j] = y[j] + hh * ((3.0 / 32.0) * f0[j] + (9.0 / 32.0) * k2[j]);
-        rhs<S>(yt, k3, st);
+        rhs<S, StageTrig<S>::incr>(yt, k3, st, tc);
 #pragma unroll
         for (int j = 0; j < D; ++j)
           yt[j] = y[j] + hh * ((1932.0 / 2197.0) * f0[j] + (-7200.0 / 2197.0) * k2[j] + (7296.0 / 2197.0) * k3[j]);
-        rhs<S>(yt, k4, st);
+        rhs<S, StageTrig<S>::incr>(yt, k4, st, tc);
 #pragma unroll
         for (int j = 0; j < D; ++j)
           yt[j] = y[j] + hh * ((8341.0 / 4104.0) * f0[j] + (-32832.0 / 4104.0) * k2[j] + (29440.0 / 4104.0) * k3[j] +
                                (-845.0 / 4104.0) * k4[j]);
-        rhs<S>(yt, k5, st);
+        rhs<S, StageTrig<S>::incr>(yt, k5, st, tc);
 #pragma unroll
         for (int j = 0; j < D; ++j)
           yt[j] = y[j] + hh * ((-6080.0 / 20520.0) * f0[j] + (41040.0 / 20520.0) * k2[j] + (-28352.0 / 20520.0) * k3[j] +
                                (9295.0 / 20520.0) * k4[j] + (-5643.0 / 20520.0) * k5[j]);
-        rhs<S>(yt, k6, st);
+        rhs<S, StageTrig<S>::incr>(yt, k6, st, tc);
 #pragma unroll
         for (int j = 0; j < D; ++j) {
           const double di = (902880.0 / 7618050.0) * f0[j] + (3953664.0 / 7618050.0) * k3[j] +
@@ -1102,7 +1161,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
                             (277020.0 / 7618050.0) * k6[j];
           yn[j] = y[j] + hh * di;
         }
-        rhs<S>(yn, fn, st);                              // dydt_out
+        rhs<S, StageTrig<S>::anchor>(yn, fn, st, tc);      // dydt_out (next attempt's anchor)
       }
       // --- cstd.c: std_control_hadjust, ord = 5 ------------------------------
       double rmax = 2.2250738585072014e-308;
