@@ -23,6 +23,9 @@ using namespace hamk_host;
 static const char kDeviceHeader[] =
 #include "hamk_device_src.inc"
     ;
+static const char kWaveHeader[] =
+#include "hamk_wave_src.inc"
+    ;
 
 static thread_local std::string g_last_error;
 
@@ -63,9 +66,9 @@ struct hamk_system {
 // ---------------------------------------------------------------------------
 static int compile_module(hamk_system* s) {
   hiprtcProgram prog = nullptr;
-  const char* hdr_src[] = {kDeviceHeader};
-  const char* hdr_name[] = {"hamk_device.hpp"};
-  hiprtcResult r = hiprtcCreateProgram(&prog, s->source.c_str(), "hamk_system.hip", 1, hdr_src, hdr_name);
+  const char* hdr_src[] = {kDeviceHeader, kWaveHeader};
+  const char* hdr_name[] = {"hamk_device.hpp", "hamk_wave.hpp"};
+  hiprtcResult r = hiprtcCreateProgram(&prog, s->source.c_str(), "hamk_system.hip", 2, hdr_src, hdr_name);
   if (r != HIPRTC_SUCCESS) return fail(HAMK_ERR_COMPILE, std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r));
   std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast",
                                    "-fno-honor-nans", "-fno-signed-zeros"};
@@ -155,7 +158,10 @@ static int bind_device(hamk_system* s) {
 
 static int launch(hamk_system* s, KernelId k, int64_t B, void** args) {
   const unsigned block = 256;
-  const int64_t grid = (B + block - 1) / block;
+  // lane kernels: one trajectory per thread; wave kernels: 64/NP trajectories per wavefront
+  int64_t per_block = block;
+  if (s->desc.wave && k != K_RKF45) per_block = 4 * (64 / (s->desc.n <= 16 ? 16 : 32));
+  const int64_t grid = (B + per_block - 1) / per_block;
   if (grid > 0x7fffffffLL) return fail(HAMK_ERR_INVALID, "ensemble too large for one launch");
   HIP_TRY(hipModuleLaunchKernel(s->fn[k], (unsigned)grid, 1, 1, block, 1, 1, 0, s->stream, args, nullptr));
   return HAMK_OK;
@@ -232,8 +238,8 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   if (m <= 0 || n <= 0) return fail(HAMK_ERR_INVALID, "m and n must be positive");
   if (!inertia || !f_outs) return fail(HAMK_ERR_INVALID, "null inertia / f_outs");
   if (u_space != HAMK_U_GENERALIZED && u_space != HAMK_U_CARTESIAN) return fail(HAMK_ERR_INVALID, "bad u_space");
-  if (n > 16 || m > 64)
-    return fail(HAMK_ERR_UNSUPPORTED, "per-lane register kernels support n <= 16, m <= 64 (larger n: not implemented yet)");
+  if (n > 32 || m > 64)
+    return fail(HAMK_ERR_UNSUPPORTED, "supported sizes: n <= 8 (one trajectory per lane), 9 <= n <= 32 with m <= 64 (wave-cooperative kernels)");
   std::string err = validate_tape(f_ops, f_nops, n, f_outs, m, "coordinate map");
   if (!err.empty()) return fail(HAMK_ERR_TAPE, err);
   const int nu = (u_space == HAMK_U_CARTESIAN) ? m : n;
@@ -252,6 +258,8 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
     if (e[0] == 'H' || e[0] == 'h') s->desc.mode_h = true;
     if (e[0] == 'D' || e[0] == 'd') s->desc.mode_h = false;
   }
+  s->desc.wave = (n > 8);
+  if (const char* e = std::getenv("HAMK_WAVE")) s->desc.wave = (e[0] == '1');      // experiments / tests
   s->desc.rk4_stage_loop = (n >= 7);
   if (const char* e = std::getenv("HAMK_RK4_LOOP")) s->desc.rk4_stage_loop = (e[0] == '1');
   s->desc.rkf_stage_loop = (n >= 4);
@@ -262,8 +270,8 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   if (rc != HAMK_OK) { delete s; return rc; }
   // keep every kernel comfortably inside SOPP branch reach: fall back to the stage-loop bodies
   const size_t kLimit = 64 * 1024;
-  const bool big_rkf = !forced_rkf && !s->desc.rkf_stage_loop && kernel_code_bytes(s->code, "hamk_rkf45_k") > kLimit;
-  const bool big_rk4 = !forced_rk4 && !s->desc.rk4_stage_loop && kernel_code_bytes(s->code, "hamk_rk4_steps_k") > kLimit;
+  const bool big_rkf = !s->desc.wave && !forced_rkf && !s->desc.rkf_stage_loop && kernel_code_bytes(s->code, "hamk_rkf45_k") > kLimit;
+  const bool big_rk4 = !s->desc.wave && !forced_rk4 && !s->desc.rk4_stage_loop && kernel_code_bytes(s->code, "hamk_rk4_steps_k") > kLimit;
   if (big_rkf || big_rk4) {
     if (big_rkf) s->desc.rkf_stage_loop = true;
     if (big_rk4) s->desc.rk4_stage_loop = true;
@@ -462,6 +470,7 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
   TRY(check_call(s, B, mem));
   if (!q0 || !p0 || !qout || !pout || !ts) return fail(HAMK_ERR_INVALID, "null q0 / p0 / ts / qout / pout");
   if (nt < 2) return fail(HAMK_ERR_INVALID, "evolveHam needs at least two times (2 <= s, Hamilton.hs:435)");
+  if (s->desc.wave) return fail(HAMK_ERR_UNSUPPORTED, "evolveHam/stepHam (adaptive RKF45) is not available on the wave-cooperative path (n > 8) yet");
   if (B == 0) return HAMK_OK;
   TRY(bind_device(s));
   TRY(upload_times(s, nt, ts));
@@ -489,6 +498,7 @@ int hamk_step_ham_batch(hamk_system* s, int64_t B, double* q, double* p, double 
                         int32_t mem) {
   TRY(check_call(s, B, mem));
   if (!q || !p) return fail(HAMK_ERR_INVALID, "null q / p");
+  if (s->desc.wave) return fail(HAMK_ERR_UNSUPPORTED, "evolveHam/stepHam (adaptive RKF45) is not available on the wave-cooperative path (n > 8) yet");
   if (B == 0) return HAMK_OK;
   TRY(bind_device(s));
   const double ts[2] = {0.0, dt};                           // Hamilton.hs:401

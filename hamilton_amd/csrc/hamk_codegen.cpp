@@ -77,7 +77,11 @@ std::string validate_tape(const hamk_op* ops, int nops, int n_in, const int32_t*
 // Emit the body of one generic function.  Values are `const auto vI`; constants
 // stay plain doubles so the jet overloads never multiply by a lifted zero jet.
 // Returns the number of trig-cache slots (one per distinct sincos operand) the body uses.
-static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const char* pfx) {
+// sink_outs (optional): value id -> list of output slots; each output is handed to
+// `sink.template put<K>(value)` right after the op that defines it, so a consumer that only
+// accumulates never keeps all M outputs live (wave kernels, M up to 64).
+static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const char* pfx,
+                     const std::vector<std::vector<int>>* sink_outs = nullptr) {
   // pair SIN/COS of a shared operand: one sincos
   std::vector<int> sin_of(nops, -1), cos_of(nops, -1);
   for (int i = 0; i < nops; ++i) {
@@ -123,6 +127,14 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
       default: o << "const auto " << v(i) << " = hamk::" << unary_name(p.op) << "(" << v(p.a) << ");\n"; break;
     }
     done[i] = 1;
+    if (sink_outs) {
+      // a fused sincos defines two values at once: flush every defined value's outputs
+      for (int j = 0; j < nops; ++j)
+        if (done[j] == 1) {
+          for (int k : (*sink_outs)[j]) o << "    sink.template put<" << k << ">(hamk::lift<A>(" << v(j) << "));\n";
+          done[j] = 2;
+        }
+    }
   }
   return nslots;
 }
@@ -130,7 +142,7 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
 std::string generate_source(const SystemDesc& d) {
   std::ostringstream o;
   o << "// generated by libhamk (hamk_codegen.cpp) from the expression tape of one System " << d.m << " " << d.n << "\n";
-  o << "#include \"hamk_device.hpp\"\n\n";
+  o << (d.wave ? "#include \"hamk_wave.hpp\"\n\n" : "#include \"hamk_device.hpp\"\n\n");
   o << "struct HamkSys {\n";
   o << "  static constexpr int N = " << d.n << ";\n";
   o << "  static constexpr int M = " << d.m << ";\n";
@@ -153,10 +165,16 @@ std::string generate_source(const SystemDesc& d) {
   const int ntrig_u = emit_body(o, d.u_ops.data(), (int)d.u_ops.size(), "u");
   o << "    return hamk::lift<A>(u" << d.u_out << ");\n";
   o << "  }\n";
+  // the same map, delivering each output to a sink as soon as it is defined
+  o << "  template <class A, int TRIG, class TC, class Sink> __device__ __forceinline__ static void coords_sink(const A (&in)[N], TC& tc, Sink& sink) {\n";
+  std::vector<std::vector<int>> sink_outs(d.f_ops.size());
+  for (int k = 0; k < d.m; ++k) sink_outs[d.f_outs[k]].push_back(k);
+  emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f", &sink_outs);
+  o << "  }\n";
   o << "  static constexpr int NTRIG_F = " << ntrig_f << ";\n";
   o << "  static constexpr int NTRIG_U = " << ntrig_u << ";\n";
   o << "};\n\n";
-  o << "HAMK_INSTANTIATE(HamkSys)\n";
+  o << (d.wave ? "HAMK_INSTANTIATE_WAVE(HamkSys)\n" : "HAMK_INSTANTIATE(HamkSys)\n");
   return o.str();
 }
 

@@ -13,6 +13,7 @@ struct SystemDesc {
   bool mode_h = true;
   bool rk4_stage_loop = false;
   bool rkf_stage_loop = false;
+  bool wave = false;            // wave-cooperative kernels (hamk_wave.hpp) instead of one trajectory per lane
   std::vector<double> inertia;
   std::vector<hamk_op> f_ops;
   std::vector<int32_t> f_outs;

@@ -1,0 +1,429 @@
+// hamk_wave.hpp -- wave-cooperative kernels for systems with many generalized coordinates
+// (9 <= n <= 32; BASELINE.json config 5, the N-link chain), where one trajectory no longer fits
+// the registers of one lane (second-order jets of 2N outputs in N directions).
+//
+// Mapping: one trajectory per group of NP = 16 or 32 lanes (G = 64/NP trajectories per
+// wavefront); LANE i OF THE GROUP CARRIES AD DIRECTION e_i.  Every lane runs the same
+// generated f/U code -- uniform control flow, the SIMT-friendly way to run forward mode --
+// at the one-direction jets Jet1<1> / Jet2<1>, with its own seed:
+//
+//   sweep 1  Jet1<1>, seed d = delta(i, lane): lane i gets column i of J (and dU/dq_i).  The
+//            column is staged in LDS as J[k][i] as soon as each x_k is defined (coords_sink).
+//   K        row i of K = J^T M J from the LDS-staged J: K[i][b] = sum_k m_k J[k][i] J[k][b]
+//            (broadcast LDS reads; the dense contraction of this path: 2 m n^2 flops).
+//   solve    LDL^T across the group: pivot row broadcast with wavefront shuffles (width NP),
+//            rank-1 update of the row each lane keeps in registers; forward substitution by
+//            shuffles; back substitution reads L^T from a padded LDS tile (conflict-free).
+//   sweep 2  Jet2<1> along the common runtime direction qd with own e_i: lane i accumulates
+//            dT/dq_i = -sum_k m_k (J qd)_k ((dJ/dq_i) qd)_k directly in the sink -- the m x n x n
+//            Hessian tensor of the reference (Hamilton.hs:222, 512 KiB per point at N = 32)
+//            never exists, not even one slice of it.
+//
+// State stays SoA in HBM (q[j*B + t]); a group loads/stores one value per lane.  LDS per
+// trajectory: max(M*NP, NP*(NP+1)) + 2*NP doubles (17 KiB at N = 32).
+#pragma once
+#include "hamk_device.hpp"
+
+namespace hamk {
+namespace wave {
+
+template <int N> struct Geo {
+  static constexpr int NP = (N <= 16) ? 16 : 32;       // lanes per trajectory
+  static constexpr int G = 64 / NP;                    // trajectories per wavefront
+  static constexpr int WAVES = 4;                      // wavefronts per 256-thread block
+};
+
+template <class S> struct Lds {
+  static constexpr int NP = Geo<S::N>::NP;
+  static constexpr int TILE = (S::M * NP > NP * (NP + 1)) ? S::M * NP : NP * (NP + 1);   // J, later L (overlaid)
+  static constexpr int PER_TRAJ = TILE + 2 * NP;       // + two all-gather buffers
+};
+
+// LDS written by some lanes of a wavefront and read by others of the same wavefront: DS
+// operations of one wave complete in order, so only the compiler has to be kept from moving them.
+HAMK_DEV void lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NP> HAMK_DEV double bcast(double x, int src) { return __shfl(x, src, NP); }
+
+template <int NP> HAMK_DEV double group_sum(double x) {
+#pragma unroll
+  for (int off = NP / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, NP);
+  return x;
+}
+
+template <int N, int NP> HAMK_DEV void allgather(double* buf, int li, double mine, double (&all)[N]) {
+  lds_sync();                       // earlier readers of this buffer are done
+  buf[li] = mine;
+  lds_sync();
+#pragma unroll
+  for (int j = 0; j < N; ++j) all[j] = buf[j];
+}
+
+// ---- sinks for coords_sink -------------------------------------------------------------------
+template <class S, int NP> struct SinkJ {          // sweep 1: stage column `li` of J, keep x for U(x)
+  double* J;
+  int li;
+  Jet1<1> x[S::U_CART ? S::M : 1];
+  template <int K> HAMK_DEV void put(const Jet1<1>& v) {
+    J[K * NP + li] = v.d[0];
+    if constexpr (S::U_CART) x[K] = v;
+  }
+};
+template <class S> struct SinkT {                  // sweep 2: dT/dq_i = -sum_k m_k x_k.dv x_k.dd
+  double dT = 0.0;
+  template <int K> HAMK_DEV void put(const Jet2<1>& v) { dT = fma(-(S::inertia(K) * v.dv), v.dd[0], dT); }
+};
+template <class S> struct SinkP {                  // momenta: p_i = sum_k J[k][i] m_k (J qd)_k
+  double p = 0.0;
+  template <int K> HAMK_DEV void put(const Jet2<1>& v) { p = fma(S::inertia(K) * v.dv, v.d[0], p); }
+};
+template <class S> struct SinkX {                  // plain coordinates
+  double x[S::M];
+  template <int K> HAMK_DEV void put(double v) { x[K] = v; }
+};
+
+HAMK_DEV double inertia_rt(const double* w, int k) { return w[k]; }
+
+// ---- per-group context -------------------------------------------------------------------------
+template <class S> struct Ctx {
+  static constexpr int N = S::N, M = S::M, NP = Geo<N>::NP;
+  double* tile;      // [TILE]
+  double* ga;        // [NP] all-gather buffer a
+  double* gb;        // [NP] all-gather buffer b
+  int li;            // lane within the group = AD direction
+};
+
+// Sweep 1 + K + LDL^T.  On return: `row` holds L[li][j] (j < li), `dinv` = 1/d_li; gU = dU/dq_li;
+// the tile holds L^T-readable padded L (row-major, stride NP+1).  q_all: all n positions.
+template <class S>
+HAMK_DEV void factor(const Ctx<S>& c, const double (&q)[S::N], double (&row)[S::N], double& dinv, double& gU,
+                     double& U, TrigCache<S::NTRIG_F>& tc, int& st) {
+  constexpr int N = S::N, M = S::M, NP = Ctx<S>::NP;
+  const int li = c.li;
+  lds_sync();                                             // previous users of the tile are done
+  {
+    Jet1<1> qj[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { qj[j].v = q[j]; qj[j].d[0] = (j == li) ? 1.0 : 0.0; }
+    SinkJ<S, NP> sink;
+    sink.J = c.tile; sink.li = li;
+    S::template coords_sink<Jet1<1>, TRIG_FULL>(qj, tc, sink);
+    TrigCache<S::NTRIG_U> tu;
+    Jet1<1> u;
+    if constexpr (S::U_CART) u = S::template potential<Jet1<1>, TRIG_FULL>(sink.x, tu);
+    else u = S::template potential<Jet1<1>, TRIG_FULL>(qj, tu);
+    gU = u.d[0]; U = u.v;
+  }
+  lds_sync();
+  // K row: K[li][b] = sum_k (m_k J[k][li]) J[k][b]
+#pragma unroll
+  for (int b = 0; b < N; ++b) row[b] = 0.0;
+#pragma unroll 2
+  for (int k = 0; k < M; ++k) {
+    const double a = S::inertia(k) * c.tile[k * NP + li];
+#pragma unroll
+    for (int b = 0; b < N; ++b) row[b] = fma(a, c.tile[k * NP + b], row[b]);
+  }
+  // LDL^T, right-looking, rows distributed over lanes
+  bool ok = true;
+  dinv = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double dj = bcast<NP>(row[j], j);
+    ok = ok && (dj > 0.0);
+    const double inv = frcp(dj);
+    const double lij = row[j] * inv;
+    if (li == j) dinv = inv;
+#pragma unroll
+    for (int k = j + 1; k < N; ++k) {
+      const double rjk = bcast<NP>(row[k], j);             // K[j][k] after the first j updates
+      if (li > j) row[k] = fma(-lij, rjk, row[k]);
+    }
+    if (li > j) row[j] = lij;
+  }
+  if (!ok && li < N) st |= ST_SINGULAR;                    // no pivoting fallback in the wave kernels
+  // L to LDS, row-major with stride NP+1: conflict-free for both the row writes and the
+  // column reads of the back substitution
+  lds_sync();                                             // J no longer needed: overlay
+#pragma unroll
+  for (int j = 0; j < N; ++j) c.tile[li * (NP + 1) + j] = row[j];
+  lds_sync();
+}
+
+// Solve K v = rhs with the factorisation left by `factor`; returns v_li.
+template <class S>
+HAMK_DEV double solve(const Ctx<S>& c, const double (&row)[S::N], double dinv, double rhs) {
+  constexpr int N = S::N, NP = Ctx<S>::NP;
+  const int li = c.li;
+  double z = rhs;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {                            // L z = rhs
+    const double zj = bcast<NP>(z, j);
+    if (li > j) z = fma(-row[j], zj, z);
+  }
+  double v = z * dinv;                                     // D y = z
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {                       // L^T v = y
+    const double vk = bcast<NP>(v, k);
+    if (li < k) v = fma(-c.tile[k * (NP + 1) + li], vk, v);
+  }
+  return v;
+}
+
+// hamEqs for the group's trajectory: lane i returns (dq_i, dp_i).           Hamilton.hs:370-387
+template <class S>
+HAMK_DEV void ham_eqs(const Ctx<S>& c, double qi, double pi, double& dqi, double& dpi, int& st) {
+  constexpr int N = S::N, NP = Ctx<S>::NP;
+  double q[N], row[N], dinv, gU, U;
+  TrigCache<S::NTRIG_F> tc;
+  allgather<N, NP>(c.ga, c.li, qi, q);
+  factor<S>(c, q, row, dinv, gU, U, tc, st);
+  const double vi = solve<S>(c, row, dinv, pi);
+  double v[N];
+  allgather<N, NP>(c.gb, c.li, vi, v);
+  Jet2<1> q2[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) { q2[j].v = q[j]; q2[j].dv = v[j]; q2[j].d[0] = (j == c.li) ? 1.0 : 0.0; q2[j].dd[0] = 0.0; }
+  SinkT<S> sink;
+  S::template coords_sink<Jet2<1>, TRIG_REUSE>(q2, tc, sink);
+  dqi = vi;
+  dpi = -(sink.dT + gU);
+}
+
+// ---- kernels ---------------------------------------------------------------------------------------
+template <class S> struct Where {
+  static constexpr int N = S::N, NP = Geo<N>::NP, G = Geo<N>::G, WAVES = Geo<N>::WAVES;
+  i64 t;            // trajectory index (clamped to B-1 for the tail)
+  bool real;        // the group's trajectory exists (not the padded tail of the last block)
+  bool live;        // this lane owns a real (trajectory, coordinate)
+  Ctx<S> c;
+  HAMK_DEV Where(double* smem, i64 B) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int grp = lane / NP;
+    c.li = lane % NP;
+    const i64 tt = ((i64)blockIdx.x * WAVES + wv) * G + grp;
+    real = tt < B;
+    live = real && (c.li < N);
+    t = (tt < B) ? tt : B - 1;
+    double* base = smem + (size_t)(wv * G + grp) * Lds<S>::PER_TRAJ;
+    c.tile = base;
+    c.ga = base + Lds<S>::TILE;
+    c.gb = c.ga + NP;
+  }
+};
+
+#define HAMK_WAVE_SMEM(S) __shared__ double smem[hamk::wave::Geo<S::N>::WAVES * hamk::wave::Geo<S::N>::G * hamk::wave::Lds<S>::PER_TRAJ]
+
+template <class S>
+HAMK_DEV void rk4_body(double* smem, double* q, double* p, i64 B, double dt, int nsteps, int* status) {
+  constexpr int N = S::N;
+  Where<S> w(smem, B);
+  const int j = (w.c.li < N) ? w.c.li : 0;
+  double yq = q[(i64)j * B + w.t], yp = p[(i64)j * B + w.t];
+  int st = 0;
+  const double h2 = 0.5 * dt, h6 = dt * (1.0 / 6.0), h3 = dt * (1.0 / 3.0);
+  double kq = 0.0, kp = 0.0, aq = yq, ap = yp;
+#pragma unroll 1
+  for (int it = 0; it < 4 * nsteps; ++it) {
+    const int sg = it & 3;
+    const double a = (sg == 0) ? 0.0 : ((sg == 3) ? dt : h2);
+    const double b = (sg == 0 || sg == 3) ? h6 : h3;
+    const double tq = fma(a, kq, yq), tp = fma(a, kp, yp);
+    ham_eqs<S>(w.c, tq, tp, kq, kp, st);
+    aq = fma(b, kq, aq); ap = fma(b, kp, ap);
+    if (sg == 3) { yq = aq; yp = ap; }
+  }
+  const bool bad = is_nonfinite_bits(yq) || is_nonfinite_bits(yp);
+  if (bad && w.c.li < N) st |= ST_NONFINITE;
+  // status of the trajectory = OR over its lanes
+  int stg = st;
+#pragma unroll
+  for (int off = Where<S>::NP / 2; off > 0; off >>= 1) stg |= __shfl_xor(stg, off, Where<S>::NP);
+  if (w.live) { q[(i64)j * B + w.t] = yq; p[(i64)j * B + w.t] = yp; }
+  if (status && w.live && w.c.li == 0) status[w.t] = stg;
+}
+
+template <class S>
+HAMK_DEV void hameqs_body(double* smem, const double* q, const double* p, double* dq, double* dp, i64 B, int* status) {
+  constexpr int N = S::N;
+  Where<S> w(smem, B);
+  const int j = (w.c.li < N) ? w.c.li : 0;
+  const double qi = q[(i64)j * B + w.t], pi = p[(i64)j * B + w.t];
+  double a, b;
+  int st = 0;
+  ham_eqs<S>(w.c, qi, pi, a, b, st);
+  if ((is_nonfinite_bits(a) || is_nonfinite_bits(b)) && w.c.li < N) st |= ST_NONFINITE;
+  int stg = st;
+#pragma unroll
+  for (int off = Where<S>::NP / 2; off > 0; off >>= 1) stg |= __shfl_xor(stg, off, Where<S>::NP);
+  if (w.live) { dq[(i64)j * B + w.t] = a; dp[(i64)j * B + w.t] = b; }
+  if (status && w.live && w.c.li == 0) status[w.t] = stg;
+}
+
+// momenta / toPhase: one Jet2<1> sweep along qd                                  Hamilton.hs:262-284
+template <class S>
+HAMK_DEV double momentum(const Ctx<S>& c, double qi, double vi) {
+  constexpr int N = S::N, NP = Ctx<S>::NP;
+  double q[N], v[N];
+  allgather<N, NP>(c.ga, c.li, qi, q);
+  allgather<N, NP>(c.gb, c.li, vi, v);
+  Jet2<1> q2[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) { q2[j].v = q[j]; q2[j].dv = v[j]; q2[j].d[0] = (j == c.li) ? 1.0 : 0.0; q2[j].dd[0] = 0.0; }
+  TrigCache<S::NTRIG_F> tc;
+  SinkP<S> sink;
+  S::template coords_sink<Jet2<1>, TRIG_FULL>(q2, tc, sink);
+  return sink.p;
+}
+
+template <class S>
+HAMK_DEV void to_phase_body(double* smem, const double* q, const double* qd, double* p, i64 B) {
+  constexpr int N = S::N;
+  Where<S> w(smem, B);
+  const int j = (w.c.li < N) ? w.c.li : 0;
+  const double pi = momentum<S>(w.c, q[(i64)j * B + w.t], qd[(i64)j * B + w.t]);
+  if (w.live) p[(i64)j * B + w.t] = pi;
+}
+
+// velocities / fromPhase                                                          Hamilton.hs:316-337
+template <class S>
+HAMK_DEV double velocity(const Ctx<S>& c, double qi, double pi, double& U, int& st) {
+  constexpr int N = S::N, NP = Ctx<S>::NP;
+  double q[N], row[N], dinv, gU;
+  TrigCache<S::NTRIG_F> tc;
+  allgather<N, NP>(c.ga, c.li, qi, q);
+  factor<S>(c, q, row, dinv, gU, U, tc, st);
+  return solve<S>(c, row, dinv, pi);
+}
+
+template <class S>
+HAMK_DEV void from_phase_body(double* smem, const double* q, const double* p, double* qd, i64 B, int* status) {
+  constexpr int N = S::N;
+  Where<S> w(smem, B);
+  const int j = (w.c.li < N) ? w.c.li : 0;
+  int st = 0;
+  double U;
+  const double vi = velocity<S>(w.c, q[(i64)j * B + w.t], p[(i64)j * B + w.t], U, st);
+  int stg = st;
+#pragma unroll
+  for (int off = Where<S>::NP / 2; off > 0; off >>= 1) stg |= __shfl_xor(stg, off, Where<S>::NP);
+  if (w.live) qd[(i64)j * B + w.t] = vi;
+  if (status && w.live && w.c.li == 0) status[w.t] = stg;
+}
+
+template <class S> HAMK_DEV double potential_only(const Ctx<S>& c, double qi) {
+  constexpr int N = S::N, NP = Ctx<S>::NP;
+  double q[N];
+  allgather<N, NP>(c.ga, c.li, qi, q);
+  return potential_value<S>(q);
+}
+
+template <class S>
+HAMK_DEV void observe_body(double* smem, const double* q, const double* p, double* ke, double* pe, double* h, i64 B,
+                           int* status) {
+  constexpr int N = S::N, NP = Geo<N>::NP;
+  Where<S> w(smem, B);
+  const int j = (w.c.li < N) ? w.c.li : 0;
+  int st = 0;
+  double U, t = 0.0;
+  const double qi = q[(i64)j * B + w.t];
+  if (ke || h) {
+    const double pi = p[(i64)j * B + w.t];
+    const double vi = velocity<S>(w.c, qi, pi, U, st);
+    t = 0.5 * group_sum<NP>((w.c.li < N) ? vi * pi : 0.0);
+  } else {
+    U = potential_only<S>(w.c, qi);
+  }
+  int stg = st;
+#pragma unroll
+  for (int off = NP / 2; off > 0; off >>= 1) stg |= __shfl_xor(stg, off, NP);
+  if (w.live && w.c.li == 0) {
+    if (ke) ke[w.t] = t;
+    if (pe) pe[w.t] = U;
+    if (h) h[w.t] = t + U;
+    if (status) status[w.t] = stg;
+  }
+}
+
+template <class S>
+HAMK_DEV void observe_config_body(double* smem, const double* q, const double* qd, double* ke, double* lag, i64 B) {
+  constexpr int N = S::N, NP = Geo<N>::NP;
+  Where<S> w(smem, B);
+  const int j = (w.c.li < N) ? w.c.li : 0;
+  const double qi = q[(i64)j * B + w.t], vi = qd[(i64)j * B + w.t];
+  const double pi = momentum<S>(w.c, qi, vi);
+  const double t = 0.5 * group_sum<NP>((w.c.li < N) ? vi * pi : 0.0);
+  double U = 0.0;
+  if (lag) U = potential_only<S>(w.c, qi);
+  if (w.live && w.c.li == 0) {
+    if (ke) ke[w.t] = t;
+    if (lag) lag[w.t] = t - U;
+  }
+}
+
+template <class S> HAMK_DEV void coords_body(double* smem, const double* q, double* x, i64 B) {
+  constexpr int N = S::N, M = S::M, NP = Geo<N>::NP;
+  Where<S> w(smem, B);
+  const int j = (w.c.li < N) ? w.c.li : 0;
+  double qq[N], xx[M];
+  allgather<N, NP>(w.c.ga, w.c.li, q[(i64)j * B + w.t], qq);
+  TrigCache<S::NTRIG_F> tc;
+  S::template coords<double, TRIG_FULL>(qq, xx, tc);
+  // every lane of the group holds all M outputs; lane li writes outputs li, li + NP, ...
+#pragma unroll
+  for (int k = 0; k < M; ++k)
+    if (w.real && (k % NP) == w.c.li) x[(i64)k * B + w.t] = xx[k];
+}
+
+}  // namespace wave
+}  // namespace hamk
+
+// Same eight kernel names as HAMK_INSTANTIATE, wave-cooperative bodies.  The adaptive stepper
+// is not available on this path yet: its kernel flags every trajectory HAMK_ST_MAXSTEPS.
+#define HAMK_INSTANTIATE_WAVE(S)                                                                                 \
+  extern "C" __global__ void __launch_bounds__(256) hamk_rk4_steps_k(double* q, double* p, long long B,          \
+                                                                      double dt, int nsteps, int* status) {      \
+    HAMK_WAVE_SMEM(S);                                                                                           \
+    hamk::wave::rk4_body<S>(smem, q, p, B, dt, nsteps, status);                                                  \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_hameqs_k(const double* q, const double* p, double* dq,  \
+                                                                   double* dp, long long B, int* status) {       \
+    HAMK_WAVE_SMEM(S);                                                                                           \
+    hamk::wave::hameqs_body<S>(smem, q, p, dq, dp, B, status);                                                   \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_coords_k(const double* q, double* x, long long B) {     \
+    HAMK_WAVE_SMEM(S);                                                                                           \
+    hamk::wave::coords_body<S>(smem, q, x, B);                                                                   \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_to_phase_k(const double* q, const double* qd,           \
+                                                                     double* p, long long B) {                   \
+    HAMK_WAVE_SMEM(S);                                                                                           \
+    hamk::wave::to_phase_body<S>(smem, q, qd, p, B);                                                             \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_from_phase_k(const double* q, const double* p,          \
+                                                                       double* qd, long long B, int* status) {   \
+    HAMK_WAVE_SMEM(S);                                                                                           \
+    hamk::wave::from_phase_body<S>(smem, q, p, qd, B, status);                                                   \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_observe_k(const double* q, const double* p, double* ke, \
+                                                                    double* pe, double* h, long long B,          \
+                                                                    int* status) {                               \
+    HAMK_WAVE_SMEM(S);                                                                                           \
+    hamk::wave::observe_body<S>(smem, q, p, ke, pe, h, B, status);                                               \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_observe_config_k(const double* q, const double* qd,     \
+                                                                           double* ke, double* lag,              \
+                                                                           long long B) {                        \
+    HAMK_WAVE_SMEM(S);                                                                                           \
+    hamk::wave::observe_config_body<S>(smem, q, qd, ke, lag, B);                                                 \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_rkf45_k(                                                \
+      const double* q0, const double* p0, double* qout, double* pout, long long B, int nt, const double* ts,     \
+      double h0, double eps_abs, double eps_rel, int row0, int inplace, int max_sub, int* status, int* nsub) {   \
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;                                        \
+    if (i < B && status) status[i] = hamk::ST_MAXSTEPS;                                                          \
+  }

@@ -1,0 +1,94 @@
+"""GPU: the wave-cooperative path (hamk_wave.hpp; lane = AD direction, LDS-staged J, shuffle
+LDL^T) against the CPU oracle -- on the large-n systems it exists for (chain16, chain32:
+BASELINE.json config 5) and, forced with HAMK_WAVE=1, on small systems that also have
+high-precision fixtures and a lane-path result to compare with."""
+import numpy as np
+import pytest
+
+from conftest import fvec, load_golden
+from hamilton_amd import examples as E
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api(hamk_lib):
+    from hamilton_amd import api as _api
+    if hamk_lib.hamk_device_count() < 1:
+        pytest.fail("no HIP device visible")
+    return _api
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.maximum(1.0, np.abs(np.asarray(b)))))
+
+
+CASES = [("spring", True), ("threeBodyPolar", True), ("chain4", True), ("opcodeZoo", True),
+         ("chain8", True), ("chain16", False), ("chain32", False)]
+
+
+@pytest.mark.parametrize("name,force", CASES)
+def test_wave_path_vs_oracle(api, oracle_lib, monkeypatch, name, force):
+    spec = E.get(name)
+    if force:
+        monkeypatch.setenv("HAMK_WAVE", "1")
+    s = api.system_from_spec(spec)
+    assert "HAMK_INSTANTIATE_WAVE" in s.source
+    o = oracle_lib.OracleSystem(spec)
+    for B in (1, 5, 67):                           # tails: not a multiple of the 8/16 trajectories per block
+        q, qd = E.sample_config(spec, 31, B)
+        if name.startswith("chain"):
+            qd = 0.3 * np.cos(np.arange(spec.n * B).reshape(spec.n, B) * 0.7)   # the C5 box has qd = 0
+        p = api.momenta(s, api.Config(q, qd))
+        op = o.to_phase_batch(q, qd)
+        assert relerr(p, op) < 1e-12, (name, B, "momenta", relerr(p, op))
+        dq, dp = api.hamEqs(s, api.Phase(q, op))
+        odq, odp, _ = o.hameqs_batch(q, op)
+        assert not np.any(s.last_status)
+        assert relerr(dq, odq) < 1e-10 and relerr(dp, odp) < 1e-10, (name, B, relerr(dq, odq), relerr(dp, odp))
+        v, _ = o.from_phase_batch(q, op)
+        assert relerr(api.velocities(s, api.Phase(q, op)), v) < 1e-10
+        ke, pe_, h = o.observe_batch(q, op)
+        assert relerr(api.keP(s, api.Phase(q, op)), ke) < 1e-10
+        assert relerr(api.pe(s, q), pe_) < 1e-12
+        assert relerr(api.hamiltonian(s, api.Phase(q, op)), h) < 1e-10
+        kc, lg = o.observe_config_batch(q, qd)
+        assert relerr(api.keC(s, api.Config(q, qd)), kc) < 1e-10
+        assert relerr(api.lagrangian(s, api.Config(q, qd)), lg) < 1e-10
+        assert relerr(api.underlyingPos(s, q), o.coords_batch(q)) < 1e-12
+        ph = api.rk4Steps(spec.dt, 5, s, api.Phase(q, op))
+        oq, opp = o.rk4_steps_batch(q, op, spec.dt, 5)
+        assert relerr(ph.positions, oq) < 1e-10 and relerr(ph.momenta, opp) < 1e-10, (name, B)
+        assert not np.any(s.last_status)
+
+
+def test_wave_path_matches_golden_and_lane_path(api, monkeypatch):
+    spec = E.get("threeBodyPolar")
+    lane = api.system_from_spec(spec)
+    monkeypatch.setenv("HAMK_WAVE", "1")
+    wave = api.system_from_spec(spec)
+    pts = load_golden("threeBodyPolar")["points"]
+    q = np.stack([fvec(p["q"]) for p in pts], axis=1)
+    p = np.stack([fvec(pt["p"]) for pt in pts], axis=1)
+    want_dp = np.stack([fvec(pt["dp"]) for pt in pts], axis=1)
+    dq_w, dp_w = api.hamEqs(wave, api.Phase(q, p))
+    dq_l, dp_l = api.hamEqs(lane, api.Phase(q, p))
+    assert relerr(dp_w, want_dp) < 1e-11 and relerr(dp_w, dp_l) < 1e-11 and relerr(dq_w, dq_l) < 1e-11
+
+
+def test_adaptive_stepper_reports_unsupported_on_wave_path(api):
+    s = api.system_from_spec(E.get("chain16"))
+    q = np.zeros((16, 2)); p = np.zeros((16, 2))
+    with pytest.raises(api.HamkError) as ei:
+        api.stepHam(0.01, s, api.Phase(q, p))
+    assert ei.value.code == -6
+
+
+def test_singular_flag_on_wave_path(api, monkeypatch):
+    monkeypatch.setenv("HAMK_WAVE", "1")
+    spec = E.chain(4)
+    spec.inertia = (0.0,) * 8
+    s = api.system_from_spec(spec)
+    q, qd = E.sample_config(spec, 0, 3)
+    api.hamEqs(s, api.Phase(q, np.ones_like(q)))
+    assert np.all(np.asarray(s.last_status) & 1)

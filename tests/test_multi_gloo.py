@@ -69,3 +69,21 @@ def test_shard_bounds_partition():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         ensemble.shard_bounds(10, 2, 2)
+
+
+def test_checkpoint_roundtrip(tmp_path, oracle_lib):
+    """Resume = reload the two flat arrays and keep stepping: identical bits to an uninterrupted run."""
+    spec = E.get("spring")
+    o = oracle_lib.OracleSystem(spec)
+    q, qd = E.sample_config(spec, 10, 32)
+    p = o.to_phase_batch(q, qd, threads=1)
+    q1, p1 = o.rk4_steps_batch(q, p, spec.dt, 4, threads=1)
+    path = str(tmp_path / "ens")
+    ensemble.save_checkpoint(path, spec.name, q1, p1, t=4 * spec.dt, step=4, dt=spec.dt, seed=E.SEED, first_index=10)
+    ck = ensemble.load_checkpoint(path)
+    assert ck["system"] == "spring" and ck["step"] == 4 and ck["first_index"] == 10 and ck["seed"] == E.SEED
+    np.testing.assert_array_equal(ck["q"], q1)
+    q2, p2 = o.rk4_steps_batch(ck["q"], ck["p"], ck["dt"], 3, threads=1)
+    qf, pf = o.rk4_steps_batch(q, p, spec.dt, 7, threads=1)
+    np.testing.assert_array_equal(q2, qf)
+    np.testing.assert_array_equal(p2, pf)
