@@ -239,7 +239,7 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   if (!inertia || !f_outs) return fail(HAMK_ERR_INVALID, "null inertia / f_outs");
   if (u_space != HAMK_U_GENERALIZED && u_space != HAMK_U_CARTESIAN) return fail(HAMK_ERR_INVALID, "bad u_space");
   if (n > 32 || m > 64)
-    return fail(HAMK_ERR_UNSUPPORTED, "supported sizes: n <= 8 (one trajectory per lane), 9 <= n <= 32 with m <= 64 (wave-cooperative kernels)");
+    return fail(HAMK_ERR_UNSUPPORTED, "supported sizes: n <= 16 (one trajectory per lane), 17 <= n <= 32 with m <= 64 (wave-cooperative kernels)");
   std::string err = validate_tape(f_ops, f_nops, n, f_outs, m, "coordinate map");
   if (!err.empty()) return fail(HAMK_ERR_TAPE, err);
   const int nu = (u_space == HAMK_U_CARTESIAN) ? m : n;
@@ -258,7 +258,9 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
     if (e[0] == 'H' || e[0] == 'h') s->desc.mode_h = true;
     if (e[0] == 'D' || e[0] == 'd') s->desc.mode_h = false;
   }
-  s->desc.wave = (n > 8);
+  // measured on MI355X (scripts/sweep_wave.py): the lane kernels win up to n = 16 even with
+  // spills (chain16: 4.5e8 vs 7.3e7 steps/s); beyond that one trajectory no longer fits a lane
+  s->desc.wave = (n > 16);
   if (const char* e = std::getenv("HAMK_WAVE")) s->desc.wave = (e[0] == '1');      // experiments / tests
   s->desc.rk4_stage_loop = (n >= 7);
   if (const char* e = std::getenv("HAMK_RK4_LOOP")) s->desc.rk4_stage_loop = (e[0] == '1');
@@ -470,7 +472,7 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
   TRY(check_call(s, B, mem));
   if (!q0 || !p0 || !qout || !pout || !ts) return fail(HAMK_ERR_INVALID, "null q0 / p0 / ts / qout / pout");
   if (nt < 2) return fail(HAMK_ERR_INVALID, "evolveHam needs at least two times (2 <= s, Hamilton.hs:435)");
-  if (s->desc.wave) return fail(HAMK_ERR_UNSUPPORTED, "evolveHam/stepHam (adaptive RKF45) is not available on the wave-cooperative path (n > 8) yet");
+  if (s->desc.wave) return fail(HAMK_ERR_UNSUPPORTED, "evolveHam/stepHam (adaptive RKF45) is not available on the wave-cooperative path (n > 16) yet");
   if (B == 0) return HAMK_OK;
   TRY(bind_device(s));
   TRY(upload_times(s, nt, ts));
@@ -498,7 +500,7 @@ int hamk_step_ham_batch(hamk_system* s, int64_t B, double* q, double* p, double 
                         int32_t mem) {
   TRY(check_call(s, B, mem));
   if (!q || !p) return fail(HAMK_ERR_INVALID, "null q / p");
-  if (s->desc.wave) return fail(HAMK_ERR_UNSUPPORTED, "evolveHam/stepHam (adaptive RKF45) is not available on the wave-cooperative path (n > 8) yet");
+  if (s->desc.wave) return fail(HAMK_ERR_UNSUPPORTED, "evolveHam/stepHam (adaptive RKF45) is not available on the wave-cooperative path (n > 16) yet");
   if (B == 0) return HAMK_OK;
   TRY(bind_device(s));
   const double ts[2] = {0.0, dt};                           // Hamilton.hs:401

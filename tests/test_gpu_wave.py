@@ -24,7 +24,7 @@ def relerr(a, b):
 
 
 CASES = [("spring", True), ("threeBodyPolar", True), ("chain4", True), ("opcodeZoo", True),
-         ("chain8", True), ("chain16", False), ("chain32", False)]
+         ("chain8", True), ("chain16", True), ("chain32", False)]
 
 
 @pytest.mark.parametrize("name,force", CASES)
@@ -77,8 +77,8 @@ def test_wave_path_matches_golden_and_lane_path(api, monkeypatch):
 
 
 def test_adaptive_stepper_reports_unsupported_on_wave_path(api):
-    s = api.system_from_spec(E.get("chain16"))
-    q = np.zeros((16, 2)); p = np.zeros((16, 2))
+    s = api.system_from_spec(E.get("chain20"))
+    q = np.zeros((20, 2)); p = np.zeros((20, 2))
     with pytest.raises(api.HamkError) as ei:
         api.stepHam(0.01, s, api.Phase(q, p))
     assert ei.value.code == -6
@@ -92,3 +92,23 @@ def test_singular_flag_on_wave_path(api, monkeypatch):
     q, qd = E.sample_config(spec, 0, 3)
     api.hamEqs(s, api.Phase(q, np.ones_like(q)))
     assert np.all(np.asarray(s.last_status) & 1)
+
+
+def test_lane_path_at_its_upper_size(api, oracle_lib):
+    """n = 12 runs one trajectory per lane (the default up to n = 16): directional jets, stage loops."""
+    spec = E.get("chain12")
+    s = api.system_from_spec(spec)
+    assert "HAMK_INSTANTIATE(HamkSys)" in s.source
+    o = oracle_lib.OracleSystem(spec)
+    q, qd = E.sample_config(spec, 5, 70)
+    qd = 0.3 * np.cos(np.arange(spec.n * 70).reshape(spec.n, 70) * 0.7)
+    p = o.to_phase_batch(q, qd)
+    dq, dp = api.hamEqs(s, api.Phase(q, p))
+    odq, odp, _ = o.hameqs_batch(q, p)
+    assert relerr(dq, odq) < 1e-10 and relerr(dp, odp) < 1e-10
+    ph = api.rk4Steps(spec.dt, 3, s, api.Phase(q, p))
+    oq, op = o.rk4_steps_batch(q, p, spec.dt, 3)
+    assert relerr(ph.positions, oq) < 1e-10 and relerr(ph.momenta, op) < 1e-10
+    st = api.stepHam(0.005, s, api.Phase(q, p))
+    sq, sp, _ = o.step_ham_batch(q, p, 0.005)
+    assert relerr(st.positions, sq) < 1e-8 and relerr(st.momenta, sp) < 1e-8
