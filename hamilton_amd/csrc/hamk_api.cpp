@@ -160,7 +160,7 @@ static int launch(hamk_system* s, KernelId k, int64_t B, void** args) {
   const unsigned block = 256;
   // lane kernels: one trajectory per thread; wave kernels: 64/NP trajectories per wavefront
   int64_t per_block = block;
-  if (s->desc.wave && k != K_RKF45) per_block = 4 * (64 / (s->desc.n <= 16 ? 16 : 32));
+  if (s->desc.wave) per_block = 4 * (64 / (s->desc.n <= 16 ? 16 : 32));
   const int64_t grid = (B + per_block - 1) / per_block;
   if (grid > 0x7fffffffLL) return fail(HAMK_ERR_INVALID, "ensemble too large for one launch");
   HIP_TRY(hipModuleLaunchKernel(s->fn[k], (unsigned)grid, 1, 1, block, 1, 1, 0, s->stream, args, nullptr));
@@ -472,7 +472,6 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
   TRY(check_call(s, B, mem));
   if (!q0 || !p0 || !qout || !pout || !ts) return fail(HAMK_ERR_INVALID, "null q0 / p0 / ts / qout / pout");
   if (nt < 2) return fail(HAMK_ERR_INVALID, "evolveHam needs at least two times (2 <= s, Hamilton.hs:435)");
-  if (s->desc.wave) return fail(HAMK_ERR_UNSUPPORTED, "evolveHam/stepHam (adaptive RKF45) is not available on the wave-cooperative path (n > 16) yet");
   if (B == 0) return HAMK_OK;
   TRY(bind_device(s));
   TRY(upload_times(s, nt, ts));
@@ -500,7 +499,6 @@ int hamk_step_ham_batch(hamk_system* s, int64_t B, double* q, double* p, double 
                         int32_t mem) {
   TRY(check_call(s, B, mem));
   if (!q || !p) return fail(HAMK_ERR_INVALID, "null q / p");
-  if (s->desc.wave) return fail(HAMK_ERR_UNSUPPORTED, "evolveHam/stepHam (adaptive RKF45) is not available on the wave-cooperative path (n > 16) yet");
   if (B == 0) return HAMK_OK;
   TRY(bind_device(s));
   const double ts[2] = {0.0, dt};                           // Hamilton.hs:401

@@ -49,6 +49,12 @@ HAMK_DEV void lds_sync() {
 
 template <int NP> HAMK_DEV double bcast(double x, int src) { return __shfl(x, src, NP); }
 
+template <int NP> HAMK_DEV double group_max(double x) {
+#pragma unroll
+  for (int off = NP / 2; off > 0; off >>= 1) { const double y = __shfl_xor(x, off, NP); x = (y > x) ? y : x; }
+  return x;
+}
+
 template <int NP> HAMK_DEV double group_sum(double x) {
 #pragma unroll
   for (int off = NP / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, NP);
@@ -81,12 +87,6 @@ template <class S> struct SinkP {                  // momenta: p_i = sum_k J[k][
   double p = 0.0;
   template <int K> HAMK_DEV void put(const Jet2<1>& v) { p = fma(S::inertia(K) * v.dv, v.d[0], p); }
 };
-template <class S> struct SinkX {                  // plain coordinates
-  double x[S::M];
-  template <int K> HAMK_DEV void put(double v) { x[K] = v; }
-};
-
-HAMK_DEV double inertia_rt(const double* w, int k) { return w[k]; }
 
 // ---- per-group context -------------------------------------------------------------------------
 template <class S> struct Ctx {
@@ -379,11 +379,132 @@ template <class S> HAMK_DEV void coords_body(double* smem, const double* q, doub
     if (w.real && (k % NP) == w.c.li) x[(i64)k * B + w.t] = xx[k];
 }
 
+
+// evolveHam / stepHam on the wave path: the same GSL semantics as hamk::rkf45_body (rkf45.c,
+// cstd.c with a_y = a_dydt = 1, evolve.c, gsl-ode.c; see hamk_device.hpp), one trajectory per
+// lane group.  t, h and the accept/reject decision are uniform within a group (the error norm
+// is a group-wide max by shuffles) but differ between the groups of a wavefront: every lane
+// always executes the attempt -- the cooperative shuffles need all lanes -- and a group that has
+// already reached the output time simply does not commit.  One inlined right-hand side serves
+// the six evaluations of an attempt through a stage switch.
+template <class S>
+HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt,
+                         const double* ts, double h0, double eps_abs, double eps_rel, int row0, int inplace,
+                         int max_sub, int* status, int* nsub) {
+  constexpr int N = S::N, NP = Geo<N>::NP;
+  Where<S> w(smem, B);
+  const int j = (w.c.li < N) ? w.c.li : 0;
+  const bool mine = w.c.li < N;
+  double yq = q0[(i64)j * B + w.t], yp = p0[(i64)j * B + w.t];
+  if (row0 == 0 && w.live) { qout[(i64)j * B + w.t] = yq; pout[(i64)j * B + w.t] = yp; }
+  int st = 0, attempts = 0;
+  double t = ts[0], h = h0;
+  double fq, fp;
+  ham_eqs<S>(w.c, yq, yp, fq, fp, st);                    // dydt_in at the initial state
+  for (int r = 1; r < nt; ++r) {
+    const double ti = ts[r];
+    for (;;) {
+      const bool active = (t < ti) && (attempts < max_sub);
+      if (!__any(active)) break;                           // wave-uniform exit
+      const double dt = ti - t;
+      double hh = h;
+      bool final_step = false;
+      if ((dt >= 0.0 && hh > dt) || (dt < 0.0 && hh < dt)) { hh = dt; final_step = true; }
+      double k2q = 0, k2p = 0, k3q = 0, k3p = 0, k4q = 0, k4p = 0, k5q = 0, k5p = 0, k6q = 0, k6p = 0;
+      double ynq = yq, ynp = yp, fnq = 0, fnp = 0;
+#pragma unroll 1
+      for (int sg = 0; sg < 6; ++sg) {
+        double tq, tp;
+        switch (sg) {
+          case 0:
+            tq = yq + (1.0 / 4.0) * hh * fq; tp = yp + (1.0 / 4.0) * hh * fp; break;
+          case 1:
+            tq = yq + hh * ((3.0 / 32.0) * fq + (9.0 / 32.0) * k2q);
+            tp = yp + hh * ((3.0 / 32.0) * fp + (9.0 / 32.0) * k2p); break;
+          case 2:
+            tq = yq + hh * ((1932.0 / 2197.0) * fq + (-7200.0 / 2197.0) * k2q + (7296.0 / 2197.0) * k3q);
+            tp = yp + hh * ((1932.0 / 2197.0) * fp + (-7200.0 / 2197.0) * k2p + (7296.0 / 2197.0) * k3p); break;
+          case 3:
+            tq = yq + hh * ((8341.0 / 4104.0) * fq + (-32832.0 / 4104.0) * k2q + (29440.0 / 4104.0) * k3q + (-845.0 / 4104.0) * k4q);
+            tp = yp + hh * ((8341.0 / 4104.0) * fp + (-32832.0 / 4104.0) * k2p + (29440.0 / 4104.0) * k3p + (-845.0 / 4104.0) * k4p); break;
+          case 4:
+            tq = yq + hh * ((-6080.0 / 20520.0) * fq + (41040.0 / 20520.0) * k2q + (-28352.0 / 20520.0) * k3q +
+                            (9295.0 / 20520.0) * k4q + (-5643.0 / 20520.0) * k5q);
+            tp = yp + hh * ((-6080.0 / 20520.0) * fp + (41040.0 / 20520.0) * k2p + (-28352.0 / 20520.0) * k3p +
+                            (9295.0 / 20520.0) * k4p + (-5643.0 / 20520.0) * k5p); break;
+          default:
+            ynq = yq + hh * ((902880.0 / 7618050.0) * fq + (3953664.0 / 7618050.0) * k3q + (3855735.0 / 7618050.0) * k4q +
+                             (-1371249.0 / 7618050.0) * k5q + (277020.0 / 7618050.0) * k6q);
+            ynp = yp + hh * ((902880.0 / 7618050.0) * fp + (3953664.0 / 7618050.0) * k3p + (3855735.0 / 7618050.0) * k4p +
+                             (-1371249.0 / 7618050.0) * k5p + (277020.0 / 7618050.0) * k6p);
+            tq = ynq; tp = ynp; break;
+        }
+        double oq, op;
+        int st_try = 0;
+        ham_eqs<S>(w.c, tq, tp, oq, op, st_try);
+        if (active) st |= st_try;
+        switch (sg) {
+          case 0: k2q = oq; k2p = op; break;
+          case 1: k3q = oq; k3p = op; break;
+          case 2: k4q = oq; k4p = op; break;
+          case 3: k5q = oq; k5p = op; break;
+          case 4: k6q = oq; k6p = op; break;
+          default: fnq = oq; fnp = op; break;
+        }
+      }
+      // cstd.c: std_control_hadjust, ord = 5; the norm runs over the group's 2n components
+      const double eq = hh * ((1.0 / 360.0) * fq + (-128.0 / 4275.0) * k3q + (-2197.0 / 75240.0) * k4q + (1.0 / 50.0) * k5q + (2.0 / 55.0) * k6q);
+      const double ep = hh * ((1.0 / 360.0) * fp + (-128.0 / 4275.0) * k3p + (-2197.0 / 75240.0) * k4p + (1.0 / 50.0) * k5p + (2.0 / 55.0) * k6p);
+      const double rq = fabs(eq) / fabs(eps_rel * (fabs(ynq) + fabs(hh * fnq)) + eps_abs);
+      const double rp = fabs(ep) / fabs(eps_rel * (fabs(ynp) + fabs(hh * fnp)) + eps_abs);
+      double rl = (rq > rp) ? rq : rp;
+      if (!mine || !(rl > 2.2250738585072014e-308)) rl = 2.2250738585072014e-308;
+      const double rmax = group_max<NP>(rl);
+      const double tnew = final_step ? ti : t + hh;
+      const double h_old = hh;
+      bool reject = false;
+      if (rmax > 1.1) {
+        double rr = 0.9 / ::pow(rmax, 1.0 / 5.0);
+        if (rr < 0.2) rr = 0.2;
+        const double hdec = rr * h_old;
+        if (fabs(hdec) < fabs(h_old) && (tnew + hdec) != tnew) { reject = true; hh = hdec; }
+      } else if (rmax < 0.5) {
+        double rr = 0.9 / ::pow(rmax, 1.0 / 6.0);
+        if (rr > 5.0) rr = 5.0;
+        if (rr < 1.0) rr = 1.0;
+        hh = rr * h_old;
+      }
+      if (active) {                                        // evolve.c: accept or undo
+        ++attempts;
+        h = hh;
+        if (!reject) {
+          if (!(tnew > t)) st |= ST_UNDERFLOW;
+          t = tnew; yq = ynq; yp = ynp; fq = fnq; fp = fnp;
+        }
+      }
+    }
+    if (t < ti) st |= ST_MAXSTEPS;
+    if (r >= row0 && w.live) {
+      double* qo = inplace ? qout : qout + (i64)r * N * B;
+      double* po = inplace ? pout : pout + (i64)r * N * B;
+      qo[(i64)j * B + w.t] = yq; po[(i64)j * B + w.t] = yp;
+    }
+  }
+  if ((is_nonfinite_bits(yq) || is_nonfinite_bits(yp)) && mine) st |= ST_NONFINITE;
+  if (!mine) st = 0;
+  int stg = st;
+#pragma unroll
+  for (int off = NP / 2; off > 0; off >>= 1) stg |= __shfl_xor(stg, off, NP);
+  if (w.live && w.c.li == 0) {
+    if (status) status[w.t] = stg;
+    if (nsub) nsub[w.t] = attempts;
+  }
+}
+
 }  // namespace wave
 }  // namespace hamk
 
-// Same eight kernel names as HAMK_INSTANTIATE, wave-cooperative bodies.  The adaptive stepper
-// is not available on this path yet: its kernel flags every trajectory HAMK_ST_MAXSTEPS.
+// Same eight kernel names as HAMK_INSTANTIATE, wave-cooperative bodies.
 #define HAMK_INSTANTIATE_WAVE(S)                                                                                 \
   extern "C" __global__ void __launch_bounds__(256) hamk_rk4_steps_k(double* q, double* p, long long B,          \
                                                                       double dt, int nsteps, int* status) {      \
@@ -424,6 +545,7 @@ template <class S> HAMK_DEV void coords_body(double* smem, const double* q, doub
   extern "C" __global__ void __launch_bounds__(256) hamk_rkf45_k(                                                \
       const double* q0, const double* p0, double* qout, double* pout, long long B, int nt, const double* ts,     \
       double h0, double eps_abs, double eps_rel, int row0, int inplace, int max_sub, int* status, int* nsub) {   \
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;                                        \
-    if (i < B && status) status[i] = hamk::ST_MAXSTEPS;                                                          \
+    HAMK_WAVE_SMEM(S);                                                                                           \
+    hamk::wave::rkf45_body<S>(smem, q0, p0, qout, pout, B, nt, ts, h0, eps_abs, eps_rel, row0, inplace, max_sub, \
+                              status, nsub);                                                                     \
   }

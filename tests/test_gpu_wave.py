@@ -76,12 +76,33 @@ def test_wave_path_matches_golden_and_lane_path(api, monkeypatch):
     assert relerr(dp_w, want_dp) < 1e-11 and relerr(dp_w, dp_l) < 1e-11 and relerr(dq_w, dq_l) < 1e-11
 
 
-def test_adaptive_stepper_reports_unsupported_on_wave_path(api):
-    s = api.system_from_spec(E.get("chain20"))
-    q = np.zeros((20, 2)); p = np.zeros((20, 2))
-    with pytest.raises(api.HamkError) as ei:
-        api.stepHam(0.01, s, api.Phase(q, p))
-    assert ei.value.code == -6
+@pytest.mark.parametrize("name,force", [("spring", True), ("threeBodyPolar", True), ("chain8", True), ("chain20", False)])
+def test_wave_adaptive_stepper_vs_oracle(api, oracle_lib, monkeypatch, name, force):
+    """stepHam / evolveHam on the wave path: GSL-semantics RKF45 with group-uniform control."""
+    spec = E.get(name)
+    if force:
+        monkeypatch.setenv("HAMK_WAVE", "1")
+    s = api.system_from_spec(spec)
+    assert "HAMK_INSTANTIATE_WAVE" in s.source
+    o = oracle_lib.OracleSystem(spec)
+    B = 37
+    q, qd = E.sample_config(spec, 77, B)
+    if name.startswith("chain"):
+        qd = 0.3 * np.cos(np.arange(spec.n * B).reshape(spec.n, B) * 0.7)
+    p = o.to_phase_batch(q, qd)
+    dt = 4 * spec.dt
+    st = api.stepHam(dt, s, api.Phase(q, p))
+    sq, sp, sns = o.step_ham_batch(q, p, dt)
+    same = np.asarray(s.last_nsub) == sns
+    assert same.mean() > 0.9, (name, same.mean(), np.asarray(s.last_nsub)[:8], sns[:8])
+    assert relerr(st.positions[:, same], sq[:, same]) < 1e-9 and relerr(st.momenta[:, same], sp[:, same]) < 1e-9
+    assert not np.any(s.last_status)
+    ts = np.array([0.0, dt, 2.5 * dt])
+    rows = api.evolveHam(s, api.Phase(q, p), ts)
+    oq, op, _ = o.evolve_ham_batch(q, p, ts)
+    np.testing.assert_array_equal(rows[0].positions, q)
+    for r in (1, 2):
+        assert relerr(rows[r].positions, oq[r]) < 1e-6 and relerr(rows[r].momenta, op[r]) < 1e-6
 
 
 def test_singular_flag_on_wave_path(api, monkeypatch):
