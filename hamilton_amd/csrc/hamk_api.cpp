@@ -72,6 +72,12 @@ static int compile_module(hamk_system* s) {
   if (r != HIPRTC_SUCCESS) return fail(HAMK_ERR_COMPILE, std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r));
   std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast",
                                    "-fno-honor-nans", "-fno-signed-zeros"};
+  if (s->desc.wave) {
+    // CodeGenPrepare's address sinking is quadratic in the thousands of LDS accesses of the
+    // straight-line wave kernels (chain32: 170 s of a 200 s build); it is an optimisation pass only
+    opts.push_back("-mllvm");
+    opts.push_back("-disable-cgp");
+  }
   std::string extra;                                   // experiments: HAMK_HIPRTC_FLAGS="-mllvm -foo ..."
   std::vector<std::string> extra_tok;
   if (const char* e = std::getenv("HAMK_HIPRTC_FLAGS")) {

@@ -80,8 +80,12 @@ std::string validate_tape(const hamk_op* ops, int nops, int n_in, const int32_t*
 // sink_outs (optional): value id -> list of output slots; each output is handed to
 // `sink.template put<K>(value)` right after the op that defines it, so a consumer that only
 // accumulates never keeps all M outputs live (wave kernels, M up to 64).
+// input_exprs (optional): expression to use for INPUT j instead of in[j] (composition u . f);
+// tc_name: the trig cache variable the body's sincos sites use.
 static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const char* pfx,
-                     const std::vector<std::vector<int>>* sink_outs = nullptr) {
+                     const std::vector<std::vector<int>>* sink_outs = nullptr,
+                     const std::vector<std::string>* input_exprs = nullptr, const char* tc_name = "tc",
+                     std::vector<int>* slot_operand = nullptr, const char* trig_mode = "TRIG") {
   // pair SIN/COS of a shared operand: one sincos
   std::vector<int> sin_of(nops, -1), cos_of(nops, -1);
   for (int i = 0; i < nops; ++i) {
@@ -93,7 +97,7 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
   int nslots = 0;
   auto slot = [&](int operand) {
     if (slot_of[operand] < 0) slot_of[operand] = nslots++;
-    return std::string("tc, ") + std::to_string(slot_of[operand]);
+    return std::string(tc_name) + ", " + std::to_string(slot_of[operand]);
   };
   auto v = [&](int i) { return std::string(pfx) + std::to_string(i); };
   for (int i = 0; i < nops; ++i) {
@@ -102,7 +106,10 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
     o << "    ";
     switch (p.op) {
       case HAMK_OP_CONST: o << "const double " << v(i) << " = " << lit(p.c) << ";\n"; break;
-      case HAMK_OP_INPUT: o << "const A& " << v(i) << " = in[" << p.a << "];\n"; break;
+      case HAMK_OP_INPUT:
+        if (input_exprs) o << "const auto& " << v(i) << " = " << (*input_exprs)[p.a] << ";\n";
+        else o << "const A " << v(i) << " = in[" << p.a << "];\n";
+        break;
       case HAMK_OP_ADD: o << "const auto " << v(i) << " = " << v(p.a) << " + " << v(p.b) << ";\n"; break;
       case HAMK_OP_SUB: o << "const auto " << v(i) << " = " << v(p.a) << " - " << v(p.b) << ";\n"; break;
       case HAMK_OP_MUL: o << "const auto " << v(i) << " = " << v(p.a) << " * " << v(p.b) << ";\n"; break;
@@ -117,10 +124,10 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
         const int si = sin_of[p.a], ci = cos_of[p.a];
         if (si >= 0 && ci >= 0 && (si == i || ci == i) && !done[si] && !done[ci]) {
           o << "hamk::bare_t<decltype(" << v(p.a) << ")> " << v(si) << ", " << v(ci)
-            << "; hamk::sincos<TRIG>(" << v(p.a) << ", " << v(si) << ", " << v(ci) << ", " << slot(p.a) << ");\n";
+            << "; hamk::sincos<" << trig_mode << ">(" << v(p.a) << ", " << v(si) << ", " << v(ci) << ", " << slot(p.a) << ");\n";
           done[si] = done[ci] = 1;
         } else {
-          o << "const auto " << v(i) << " = hamk::" << (p.op == HAMK_OP_SIN ? "sin" : "cos") << "<TRIG>(" << v(p.a)
+          o << "const auto " << v(i) << " = hamk::" << (p.op == HAMK_OP_SIN ? "sin" : "cos") << "<" << trig_mode << ">(" << v(p.a)
             << ", " << slot(p.a) << ");\n";
         }
       } break;
@@ -135,6 +142,11 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
           done[j] = 2;
         }
     }
+  }
+  if (slot_operand) {
+    slot_operand->assign(nslots, -1);
+    for (int i = 0; i < nops; ++i)
+      if (slot_of[i] >= 0) (*slot_operand)[slot_of[i]] = i;
   }
   return nslots;
 }
@@ -156,7 +168,8 @@ std::string generate_source(const SystemDesc& d) {
   o << "};\n    return w[k];\n  }\n";
   // coordinate map f: generalized -> cartesian                       (_sysCoords, Hamilton.hs:220)
   o << "  template <class A, int TRIG, class TC> __device__ __forceinline__ static void coords(const A (&in)[N], A (&x)[M], TC& tc) {\n";
-  const int ntrig_f = emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f");
+  std::vector<int> slot_operand;
+  const int ntrig_f = emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f", nullptr, nullptr, "tc", &slot_operand);
   for (int k = 0; k < d.m; ++k) o << "    x[" << k << "] = hamk::lift<A>(f" << d.f_outs[k] << ");\n";
   o << "  }\n";
   // potential                                                         (_sysPotential, Hamilton.hs:223 / :254)
@@ -166,11 +179,36 @@ std::string generate_source(const SystemDesc& d) {
   o << "    return hamk::lift<A>(u" << d.u_out << ");\n";
   o << "  }\n";
   // the same map, delivering each output to a sink as soon as it is defined
-  o << "  template <class A, int TRIG, class TC, class Sink> __device__ __forceinline__ static void coords_sink(const A (&in)[N], TC& tc, Sink& sink) {\n";
+  o << "  template <class A, int TRIG, class IN, class TC, class Sink> __device__ __forceinline__ static void coords_sink(const IN& in, TC& tc, Sink& sink) {\n";
   std::vector<std::vector<int>> sink_outs(d.f_ops.size());
   for (int k = 0; k < d.m; ++k) sink_outs[d.f_outs[k]].push_back(k);
   emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f", &sink_outs);
   o << "  }\n";
+  // f with a sink, followed by the potential on the same SSA values (u . f when U is cartesian):
+  // no array of M outputs is ever materialised
+  o << "  template <class A, int TRIG, class IN, class TC, class TCU, class Sink> __device__ __forceinline__ static A coords_sink_u(const IN& in, TC& tc, TCU& tcu, Sink& sink) {\n";
+  emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f", &sink_outs);
+  {
+    std::vector<std::string> u_in;
+    if (d.u_space == HAMK_U_CARTESIAN) for (int k = 0; k < d.m; ++k) u_in.push_back("f" + std::to_string(d.f_outs[k]));
+    else for (int j = 0; j < d.n; ++j) u_in.push_back("in[" + std::to_string(j) + "]");
+    emit_body(o, d.u_ops.data(), (int)d.u_ops.size(), "u", nullptr, &u_in, "tcu", nullptr, "hamk::TRIG_FULL");
+  }
+  o << "    return hamk::lift<A>(u" << d.u_out << ");\n";
+  o << "  }\n";
+  // which input (or -1) each sincos site of f takes as its operand: sites fed by inputs can be
+  // evaluated once per trajectory and shared (wave kernels)
+  o << "  __device__ __forceinline__ static constexpr int trig_input(int slot) {\n    constexpr int w[" << (ntrig_f > 0 ? ntrig_f : 1) << "] = {";
+  bool all_inputs = ntrig_f > 0;
+  for (int k = 0; k < ntrig_f; ++k) {
+    const int opi = slot_operand[k];
+    const int inp = (opi >= 0 && d.f_ops[opi].op == HAMK_OP_INPUT) ? d.f_ops[opi].a : -1;
+    if (inp < 0) all_inputs = false;
+    o << (k ? ", " : "") << inp;
+  }
+  if (ntrig_f == 0) o << "-1";
+  o << "};\n    return w[slot];\n  }\n";
+  o << "  static constexpr bool TRIG_ALL_INPUTS = " << (all_inputs ? "true" : "false") << ";\n";
   o << "  static constexpr int NTRIG_F = " << ntrig_f << ";\n";
   o << "  static constexpr int NTRIG_U = " << ntrig_u << ";\n";
   o << "};\n\n";

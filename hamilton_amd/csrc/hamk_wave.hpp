@@ -7,10 +7,13 @@
 // generated f/U code -- uniform control flow, the SIMT-friendly way to run forward mode --
 // at the one-direction jets Jet1<1> / Jet2<1>, with its own seed:
 //
-//   sweep 1  Jet1<1>, seed d = delta(i, lane): lane i gets column i of J (and dU/dq_i).  The
-//            column is staged in LDS as J[k][i] as soon as each x_k is defined (coords_sink).
-//   K        row i of K = J^T M J from the LDS-staged J: K[i][b] = sum_k m_k J[k][i] J[k][b]
-//            (broadcast LDS reads; the dense contraction of this path: 2 m n^2 flops).
+//   sweep 1  Jet1<1>, seed d = delta(i, lane): lane i gets column i of J (and dU/dq_i).  Each
+//            row J[k][.] passes through a 2 x NP-double LDS buffer the moment x_k is defined
+//            (coords_sink_u hands outputs to a sink) and is consumed at once:
+//   K        K = J^T M J accumulates inside the sink, one rank-1 update per x_k, in circulant
+//            form: lane i keeps K[i][(i+d) mod NP], d = 0..NP/2 -- every unordered pair once
+//            (half the 2 m n^2 flops of the dense contraction), rotated LDS reads are
+//            conflict-free.  No J tile, no second pass over it.
 //   solve    LDL^T across the group: pivot row broadcast with wavefront shuffles (width NP),
 //            rank-1 update of the row each lane keeps in registers; forward substitution by
 //            shuffles; back substitution reads L^T from a padded LDS tile (conflict-free).
@@ -19,8 +22,13 @@
 //            Hessian tensor of the reference (Hamilton.hs:222, 512 KiB per point at N = 32)
 //            never exists, not even one slice of it.
 //
+//   sincos   when every sincos site of f takes an input as operand (angles), lane j evaluates
+//            sincos(q_j) once and the pairs live in LDS: the sweeps read them (TRIG_REUSE)
+//            instead of every lane recomputing all n of them.
+//
 // State stays SoA in HBM (q[j*B + t]); a group loads/stores one value per lane.  LDS per
-// trajectory: max(M*NP, NP*(NP+1)) + 2*NP doubles (17 KiB at N = 32).
+// trajectory: NP*(NP+1) (K, then L) + 4*NP + 2*NTRIG doubles (10 KiB at N = 32): two 256-thread
+// blocks per CU, i.e. two wavefronts per SIMD.
 #pragma once
 #include "hamk_device.hpp"
 
@@ -35,9 +43,14 @@ template <int N> struct Geo {
 
 template <class S> struct Lds {
   static constexpr int NP = Geo<S::N>::NP;
-  static constexpr int TILE = (S::M * NP > NP * (NP + 1)) ? S::M * NP : NP * (NP + 1);   // J, later L (overlaid)
-  static constexpr int PER_TRAJ = TILE + 2 * NP;       // + two all-gather buffers
+  static constexpr int NT = (S::NTRIG_F > 0) ? S::NTRIG_F : 1;
+  static constexpr int TILE = NP * (NP + 1);            // K (row-major, stride NP+1), then L
+  static constexpr int PER_TRAJ = TILE + 4 * NP + 2 * NT;   // + row double-buffer + two all-gather buffers + sincos pairs
 };
+
+// sincos pairs of the trajectory's current point, resident in LDS (same member syntax as
+// hamk::TrigCache, so the generated code and trig_pair<> work on it unchanged)
+struct TrigLds { double* s; double* c; double* ax; double* as; double* ac; };
 
 // LDS written by some lanes of a wavefront and read by others of the same wavefront: DS
 // operations of one wave complete in order, so only the compiler has to be kept from moving them.
@@ -69,14 +82,30 @@ template <int N, int NP> HAMK_DEV void allgather(double* buf, int li, double min
   for (int j = 0; j < N; ++j) all[j] = buf[j];
 }
 
+// ---- inputs of a sweep, built on the fly from the LDS-resident q (and qd): no register arrays ----
+struct InJet1 {                                    // q_j with seed d = delta(j, lane)
+  const double* q; int li;
+  HAMK_DEV Jet1<1> operator[](int j) const { Jet1<1> r; r.v = q[j]; r.d[0] = (j == li) ? 1.0 : 0.0; return r; }
+};
+struct InJet2 {                                    // q_j along the common direction v with own e_lane
+  const double* q; const double* v; int li;
+  HAMK_DEV Jet2<1> operator[](int j) const {
+    Jet2<1> r; r.v = q[j]; r.dv = v[j]; r.d[0] = (j == li) ? 1.0 : 0.0; r.dd[0] = 0.0; return r;
+  }
+};
+
 // ---- sinks for coords_sink -------------------------------------------------------------------
-template <class S, int NP> struct SinkJ {          // sweep 1: stage column `li` of J, keep x for U(x)
-  double* J;
+template <class S, int NP> struct SinkK {          // sweep 1: K += m_k J[k][.]^T J[k][.], circulant storage
+  double* buf;                                     // [2][NP] row double-buffer
   int li;
-  Jet1<1> x[S::U_CART ? S::M : 1];
+  double rot[NP / 2 + 1];                          // K[li][(li + d) mod NP]
   template <int K> HAMK_DEV void put(const Jet1<1>& v) {
-    J[K * NP + li] = v.d[0];
-    if constexpr (S::U_CART) x[K] = v;
+    double* b = buf + (K & 1) * NP;
+    b[li] = v.d[0];
+    lds_sync();
+    const double a = S::inertia(K) * v.d[0];
+#pragma unroll
+    for (int d = 0; d <= NP / 2; ++d) rot[d] = fma(a, b[(li + d) & (NP - 1)], rot[d]);
   }
 };
 template <class S> struct SinkT {                  // sweep 2: dT/dq_i = -sum_k m_k x_k.dv x_k.dd
@@ -91,43 +120,67 @@ template <class S> struct SinkP {                  // momenta: p_i = sum_k J[k][
 // ---- per-group context -------------------------------------------------------------------------
 template <class S> struct Ctx {
   static constexpr int N = S::N, M = S::M, NP = Geo<N>::NP;
-  double* tile;      // [TILE]
+  double* tile;      // [TILE] K, then L
+  double* rowbuf;    // [2][NP] J row double-buffer
   double* ga;        // [NP] all-gather buffer a
   double* gb;        // [NP] all-gather buffer b
+  TrigLds trig;      // [NT] sincos pairs in LDS
   int li;            // lane within the group = AD direction
 };
 
-// Sweep 1 + K + LDL^T.  On return: `row` holds L[li][j] (j < li), `dinv` = 1/d_li; gU = dU/dq_li;
-// the tile holds L^T-readable padded L (row-major, stride NP+1).  q_all: all n positions.
+// Fill the LDS-resident sincos pairs cooperatively when every site's operand is an input.
+// Returns the TRIG mode the first sweep must use.
+template <class S> HAMK_DEV void cooperative_trig(const Ctx<S>& c, double qi) {
+  if constexpr (S::TRIG_ALL_INPUTS && S::NTRIG_F > 0) {
+    constexpr int NP = Ctx<S>::NP;
+    double sv, cv;
+    sincos_f64(qi, sv, cv);                               // lane j: sincos(q_j), once per trajectory
+    lds_sync();
+    c.rowbuf[c.li] = sv; c.rowbuf[NP + c.li] = cv;        // (the row buffer is free here)
+    lds_sync();
+    if (c.li < S::NTRIG_F) {                              // lane k fills site k
+      const int src = S::trig_input(c.li);
+      c.trig.s[c.li] = c.rowbuf[src];
+      c.trig.c[c.li] = c.rowbuf[NP + src];
+    }
+    static_assert(S::NTRIG_F <= NP, "more sincos sites than lanes in a group");
+    lds_sync();
+  }
+}
+
+// Sweep 1 (with K accumulated in the sink) + LDL^T.  On return: `row` holds L[li][j] (j < li),
+// `dinv` = 1/d_li; gU = dU/dq_li; the tile holds L (row-major, stride NP+1).
 template <class S>
-HAMK_DEV void factor(const Ctx<S>& c, const double (&q)[S::N], double (&row)[S::N], double& dinv, double& gU,
-                     double& U, TrigCache<S::NTRIG_F>& tc, int& st) {
-  constexpr int N = S::N, M = S::M, NP = Ctx<S>::NP;
+HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& dinv, double& gU, double& U, int& st) {
+  constexpr int N = S::N, NP = Ctx<S>::NP;
+  constexpr int TRIG1 = (S::TRIG_ALL_INPUTS && S::NTRIG_F > 0) ? TRIG_REUSE : TRIG_FULL;
   const int li = c.li;
-  lds_sync();                                             // previous users of the tile are done
+  cooperative_trig<S>(c, qi);
+  double rot[NP / 2 + 1];
   {
-    Jet1<1> qj[N];
+    InJet1 qj{c.ga, li};                                  // q lives in the gather buffer a
+    SinkK<S, NP> sink;
+    sink.buf = c.rowbuf; sink.li = li;
 #pragma unroll
-    for (int j = 0; j < N; ++j) { qj[j].v = q[j]; qj[j].d[0] = (j == li) ? 1.0 : 0.0; }
-    SinkJ<S, NP> sink;
-    sink.J = c.tile; sink.li = li;
-    S::template coords_sink<Jet1<1>, TRIG_FULL>(qj, tc, sink);
+    for (int d = 0; d <= NP / 2; ++d) sink.rot[d] = 0.0;
     TrigCache<S::NTRIG_U> tu;
-    Jet1<1> u;
-    if constexpr (S::U_CART) u = S::template potential<Jet1<1>, TRIG_FULL>(sink.x, tu);
-    else u = S::template potential<Jet1<1>, TRIG_FULL>(qj, tu);
+    TrigLds tl = c.trig;
+    const Jet1<1> u = S::template coords_sink_u<Jet1<1>, TRIG1>(qj, tl, tu, sink);
     gU = u.d[0]; U = u.v;
+#pragma unroll
+    for (int d = 0; d <= NP / 2; ++d) rot[d] = sink.rot[d];
+  }
+  // circulant -> full symmetric K in the tile, then each lane takes its row
+  lds_sync();                                             // previous readers of the tile (L of the last solve) are done
+#pragma unroll
+  for (int d = 0; d <= NP / 2; ++d) {
+    const int b = (li + d) & (NP - 1);
+    c.tile[li * (NP + 1) + b] = rot[d];
+    c.tile[b * (NP + 1) + li] = rot[d];
   }
   lds_sync();
-  // K row: K[li][b] = sum_k (m_k J[k][li]) J[k][b]
 #pragma unroll
-  for (int b = 0; b < N; ++b) row[b] = 0.0;
-#pragma unroll 2
-  for (int k = 0; k < M; ++k) {
-    const double a = S::inertia(k) * c.tile[k * NP + li];
-#pragma unroll
-    for (int b = 0; b < N; ++b) row[b] = fma(a, c.tile[k * NP + b], row[b]);
-  }
+  for (int b = 0; b < N; ++b) row[b] = c.tile[li * (NP + 1) + b];
   // LDL^T, right-looking, rows distributed over lanes
   bool ok = true;
   dinv = 0.0;
@@ -146,9 +199,9 @@ HAMK_DEV void factor(const Ctx<S>& c, const double (&q)[S::N], double (&row)[S::
     if (li > j) row[j] = lij;
   }
   if (!ok && li < N) st |= ST_SINGULAR;                    // no pivoting fallback in the wave kernels
-  // L to LDS, row-major with stride NP+1: conflict-free for both the row writes and the
-  // column reads of the back substitution
-  lds_sync();                                             // J no longer needed: overlay
+  // L over K in the tile (stride NP+1: conflict-free for these row writes and for the column
+  // reads of the back substitution)
+  lds_sync();
 #pragma unroll
   for (int j = 0; j < N; ++j) c.tile[li * (NP + 1) + j] = row[j];
   lds_sync();
@@ -177,19 +230,20 @@ HAMK_DEV double solve(const Ctx<S>& c, const double (&row)[S::N], double dinv, d
 // hamEqs for the group's trajectory: lane i returns (dq_i, dp_i).           Hamilton.hs:370-387
 template <class S>
 HAMK_DEV void ham_eqs(const Ctx<S>& c, double qi, double pi, double& dqi, double& dpi, int& st) {
-  constexpr int N = S::N, NP = Ctx<S>::NP;
-  double q[N], row[N], dinv, gU, U;
-  TrigCache<S::NTRIG_F> tc;
-  allgather<N, NP>(c.ga, c.li, qi, q);
-  factor<S>(c, q, row, dinv, gU, U, tc, st);
+  constexpr int N = S::N;
+  double row[N], dinv, gU, U;
+  lds_sync();
+  c.ga[c.li] = qi;                                        // all-gather q through LDS; it stays there
+  lds_sync();
+  factor<S>(c, qi, row, dinv, gU, U, st);
   const double vi = solve<S>(c, row, dinv, pi);
-  double v[N];
-  allgather<N, NP>(c.gb, c.li, vi, v);
-  Jet2<1> q2[N];
-#pragma unroll
-  for (int j = 0; j < N; ++j) { q2[j].v = q[j]; q2[j].dv = v[j]; q2[j].d[0] = (j == c.li) ? 1.0 : 0.0; q2[j].dd[0] = 0.0; }
+  lds_sync();
+  c.gb[c.li] = vi;                                        // ... and qd
+  lds_sync();
+  InJet2 q2{c.ga, c.gb, c.li};
   SinkT<S> sink;
-  S::template coords_sink<Jet2<1>, TRIG_REUSE>(q2, tc, sink);
+  TrigLds tl = c.trig;
+  S::template coords_sink<Jet2<1>, TRIG_REUSE>(q2, tl, sink);   // sincos pairs of sweep 1, from LDS
   dqi = vi;
   dpi = -(sink.dT + gU);
 }
@@ -211,8 +265,12 @@ template <class S> struct Where {
     t = (tt < B) ? tt : B - 1;
     double* base = smem + (size_t)(wv * G + grp) * Lds<S>::PER_TRAJ;
     c.tile = base;
-    c.ga = base + Lds<S>::TILE;
+    c.rowbuf = base + Lds<S>::TILE;
+    c.ga = c.rowbuf + 2 * NP;
     c.gb = c.ga + NP;
+    c.trig.s = c.gb + NP;
+    c.trig.c = c.trig.s + Lds<S>::NT;
+    c.trig.ax = c.trig.as = c.trig.ac = nullptr;
   }
 };
 
@@ -267,16 +325,15 @@ HAMK_DEV void hameqs_body(double* smem, const double* q, const double* p, double
 // momenta / toPhase: one Jet2<1> sweep along qd                                  Hamilton.hs:262-284
 template <class S>
 HAMK_DEV double momentum(const Ctx<S>& c, double qi, double vi) {
-  constexpr int N = S::N, NP = Ctx<S>::NP;
-  double q[N], v[N];
-  allgather<N, NP>(c.ga, c.li, qi, q);
-  allgather<N, NP>(c.gb, c.li, vi, v);
-  Jet2<1> q2[N];
-#pragma unroll
-  for (int j = 0; j < N; ++j) { q2[j].v = q[j]; q2[j].dv = v[j]; q2[j].d[0] = (j == c.li) ? 1.0 : 0.0; q2[j].dd[0] = 0.0; }
-  TrigCache<S::NTRIG_F> tc;
+  constexpr int TRIG1 = (S::TRIG_ALL_INPUTS && S::NTRIG_F > 0) ? TRIG_REUSE : TRIG_FULL;
+  lds_sync();
+  c.ga[c.li] = qi; c.gb[c.li] = vi;
+  lds_sync();
+  cooperative_trig<S>(c, qi);
+  InJet2 q2{c.ga, c.gb, c.li};
   SinkP<S> sink;
-  S::template coords_sink<Jet2<1>, TRIG_FULL>(q2, tc, sink);
+  TrigLds tl = c.trig;
+  S::template coords_sink<Jet2<1>, TRIG1>(q2, tl, sink);
   return sink.p;
 }
 
@@ -293,10 +350,11 @@ HAMK_DEV void to_phase_body(double* smem, const double* q, const double* qd, dou
 template <class S>
 HAMK_DEV double velocity(const Ctx<S>& c, double qi, double pi, double& U, int& st) {
   constexpr int N = S::N, NP = Ctx<S>::NP;
-  double q[N], row[N], dinv, gU;
-  TrigCache<S::NTRIG_F> tc;
-  allgather<N, NP>(c.ga, c.li, qi, q);
-  factor<S>(c, q, row, dinv, gU, U, tc, st);
+  double row[N], dinv, gU;
+  lds_sync();
+  c.ga[c.li] = qi;
+  lds_sync();
+  factor<S>(c, qi, row, dinv, gU, U, st);
   return solve<S>(c, row, dinv, pi);
 }
 
@@ -506,8 +564,8 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
 
 // Same eight kernel names as HAMK_INSTANTIATE, wave-cooperative bodies.
 #define HAMK_INSTANTIATE_WAVE(S)                                                                                 \
-  extern "C" __global__ void __launch_bounds__(256) hamk_rk4_steps_k(double* q, double* p, long long B,          \
-                                                                      double dt, int nsteps, int* status) {      \
+  extern "C" __global__ void __launch_bounds__(256, 2) hamk_rk4_steps_k(double* q, double* p, long long B,       \
+                                                                         double dt, int nsteps, int* status) {   \
     HAMK_WAVE_SMEM(S);                                                                                           \
     hamk::wave::rk4_body<S>(smem, q, p, B, dt, nsteps, status);                                                  \
   }                                                                                                              \

@@ -27,7 +27,7 @@ def run(name, B, nsteps, wave, reps=3):
 
 if __name__ == "__main__":
     cfgs = [("chain8", 65536, 50, "0"), ("chain8", 65536, 50, "1"), ("chain12", 65536, 20, "0"), ("chain12", 65536, 20, "1"),
-            ("chain16", 65536, 20, "0"), ("chain16", 65536, 20, "1"), ("chain32", 65536, 10, None)]
+            ("chain16", 65536, 20, "0"), ("chain16", 65536, 20, "1"), ("chain20", 65536, 10, None), ("chain32", 65536, 10, None)]
     only = sys.argv[1:]
     for name, B, ns, wave in cfgs:
         if only and name not in only: continue
