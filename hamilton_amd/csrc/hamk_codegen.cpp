@@ -99,17 +99,21 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
     if (slot_of[operand] < 0) slot_of[operand] = nslots++;
     return std::string(tc_name) + ", " + std::to_string(slot_of[operand]);
   };
-  auto v = [&](int i) { return std::string(pfx) + std::to_string(i); };
+  // INPUT values are not materialised: every use reads `in[j]` in place.  With array inputs
+  // that is a reference; with the wave kernels' LDS-backed proxies it keeps 32 input jets from
+  // all being live from the top of the function (the tape lists its inputs first).
+  auto v = [&](int i) {
+    if (ops[i].op == HAMK_OP_INPUT)
+      return input_exprs ? (*input_exprs)[ops[i].a] : std::string("in[") + std::to_string(ops[i].a) + "]";
+    return std::string(pfx) + std::to_string(i);
+  };
   for (int i = 0; i < nops; ++i) {
     if (done[i]) continue;
     const hamk_op& p = ops[i];
     o << "    ";
     switch (p.op) {
       case HAMK_OP_CONST: o << "const double " << v(i) << " = " << lit(p.c) << ";\n"; break;
-      case HAMK_OP_INPUT:
-        if (input_exprs) o << "const auto& " << v(i) << " = " << (*input_exprs)[p.a] << ";\n";
-        else o << "const A " << v(i) << " = in[" << p.a << "];\n";
-        break;
+      case HAMK_OP_INPUT: o << "// input " << p.a << "\n"; break;
       case HAMK_OP_ADD: o << "const auto " << v(i) << " = " << v(p.a) << " + " << v(p.b) << ";\n"; break;
       case HAMK_OP_SUB: o << "const auto " << v(i) << " = " << v(p.a) << " - " << v(p.b) << ";\n"; break;
       case HAMK_OP_MUL: o << "const auto " << v(i) << " = " << v(p.a) << " * " << v(p.b) << ";\n"; break;

@@ -27,7 +27,7 @@
 //            instead of every lane recomputing all n of them.
 //
 // State stays SoA in HBM (q[j*B + t]); a group loads/stores one value per lane.  LDS per
-// trajectory: NP*(NP+1) (K, then L) + 4*NP + 2*NTRIG doubles (10 KiB at N = 32): two 256-thread
+// trajectory: NP*(NP+1) (K, then L) + 4*NP + 2*NTRIG doubles (9.75 KiB at N = 32): two 256-thread
 // blocks per CU, i.e. two wavefronts per SIMD.
 #pragma once
 #include "hamk_device.hpp"
@@ -45,7 +45,7 @@ template <class S> struct Lds {
   static constexpr int NP = Geo<S::N>::NP;
   static constexpr int NT = (S::NTRIG_F > 0) ? S::NTRIG_F : 1;
   static constexpr int TILE = NP * (NP + 1);            // K (row-major, stride NP+1), then L
-  static constexpr int PER_TRAJ = TILE + 4 * NP + 2 * NT;   // + row double-buffer + two all-gather buffers + sincos pairs
+  static constexpr int PER_TRAJ = TILE + 4 * NP + 2 * NT;   // + row buffer (row stored twice) + two all-gather buffers + sincos pairs
 };
 
 // sincos pairs of the trajectory's current point, resident in LDS (same member syntax as
@@ -58,9 +58,20 @@ HAMK_DEV void lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // also a scheduling barrier: the phases of an evaluation must not be interleaved by the
+  // machine scheduler (it otherwise overlaps them freely and needs ~400 VGPRs for a stream
+  // whose phases need at most ~200 each)
+  __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NP> HAMK_DEV double bcast(double x, int src) { return __shfl(x, src, NP); }
+// Value of lane `src` of the caller's group, for all lanes of the group.  grp4 = 4 * (first lane
+// of the group): the byte index ds_bpermute wants is grp4 + 4*src, and with src a literal the
+// 4*src goes into the instruction's offset field -- no per-source index registers.
+HAMK_DEV double bcast4(double x, int grp4, int src) {
+  const int lo = __builtin_amdgcn_ds_bpermute(grp4 + 4 * src, __double2loint(x));
+  const int hi = __builtin_amdgcn_ds_bpermute(grp4 + 4 * src, __double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
 
 template <int NP> HAMK_DEV double group_max(double x) {
 #pragma unroll
@@ -96,16 +107,17 @@ struct InJet2 {                                    // q_j along the common direc
 
 // ---- sinks for coords_sink -------------------------------------------------------------------
 template <class S, int NP> struct SinkK {          // sweep 1: K += m_k J[k][.]^T J[k][.], circulant storage
-  double* buf;                                     // [2][NP] row double-buffer
-  int li;
-  double rot[NP / 2 + 1];                          // K[li][(li + d) mod NP]
-  template <int K> HAMK_DEV void put(const Jet1<1>& v) {
-    double* b = buf + (K & 1) * NP;
-    b[li] = v.d[0];
+  double* buf;                                     // [2*NP]: the row stored twice back to back so that
+  int li;                                          //   b[li + d] never wraps: one base register + immediate
+  double rot[NP / 2 + 1];                          //   offsets.  rot[d] = K[li][(li+d) mod NP].  One buffer is
+  template <int K> HAMK_DEV void put(const Jet1<1>& v) {   // enough: DS operations of a wave execute in order.
+    double* b = buf + li;
+    b[0] = v.d[0];
+    b[NP] = v.d[0];
     lds_sync();
     const double a = S::inertia(K) * v.d[0];
 #pragma unroll
-    for (int d = 0; d <= NP / 2; ++d) rot[d] = fma(a, b[(li + d) & (NP - 1)], rot[d]);
+    for (int d = 0; d <= NP / 2; ++d) rot[d] = fma(a, b[d], rot[d]);
   }
 };
 template <class S> struct SinkT {                  // sweep 2: dT/dq_i = -sum_k m_k x_k.dv x_k.dd
@@ -118,14 +130,26 @@ template <class S> struct SinkP {                  // momenta: p_i = sum_k J[k][
 };
 
 // ---- per-group context -------------------------------------------------------------------------
+// LDS addresses are formed as smem + off + constant with `off` (and the lane id) re-defined
+// opaquely at the top of every evaluation (`launder`): the constant then folds into the DS
+// instruction's offset field, and loop-invariant code motion cannot hoist hundreds of distinct
+// LDS addresses out of the stepping loop into VGPRs (measured before: 365 spilled registers and
+// 1.4 KiB of scratch per lane, 78 % of the wave cycles waiting).
 template <class S> struct Ctx {
   static constexpr int N = S::N, M = S::M, NP = Geo<N>::NP;
-  double* tile;      // [TILE] K, then L
-  double* rowbuf;    // [2][NP] J row double-buffer
-  double* ga;        // [NP] all-gather buffer a
-  double* gb;        // [NP] all-gather buffer b
-  TrigLds trig;      // [NT] sincos pairs in LDS
+  double* smem;      // the block's __shared__ array
+  int off;           // this trajectory's offset into it (doubles)
   int li;            // lane within the group = AD direction
+  HAMK_DEV double* tile() const { return smem + off; }                                   // [TILE] K, then L
+  HAMK_DEV double* rowbuf() const { return smem + off + Lds<S>::TILE; }                  // [2*NP] J row buffer
+  HAMK_DEV double* ga() const { return smem + off + Lds<S>::TILE + 2 * NP; }             // [NP] q
+  HAMK_DEV double* gb() const { return smem + off + Lds<S>::TILE + 3 * NP; }             // [NP] qd
+  HAMK_DEV TrigLds trig() const {
+    TrigLds t; t.s = smem + off + Lds<S>::TILE + 4 * NP; t.c = t.s + Lds<S>::NT; t.ax = t.as = t.ac = nullptr; return t;
+  }
+  int g4;            // 4 * (first lane of the group within the wavefront)
+  HAMK_DEV int grp4() const { return g4; }
+  HAMK_DEV Ctx launder() const { Ctx c = *this; asm volatile("" : "+v"(c.off), "+v"(c.li), "+v"(c.g4)); return c; }
 };
 
 // Fill the LDS-resident sincos pairs cooperatively when every site's operand is an input.
@@ -136,12 +160,12 @@ template <class S> HAMK_DEV void cooperative_trig(const Ctx<S>& c, double qi) {
     double sv, cv;
     sincos_f64(qi, sv, cv);                               // lane j: sincos(q_j), once per trajectory
     lds_sync();
-    c.rowbuf[c.li] = sv; c.rowbuf[NP + c.li] = cv;        // (the row buffer is free here)
+    c.rowbuf()[c.li] = sv; c.rowbuf()[NP + c.li] = cv;        // (the row buffer is free here)
     lds_sync();
     if (c.li < S::NTRIG_F) {                              // lane k fills site k
       const int src = S::trig_input(c.li);
-      c.trig.s[c.li] = c.rowbuf[src];
-      c.trig.c[c.li] = c.rowbuf[NP + src];
+      c.trig().s[c.li] = c.rowbuf()[src];
+      c.trig().c[c.li] = c.rowbuf()[NP + src];
     }
     static_assert(S::NTRIG_F <= NP, "more sincos sites than lanes in a group");
     lds_sync();
@@ -158,13 +182,13 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
   cooperative_trig<S>(c, qi);
   double rot[NP / 2 + 1];
   {
-    InJet1 qj{c.ga, li};                                  // q lives in the gather buffer a
+    InJet1 qj{c.ga(), li};                                  // q lives in the gather buffer a
     SinkK<S, NP> sink;
-    sink.buf = c.rowbuf; sink.li = li;
+    sink.buf = c.rowbuf(); sink.li = li;
 #pragma unroll
     for (int d = 0; d <= NP / 2; ++d) sink.rot[d] = 0.0;
     TrigCache<S::NTRIG_U> tu;
-    TrigLds tl = c.trig;
+    TrigLds tl = c.trig();
     const Jet1<1> u = S::template coords_sink_u<Jet1<1>, TRIG1>(qj, tl, tu, sink);
     gU = u.d[0]; U = u.v;
 #pragma unroll
@@ -175,25 +199,25 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
 #pragma unroll
   for (int d = 0; d <= NP / 2; ++d) {
     const int b = (li + d) & (NP - 1);
-    c.tile[li * (NP + 1) + b] = rot[d];
-    c.tile[b * (NP + 1) + li] = rot[d];
+    c.tile()[li * (NP + 1) + b] = rot[d];
+    c.tile()[b * (NP + 1) + li] = rot[d];
   }
   lds_sync();
 #pragma unroll
-  for (int b = 0; b < N; ++b) row[b] = c.tile[li * (NP + 1) + b];
+  for (int b = 0; b < N; ++b) row[b] = c.tile()[li * (NP + 1) + b];
   // LDL^T, right-looking, rows distributed over lanes
   bool ok = true;
   dinv = 0.0;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    const double dj = bcast<NP>(row[j], j);
+    const double dj = bcast4(row[j], c.grp4(), j);
     ok = ok && (dj > 0.0);
     const double inv = frcp(dj);
     const double lij = row[j] * inv;
     if (li == j) dinv = inv;
 #pragma unroll
     for (int k = j + 1; k < N; ++k) {
-      const double rjk = bcast<NP>(row[k], j);             // K[j][k] after the first j updates
+      const double rjk = bcast4(row[k], c.grp4(), j);             // K[j][k] after the first j updates
       if (li > j) row[k] = fma(-lij, rjk, row[k]);
     }
     if (li > j) row[j] = lij;
@@ -203,7 +227,7 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
   // reads of the back substitution)
   lds_sync();
 #pragma unroll
-  for (int j = 0; j < N; ++j) c.tile[li * (NP + 1) + j] = row[j];
+  for (int j = 0; j < N; ++j) c.tile()[li * (NP + 1) + j] = row[j];
   lds_sync();
 }
 
@@ -215,34 +239,39 @@ HAMK_DEV double solve(const Ctx<S>& c, const double (&row)[S::N], double dinv, d
   double z = rhs;
 #pragma unroll
   for (int j = 0; j < N; ++j) {                            // L z = rhs
-    const double zj = bcast<NP>(z, j);
+    const double zj = bcast4(z, c.grp4(), j);
     if (li > j) z = fma(-row[j], zj, z);
   }
   double v = z * dinv;                                     // D y = z
 #pragma unroll
   for (int k = N - 1; k >= 0; --k) {                       // L^T v = y
-    const double vk = bcast<NP>(v, k);
-    if (li < k) v = fma(-c.tile[k * (NP + 1) + li], vk, v);
+    const double vk = bcast4(v, c.grp4(), k);
+    if (li < k) v = fma(-c.tile()[k * (NP + 1) + li], vk, v);
   }
   return v;
 }
 
 // hamEqs for the group's trajectory: lane i returns (dq_i, dp_i).           Hamilton.hs:370-387
 template <class S>
-HAMK_DEV void ham_eqs(const Ctx<S>& c, double qi, double pi, double& dqi, double& dpi, int& st) {
+HAMK_DEV void ham_eqs(const Ctx<S>& c0, double qi, double pi, double& dqi, double& dpi, int& st) {
   constexpr int N = S::N;
+  const Ctx<S> c = c0.launder();
   double row[N], dinv, gU, U;
   lds_sync();
-  c.ga[c.li] = qi;                                        // all-gather q through LDS; it stays there
+  c.ga()[c.li] = qi;                                        // all-gather q through LDS; it stays there
   lds_sync();
   factor<S>(c, qi, row, dinv, gU, U, st);
   const double vi = solve<S>(c, row, dinv, pi);
   lds_sync();
-  c.gb[c.li] = vi;                                        // ... and qd
+  c.gb()[c.li] = vi;                                        // ... and qd
   lds_sync();
-  InJet2 q2{c.ga, c.gb, c.li};
+  // Fresh opaque addresses for the second sweep: with provably identical LDS loads the compiler
+  // merges the value/gradient parts of sweep 2 into sweep 1 and keeps ~150 registers alive across
+  // the whole factorisation to save a few hundred cheap instructions.
+  const Ctx<S> c2 = c.launder();
+  InJet2 q2{c2.ga(), c2.gb(), c2.li};
   SinkT<S> sink;
-  TrigLds tl = c.trig;
+  TrigLds tl = c2.trig();
   S::template coords_sink<Jet2<1>, TRIG_REUSE>(q2, tl, sink);   // sincos pairs of sweep 1, from LDS
   dqi = vi;
   dpi = -(sink.dT + gU);
@@ -263,14 +292,9 @@ template <class S> struct Where {
     real = tt < B;
     live = real && (c.li < N);
     t = (tt < B) ? tt : B - 1;
-    double* base = smem + (size_t)(wv * G + grp) * Lds<S>::PER_TRAJ;
-    c.tile = base;
-    c.rowbuf = base + Lds<S>::TILE;
-    c.ga = c.rowbuf + 2 * NP;
-    c.gb = c.ga + NP;
-    c.trig.s = c.gb + NP;
-    c.trig.c = c.trig.s + Lds<S>::NT;
-    c.trig.ax = c.trig.as = c.trig.ac = nullptr;
+    c.smem = smem;
+    c.off = (wv * G + grp) * Lds<S>::PER_TRAJ;
+    c.g4 = 4 * grp * NP;
   }
 };
 
@@ -324,15 +348,16 @@ HAMK_DEV void hameqs_body(double* smem, const double* q, const double* p, double
 
 // momenta / toPhase: one Jet2<1> sweep along qd                                  Hamilton.hs:262-284
 template <class S>
-HAMK_DEV double momentum(const Ctx<S>& c, double qi, double vi) {
+HAMK_DEV double momentum(const Ctx<S>& c0, double qi, double vi) {
+  const Ctx<S> c = c0.launder();
   constexpr int TRIG1 = (S::TRIG_ALL_INPUTS && S::NTRIG_F > 0) ? TRIG_REUSE : TRIG_FULL;
   lds_sync();
-  c.ga[c.li] = qi; c.gb[c.li] = vi;
+  c.ga()[c.li] = qi; c.gb()[c.li] = vi;
   lds_sync();
   cooperative_trig<S>(c, qi);
-  InJet2 q2{c.ga, c.gb, c.li};
+  InJet2 q2{c.ga(), c.gb(), c.li};
   SinkP<S> sink;
-  TrigLds tl = c.trig;
+  TrigLds tl = c.trig();
   S::template coords_sink<Jet2<1>, TRIG1>(q2, tl, sink);
   return sink.p;
 }
@@ -348,11 +373,12 @@ HAMK_DEV void to_phase_body(double* smem, const double* q, const double* qd, dou
 
 // velocities / fromPhase                                                          Hamilton.hs:316-337
 template <class S>
-HAMK_DEV double velocity(const Ctx<S>& c, double qi, double pi, double& U, int& st) {
+HAMK_DEV double velocity(const Ctx<S>& c0, double qi, double pi, double& U, int& st) {
+  const Ctx<S> c = c0.launder();
   constexpr int N = S::N, NP = Ctx<S>::NP;
   double row[N], dinv, gU;
   lds_sync();
-  c.ga[c.li] = qi;
+  c.ga()[c.li] = qi;
   lds_sync();
   factor<S>(c, qi, row, dinv, gU, U, st);
   return solve<S>(c, row, dinv, pi);
@@ -376,7 +402,7 @@ HAMK_DEV void from_phase_body(double* smem, const double* q, const double* p, do
 template <class S> HAMK_DEV double potential_only(const Ctx<S>& c, double qi) {
   constexpr int N = S::N, NP = Ctx<S>::NP;
   double q[N];
-  allgather<N, NP>(c.ga, c.li, qi, q);
+  allgather<N, NP>(c.ga(), c.li, qi, q);
   return potential_value<S>(q);
 }
 
@@ -428,7 +454,7 @@ template <class S> HAMK_DEV void coords_body(double* smem, const double* q, doub
   Where<S> w(smem, B);
   const int j = (w.c.li < N) ? w.c.li : 0;
   double qq[N], xx[M];
-  allgather<N, NP>(w.c.ga, w.c.li, q[(i64)j * B + w.t], qq);
+  allgather<N, NP>(w.c.ga(), w.c.li, q[(i64)j * B + w.t], qq);
   TrigCache<S::NTRIG_F> tc;
   S::template coords<double, TRIG_FULL>(qq, xx, tc);
   // every lane of the group holds all M outputs; lane li writes outputs li, li + NP, ...

@@ -1,0 +1,13 @@
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hamilton_amd import api, examples as E
+name = sys.argv[1] if len(sys.argv) > 1 else "chain32"
+spec = E.get(name); s = api.system_from_spec(spec)
+B = 65536
+q, qd = E.sample_config(spec, 0, B)
+ph = api.toPhase(s, api.Config(torch.from_numpy(q).cuda(), torch.from_numpy(qd).cuda()))
+st = api.Phase(ph.positions.clone(), ph.momenta.clone())
+for _ in range(2):
+    api.rk4Steps(spec.dt, 4, s, st, inplace=True)
+torch.cuda.synchronize()
