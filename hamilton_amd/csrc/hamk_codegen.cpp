@@ -155,6 +155,14 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
   return nslots;
 }
 
+// Name of value `id` in an emitted body: inputs are never materialised (see emit_body).
+static std::string value_name(const std::vector<hamk_op>& ops, const char* pfx, int id,
+                              const std::vector<std::string>* input_exprs = nullptr) {
+  if (ops[id].op == HAMK_OP_INPUT)
+    return input_exprs ? (*input_exprs)[ops[id].a] : std::string("in[") + std::to_string(ops[id].a) + "]";
+  return std::string(pfx) + std::to_string(id);
+}
+
 std::string generate_source(const SystemDesc& d) {
   std::ostringstream o;
   o << "// generated by libhamk (hamk_codegen.cpp) from the expression tape of one System " << d.m << " " << d.n << "\n";
@@ -174,13 +182,13 @@ std::string generate_source(const SystemDesc& d) {
   o << "  template <class A, int TRIG, class TC> __device__ __forceinline__ static void coords(const A (&in)[N], A (&x)[M], TC& tc) {\n";
   std::vector<int> slot_operand;
   const int ntrig_f = emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f", nullptr, nullptr, "tc", &slot_operand);
-  for (int k = 0; k < d.m; ++k) o << "    x[" << k << "] = hamk::lift<A>(f" << d.f_outs[k] << ");\n";
+  for (int k = 0; k < d.m; ++k) o << "    x[" << k << "] = hamk::lift<A>(" << value_name(d.f_ops, "f", d.f_outs[k]) << ");\n";
   o << "  }\n";
   // potential                                                         (_sysPotential, Hamilton.hs:223 / :254)
   const int nu = d.u_space == HAMK_U_CARTESIAN ? d.m : d.n;
   o << "  template <class A, int TRIG, class TC> __device__ __forceinline__ static A potential(const A (&in)[" << nu << "], TC& tc) {\n";
   const int ntrig_u = emit_body(o, d.u_ops.data(), (int)d.u_ops.size(), "u");
-  o << "    return hamk::lift<A>(u" << d.u_out << ");\n";
+  o << "    return hamk::lift<A>(" << value_name(d.u_ops, "u", d.u_out) << ");\n";
   o << "  }\n";
   // the same map, delivering each output to a sink as soon as it is defined
   o << "  template <class A, int TRIG, class IN, class TC, class Sink> __device__ __forceinline__ static void coords_sink(const IN& in, TC& tc, Sink& sink) {\n";
@@ -194,11 +202,11 @@ std::string generate_source(const SystemDesc& d) {
   emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f", &sink_outs);
   {
     std::vector<std::string> u_in;
-    if (d.u_space == HAMK_U_CARTESIAN) for (int k = 0; k < d.m; ++k) u_in.push_back("f" + std::to_string(d.f_outs[k]));
+    if (d.u_space == HAMK_U_CARTESIAN) for (int k = 0; k < d.m; ++k) u_in.push_back(value_name(d.f_ops, "f", d.f_outs[k]));
     else for (int j = 0; j < d.n; ++j) u_in.push_back("in[" + std::to_string(j) + "]");
     emit_body(o, d.u_ops.data(), (int)d.u_ops.size(), "u", nullptr, &u_in, "tcu", nullptr, "hamk::TRIG_FULL");
+    o << "    return hamk::lift<A>(" << value_name(d.u_ops, "u", d.u_out, &u_in) << ");\n";
   }
-  o << "    return hamk::lift<A>(u" << d.u_out << ");\n";
   o << "  }\n";
   // which input (or -1) each sincos site of f takes as its operand: sites fed by inputs can be
   // evaluated once per trajectory and shared (wave kernels)

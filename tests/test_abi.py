@@ -100,3 +100,13 @@ def test_kernels_stay_within_branch_reach(hamk_lib, name):
     # every device function inlined: no call frames, no scratch for calls (a recursive helper
     # once slipped through as a real call and cost 120 VGPRs + spills in the adaptive stepper)
     assert s.num_device_functions == 8, (name, s.num_device_functions)
+
+
+@pytest.mark.parametrize("name", ["room", "spring", "twoBody", "opcodeZoo", "chain20"])
+def test_wave_specialisation_compiles_for_gfx950(hamk_lib, monkeypatch, name):
+    """The wave-cooperative module (hamk_wave.hpp) builds for gfx950 too -- forced here on small
+    systems, incl. `room` whose coordinate map is the identity (outputs that are inputs)."""
+    from hamilton_amd import api
+    monkeypatch.setenv("HAMK_WAVE", "1")
+    s = api.system_from_spec(E.get(name))
+    assert "HAMK_INSTANTIATE_WAVE(HamkSys)" in s.source and s.num_device_functions == 8
