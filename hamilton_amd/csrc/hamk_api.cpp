@@ -55,6 +55,11 @@ struct hamk_system {
   hipModule_t module = nullptr;
   hipFunction_t fn[K__COUNT] = {};
   hipStream_t stream = nullptr;
+  // grow-only device staging for HAMK_MEM_HOST calls (slot i serves the i-th staged array of a
+  // call): the reference's own usage pattern is one small stepHam per frame (Examples.hs:429),
+  // where a hipMalloc/hipFree pair per array per call would dominate
+  std::vector<void*> stage_buf;
+  std::vector<size_t> stage_cap;
   // small device scratch for evolveHam's time grid
   double* d_ts = nullptr;
   size_t d_ts_cap = 0;
@@ -151,6 +156,8 @@ static int bind_device(hamk_system* s) {
     hipModuleUnload(s->module);
     s->module = nullptr;
     if (s->d_ts) { hipFree(s->d_ts); s->d_ts = nullptr; s->d_ts_cap = 0; }
+    for (void*& b : s->stage_buf) if (b) { hipFree(b); b = nullptr; }
+    s->stage_cap.assign(s->stage_cap.size(), 0);
   }
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
@@ -184,7 +191,6 @@ struct Staged {
 class Stager {
  public:
   explicit Stager(hamk_system* s, int mem) : s_(s), host_(mem == HAMK_MEM_HOST) {}
-  ~Stager() { for (auto& b : bufs_) if (b.dev) hipFree(b.dev); }
   // returns the device pointer to use for `p` (nullptr stays nullptr)
   template <class T> int in(const T* p, size_t count, T** dev) { return add((void*)p, count * sizeof(T), true, false, (void**)dev); }
   template <class T> int out(T* p, size_t count, T** dev) { return add((void*)p, count * sizeof(T), false, true, (void**)dev); }
@@ -201,7 +207,16 @@ class Stager {
   int add(void* p, size_t bytes, bool copy_in, bool copy_out, void** dev) {
     if (!p || !host_ || bytes == 0) { *dev = p; return HAMK_OK; }
     Staged b; b.host = p; b.bytes = bytes; b.out = copy_out;
-    HIP_TRY(hipMalloc(&b.dev, bytes));
+    const size_t slot = bufs_.size();
+    if (slot >= s_->stage_buf.size()) { s_->stage_buf.push_back(nullptr); s_->stage_cap.push_back(0); }
+    if (s_->stage_cap[slot] < bytes) {
+      HIP_TRY(hipStreamSynchronize(s_->stream));          // nobody may still be using the old block
+      if (s_->stage_buf[slot]) hipFree(s_->stage_buf[slot]);
+      s_->stage_buf[slot] = nullptr; s_->stage_cap[slot] = 0;
+      HIP_TRY(hipMalloc(&s_->stage_buf[slot], bytes));
+      s_->stage_cap[slot] = bytes;
+    }
+    b.dev = s_->stage_buf[slot];
     bufs_.push_back(b);
     if (copy_in) HIP_TRY(hipMemcpyAsync(b.dev, p, bytes, hipMemcpyHostToDevice, s_->stream));
     *dev = b.dev;
@@ -295,6 +310,7 @@ void hamk_system_destroy(hamk_system* s) {
   if (!s) return;
   if (s->module) hipModuleUnload(s->module);
   if (s->d_ts) hipFree(s->d_ts);
+  for (void* b : s->stage_buf) if (b) hipFree(b);
   delete s;
 }
 

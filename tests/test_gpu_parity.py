@@ -329,3 +329,34 @@ def test_all_codegen_variants_agree(api, oracle_lib, name, monkeypatch):
             assert same.mean() > 0.9, (name, mode, loop, same.mean())
             assert relerr(st.positions[:, same], sq[:, same]) < 1e-10, (name, mode, loop)
             assert relerr(st.momenta[:, same], sp[:, same]) < 1e-10, (name, mode, loop)
+
+
+def test_evolveham_time_grid_edge_cases(api, systems):
+    """hmatrix-gsl's loop is `for each ti: while (t < ti) step` (SURVEY.md section 8c box): a repeated or
+    decreasing time does no stepping and returns the current state; a negative step does nothing."""
+    spec, s, o = systems["doublePendulum"]
+    q, qd = E.sample_config(spec, 3, 9)
+    p = o.to_phase_batch(q, qd)
+    ts = np.array([0.0, 0.1, 0.1, 0.05, 0.2])
+    rows = api.evolveHam(s, api.Phase(q, p), ts)
+    oq, op, _ = o.evolve_ham_batch(q, p, ts)
+    np.testing.assert_array_equal(rows[2].positions, rows[1].positions)
+    np.testing.assert_array_equal(rows[3].positions, rows[1].positions)
+    for r in range(1, 5):
+        assert relerr(rows[r].positions, oq[r]) < 1e-9 and relerr(rows[r].momenta, op[r]) < 1e-9
+    back = api.stepHam(-0.01, s, api.Phase(q, p))                 # t = 0 >= ti = -0.01: no steps
+    np.testing.assert_array_equal(back.positions, q)
+    np.testing.assert_array_equal(back.momenta, p)
+
+
+def test_single_trajectory_frame_loop(api, systems):
+    """BASELINE config 1 shape: one trajectory, repeated stepHam calls through the host-staged path
+    (persistent staging buffers in the handle); results equal the CPU oracle's to roundoff growth."""
+    spec, s, o = systems["doublePendulum"]
+    q, p = np.array(spec.q0), np.zeros(2)
+    oq, op = q, p
+    for _ in range(50):
+        ph = api.stepHam(1.0 / 12.0, s, api.Phase(q, p))          # Examples.hs:415,429
+        q, p = ph.positions, ph.momenta
+        oq, op = o.step_ham(1.0 / 12.0, oq, op)
+    assert relerr(q, oq) < 1e-7 and relerr(p, op) < 1e-7
