@@ -18,6 +18,6 @@ for _ in range(1000):
     oq, op = o.step_ham(0.01, oq, op)
 c = time.perf_counter() - t0
 r4 = api.rk4Steps(0.01, 1000, s, api.Phase(np.array(spec.q0), np.zeros(2)))
-print(f"C1 stepHam x1000: GPU path {g*1e3:.1f} ms ({g*1e3:.3f} ms/call), CPU oracle {c*1e3:.1f} ms; "
+print(f"C1 stepHam x1000: GPU path {g*1e3:.1f} ms ({g*1e3:.1f} us/call), CPU oracle {c*1e3:.1f} ms ({c*1e3:.1f} us/call); "
       f"max|dphase| GPU vs oracle {max(np.max(np.abs(q-oq)), np.max(np.abs(p-op))):.2e}; "
       f"RK4 x1000 vs stepHam x1000 (truncation): {max(np.max(np.abs(r4.positions-q)), np.max(np.abs(r4.momenta-p))):.2e}")
