@@ -275,9 +275,11 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   s->desc.u_ops.assign(u_ops, u_ops + u_nops);
   s->desc.u_out = u_out;
   s->desc.mode_h = (n <= 3);     // measured on MI355X (scripts/sweep.py): H >= D up to n = 3, D ahead from n = 4
-  if (const char* e = std::getenv("HAMK_AD_MODE")) {          // experiments: force "H" or "D"
-    if (e[0] == 'H' || e[0] == 'h') s->desc.mode_h = true;
-    if (e[0] == 'D' || e[0] == 'd') s->desc.mode_h = false;
+  s->desc.mode_r = !s->desc.mode_h;
+  if (const char* e = std::getenv("HAMK_AD_MODE")) {          // experiments: force "H", "D" (Jet2 sweep) or "R" (reverse sweep)
+    if (e[0] == 'H' || e[0] == 'h') { s->desc.mode_h = true; s->desc.mode_r = false; }
+    if (e[0] == 'D' || e[0] == 'd') { s->desc.mode_h = false; s->desc.mode_r = false; }
+    if (e[0] == 'R' || e[0] == 'r') { s->desc.mode_h = false; s->desc.mode_r = true; }
   }
   // measured on MI355X (scripts/sweep_wave.py): the lane kernels win up to n = 16 even with
   // spills (chain16: 4.5e8 vs 7.3e7 steps/s); beyond that one trajectory no longer fits a lane

@@ -163,6 +163,222 @@ static std::string value_name(const std::vector<hamk_op>& ops, const char* pfx, 
   return std::string(pfx) + std::to_string(id);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Reverse sweep (MODE_R).  The quantity hamEqs needs from second derivatives is a GRADIENT:
+//   dT/dq_i = -d/dq_i [ sum_k u_k (D_v x_k)(q) ],   u_k = m_k (J qd)_k held fixed, v = qd,
+// so one forward pass of (value, tangent along v) followed by one reverse pass over the tape
+// yields all n components at O(tape) cost, against the O(n * tape) of carrying n directions in
+// forward mode (Jet2<N>).  Emitted as explicit scalar code; the elementary derivative rules are
+// the d2_* helpers of hamk_device.hpp, sincos pairs come from the TrigCache of the first sweep.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct RevTape {
+  std::vector<hamk_op> ops;          // DIV expanded into RECIP + MUL
+  std::vector<int> slot;             // per op: trig cache slot (SIN/COS), else -1
+  std::vector<int> outs;             // output k -> value id
+};
+
+double host_ipow(double x, int k) {
+  unsigned int e = (k < 0) ? (unsigned int)(-(long long)k) : (unsigned int)k;
+  double r = 1.0, b = x;
+  while (e) { if (e & 1u) r *= b; b *= b; e >>= 1; }
+  return (k < 0) ? 1.0 / r : r;
+}
+
+// value of an op whose operands are all constants (folded on the host, fp64 as written)
+double fold_const(const hamk_op& p, double a, double b) {
+  switch (p.op) {
+    case HAMK_OP_ADD: return a + b;   case HAMK_OP_SUB: return a - b;   case HAMK_OP_MUL: return a * b;
+    case HAMK_OP_DIV: return a / b;   case HAMK_OP_NEG: return -a;      case HAMK_OP_RECIP: return 1.0 / a;
+    case HAMK_OP_SIN: return std::sin(a);   case HAMK_OP_COS: return std::cos(a);   case HAMK_OP_TAN: return std::tan(a);
+    case HAMK_OP_ASIN: return std::asin(a); case HAMK_OP_ACOS: return std::acos(a); case HAMK_OP_ATAN: return std::atan(a);
+    case HAMK_OP_SINH: return std::sinh(a); case HAMK_OP_COSH: return std::cosh(a); case HAMK_OP_TANH: return std::tanh(a);
+    case HAMK_OP_ASINH: return std::asinh(a); case HAMK_OP_ACOSH: return std::acosh(a); case HAMK_OP_ATANH: return std::atanh(a);
+    case HAMK_OP_EXP: return std::exp(a);   case HAMK_OP_LOG: return std::log(a);   case HAMK_OP_SQRT: return std::sqrt(a);
+    case HAMK_OP_POWC: return std::pow(a, p.c); case HAMK_OP_POWI: return host_ipow(a, p.b);
+    case HAMK_OP_POW: return std::pow(a, b);    case HAMK_OP_ATAN2: return std::atan2(a, b);
+    default: return std::nan("");
+  }
+}
+
+RevTape expand_for_reverse(const SystemDesc& d) {
+  RevTape r;
+  const int n0 = (int)d.f_ops.size();
+  std::vector<int> remap(n0, -1), slot_of_operand(n0, -1);
+  int nslots = 0;
+  for (int i = 0; i < n0; ++i) {
+    hamk_op p = d.f_ops[i];
+    int slot = -1;
+    if (p.op == HAMK_OP_SIN || p.op == HAMK_OP_COS) {          // same numbering as emit_body
+      if (slot_of_operand[p.a] < 0) slot_of_operand[p.a] = nslots++;
+      slot = slot_of_operand[p.a];
+    }
+    const bool unary_or_binary = p.op != HAMK_OP_CONST && p.op != HAMK_OP_INPUT;
+    const bool two = p.op == HAMK_OP_ADD || p.op == HAMK_OP_SUB || p.op == HAMK_OP_MUL || p.op == HAMK_OP_DIV ||
+                     p.op == HAMK_OP_POW || p.op == HAMK_OP_ATAN2;
+    if (unary_or_binary) p.a = remap[p.a];
+    if (two) p.b = remap[p.b];
+    if (unary_or_binary && r.ops[p.a].op == HAMK_OP_CONST && (!two || r.ops[p.b].op == HAMK_OP_CONST)) {
+      hamk_op c{HAMK_OP_CONST, 0, 0, 0, fold_const(p, r.ops[p.a].c, two ? r.ops[p.b].c : 0.0)};
+      r.ops.push_back(c); r.slot.push_back(-1);
+    } else if (p.op == HAMK_OP_DIV && r.ops[p.b].op == HAMK_OP_CONST) {      // x / c = x * (1/c)
+      hamk_op rc{HAMK_OP_CONST, 0, 0, 0, 1.0 / r.ops[p.b].c};
+      r.ops.push_back(rc); r.slot.push_back(-1);
+      hamk_op mu{HAMK_OP_MUL, p.a, (int32_t)r.ops.size() - 1, 0, 0.0};
+      r.ops.push_back(mu); r.slot.push_back(-1);
+    } else if (p.op == HAMK_OP_DIV) {
+      hamk_op rc{HAMK_OP_RECIP, p.b, 0, 0, 0.0};
+      r.ops.push_back(rc); r.slot.push_back(-1);
+      hamk_op mu{HAMK_OP_MUL, p.a, (int32_t)r.ops.size() - 1, 0, 0.0};
+      r.ops.push_back(mu); r.slot.push_back(-1);
+    } else {
+      r.ops.push_back(p); r.slot.push_back(slot);
+    }
+    remap[i] = (int)r.ops.size() - 1;
+  }
+  for (int k = 0; k < d.m; ++k) r.outs.push_back(remap[d.f_outs[k]]);
+  return r;
+}
+
+const char* d2_name(int op) {
+  switch (op) {
+    case HAMK_OP_RECIP: return "recip"; case HAMK_OP_TAN: return "tan"; case HAMK_OP_ASIN: return "asin";
+    case HAMK_OP_ACOS: return "acos"; case HAMK_OP_ATAN: return "atan"; case HAMK_OP_SINH: return "sinh";
+    case HAMK_OP_COSH: return "cosh"; case HAMK_OP_TANH: return "tanh"; case HAMK_OP_ASINH: return "asinh";
+    case HAMK_OP_ACOSH: return "acosh"; case HAMK_OP_ATANH: return "atanh"; case HAMK_OP_EXP: return "exp";
+    case HAMK_OP_LOG: return "log"; case HAMK_OP_SQRT: return "sqrt"; default: return nullptr;
+  }
+}
+}  // namespace
+
+static void emit_reverse(std::ostringstream& o, const SystemDesc& d) {
+  const RevTape r = expand_for_reverse(d);
+  const int n = (int)r.ops.size();
+  auto is_const = [&](int i) { return r.ops[i].op == HAMK_OP_CONST; };
+  auto is_input = [&](int i) { return r.ops[i].op == HAMK_OP_INPUT; };
+  std::vector<char> active(n, 0);                    // depends on an input
+  for (int i = 0; i < n; ++i) {
+    const hamk_op& p = r.ops[i];
+    if (p.op == HAMK_OP_INPUT) active[i] = 1;
+    else if (p.op != HAMK_OP_CONST) {
+      active[i] = active[p.a];
+      if (p.op == HAMK_OP_ADD || p.op == HAMK_OP_SUB || p.op == HAMK_OP_MUL || p.op == HAMK_OP_POW || p.op == HAMK_OP_ATAN2)
+        active[i] = active[p.a] || active[p.b];
+    }
+  }
+  auto val = [&](int i) -> std::string {             // primal value
+    if (is_const(i)) return lit(r.ops[i].c);
+    if (is_input(i)) return "q[" + std::to_string(r.ops[i].a) + "]";
+    return "r" + std::to_string(i);
+  };
+  auto tan_ = [&](int i) -> std::string {            // tangent along v
+    if (!active[i]) return "0.0";
+    if (is_input(i)) return "v[" + std::to_string(r.ops[i].a) + "]";
+    return "t" + std::to_string(i);
+  };
+  auto adj = [&](int i, char w) -> std::string {     // adjoint accumulators: a = of value, b = of tangent
+    if (is_input(i)) return std::string(1, w) + "q" + std::to_string(r.ops[i].a);
+    return std::string(1, w) + std::to_string(i);
+  };
+  o << "  // dT[i] = -d/dq_i sum_k inertia(k) * (J v)_k * (D_v x_k)(q), (J v)_k held fixed: forward (value, tangent),\n";
+  o << "  // then adjoints in reverse tape order\n";
+  o << "  template <class TC> __device__ __forceinline__ static void dT_reverse(const double (&q)[N], const double (&v)[N], TC& tc, double (&dT)[N]) {\n";
+  // ---- forward -----------------------------------------------------------------------------
+  for (int i = 0; i < n; ++i) {
+    const hamk_op& p = r.ops[i];
+    if (p.op == HAMK_OP_CONST || p.op == HAMK_OP_INPUT) continue;
+    const std::string I = std::to_string(i);
+    o << "    ";
+    if (!active[i]) {                                // constant subexpression (kept exact, no tangent)
+      switch (p.op) {
+        case HAMK_OP_ADD: o << "const double r" << I << " = " << val(p.a) << " + " << val(p.b) << ";\n"; break;
+        case HAMK_OP_SUB: o << "const double r" << I << " = " << val(p.a) << " - " << val(p.b) << ";\n"; break;
+        case HAMK_OP_MUL: o << "const double r" << I << " = " << val(p.a) << " * " << val(p.b) << ";\n"; break;
+        case HAMK_OP_NEG: o << "const double r" << I << " = -" << val(p.a) << ";\n"; break;
+        default: o << "const double r" << I << " = hamk::quiet_nan(); // constant subexpression of a function: fold on the host\n"; break;
+      }
+      continue;
+    }
+    switch (p.op) {
+      case HAMK_OP_ADD:
+        o << "const double r" << I << " = " << val(p.a) << " + " << val(p.b) << ", t" << I << " = " << tan_(p.a) << " + " << tan_(p.b) << ";\n"; break;
+      case HAMK_OP_SUB:
+        o << "const double r" << I << " = " << val(p.a) << " - " << val(p.b) << ", t" << I << " = " << tan_(p.a) << " - " << tan_(p.b) << ";\n"; break;
+      case HAMK_OP_MUL:
+        o << "const double r" << I << " = " << val(p.a) << " * " << val(p.b) << ", t" << I << " = " << val(p.a) << " * " << tan_(p.b)
+          << " + " << tan_(p.a) << " * " << val(p.b) << ";\n"; break;
+      case HAMK_OP_NEG:
+        o << "const double r" << I << " = -" << val(p.a) << ", t" << I << " = -" << tan_(p.a) << ";\n"; break;
+      case HAMK_OP_SIN:
+        o << "const double r" << I << " = tc.s[" << r.slot[i] << "], g" << I << " = tc.c[" << r.slot[i] << "], h" << I << " = -tc.s[" << r.slot[i]
+          << "], t" << I << " = g" << I << " * " << tan_(p.a) << ";\n"; break;
+      case HAMK_OP_COS:
+        o << "const double r" << I << " = tc.c[" << r.slot[i] << "], g" << I << " = -tc.s[" << r.slot[i] << "], h" << I << " = -tc.c[" << r.slot[i]
+          << "], t" << I << " = g" << I << " * " << tan_(p.a) << ";\n"; break;
+      case HAMK_OP_POWI:
+        o << "double r" << I << ", g" << I << ", h" << I << "; hamk::d2_powi<" << p.b << ">(" << val(p.a) << ", r" << I << ", g" << I << ", h" << I
+          << "); const double t" << I << " = g" << I << " * " << tan_(p.a) << ";\n"; break;
+      case HAMK_OP_POWC:
+        o << "double r" << I << ", g" << I << ", h" << I << "; hamk::d2_powc(" << val(p.a) << ", " << lit(p.c) << ", r" << I << ", g" << I << ", h" << I
+          << "); const double t" << I << " = g" << I << " * " << tan_(p.a) << ";\n"; break;
+      case HAMK_OP_POW:
+      case HAMK_OP_ATAN2:
+        o << "double r" << I << ", fa" << I << ", fb" << I << ", faa" << I << ", fab" << I << ", fbb" << I << "; hamk::d2_"
+          << (p.op == HAMK_OP_POW ? "pow" : "atan2") << "(" << val(p.a) << ", " << val(p.b) << ", r" << I << ", fa" << I << ", fb" << I << ", faa" << I
+          << ", fab" << I << ", fbb" << I << "); const double t" << I << " = fa" << I << " * " << tan_(p.a) << " + fb" << I << " * " << tan_(p.b) << ";\n";
+        break;
+      default:
+        o << "double r" << I << ", g" << I << ", h" << I << "; hamk::d2_" << d2_name(p.op) << "(" << val(p.a) << ", r" << I << ", g" << I << ", h" << I
+          << "); const double t" << I << " = g" << I << " * " << tan_(p.a) << ";\n";
+        break;
+    }
+  }
+  // ---- adjoints -----------------------------------------------------------------------------
+  o << "    double";
+  for (int j = 0; j < d.n; ++j) o << (j ? "," : "") << " aq" << j << " = 0.0, bq" << j << " = 0.0";
+  o << ";\n";
+  for (int i = 0; i < n; ++i)
+    if (active[i] && !is_input(i)) o << "    double a" << i << " = 0.0, b" << i << " = 0.0;\n";
+  for (int k = 0; k < d.m; ++k) {                    // seeds: g = sum_k u_k t_k, u_k = m_k t_k (fixed)
+    const int id = r.outs[k];
+    if (!active[id]) continue;
+    o << "    " << adj(id, 'b') << " += " << lit(d.inertia[k]) << " * " << tan_(id) << ";\n";
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    const hamk_op& p = r.ops[i];
+    if (!active[i] || is_input(i)) continue;
+    const std::string I = std::to_string(i), aI = "a" + I, bI = "b" + I;
+    auto acc = [&](int x, char w, const std::string& expr) {
+      if (active[x]) o << "    " << adj(x, w) << " += " << expr << ";\n";
+    };
+    switch (p.op) {
+      case HAMK_OP_ADD: acc(p.a, 'a', aI); acc(p.a, 'b', bI); acc(p.b, 'a', aI); acc(p.b, 'b', bI); break;
+      case HAMK_OP_SUB: acc(p.a, 'a', aI); acc(p.a, 'b', bI); acc(p.b, 'a', "-" + aI); acc(p.b, 'b', "-" + bI); break;
+      case HAMK_OP_NEG: acc(p.a, 'a', "-" + aI); acc(p.a, 'b', "-" + bI); break;
+      case HAMK_OP_MUL:
+        acc(p.a, 'a', aI + " * " + val(p.b) + (active[p.b] ? " + " + bI + " * " + tan_(p.b) : ""));
+        acc(p.a, 'b', bI + " * " + val(p.b));
+        acc(p.b, 'a', aI + " * " + val(p.a) + (active[p.a] ? " + " + bI + " * " + tan_(p.a) : ""));
+        acc(p.b, 'b', bI + " * " + val(p.a));
+        break;
+      case HAMK_OP_POW:
+      case HAMK_OP_ATAN2:
+        acc(p.a, 'a', aI + " * fa" + I + " + " + bI + " * (faa" + I + " * " + tan_(p.a) + " + fab" + I + " * " + tan_(p.b) + ")");
+        acc(p.a, 'b', bI + " * fa" + I);
+        acc(p.b, 'a', aI + " * fb" + I + " + " + bI + " * (fab" + I + " * " + tan_(p.a) + " + fbb" + I + " * " + tan_(p.b) + ")");
+        acc(p.b, 'b', bI + " * fb" + I);
+        break;
+      default:                                        // every unary function: y = g(x), ty = g'(x) tx
+        acc(p.a, 'a', aI + " * g" + I + " + " + bI + " * h" + I + " * " + tan_(p.a));
+        acc(p.a, 'b', bI + " * g" + I);
+        break;
+    }
+  }
+  for (int j = 0; j < d.n; ++j) o << "    dT[" << j << "] = -aq" << j << "; (void)bq" << j << ";\n";
+  o << "  }\n";
+}
+
 std::string generate_source(const SystemDesc& d) {
   std::ostringstream o;
   o << "// generated by libhamk (hamk_codegen.cpp) from the expression tape of one System " << d.m << " " << d.n << "\n";
@@ -174,6 +390,7 @@ std::string generate_source(const SystemDesc& d) {
   o << "  static constexpr bool MODE_H = " << (d.mode_h ? "true" : "false") << ";\n";
   o << "  static constexpr bool RK4_STAGE_LOOP = " << (d.rk4_stage_loop ? "true" : "false") << ";\n";
   o << "  static constexpr bool RKF_STAGE_LOOP = " << (d.rkf_stage_loop ? "true" : "false") << ";\n";
+  o << "  static constexpr bool MODE_R = " << (d.mode_r ? "true" : "false") << ";\n";
   o << "  __device__ __forceinline__ static constexpr double inertia(int k) {\n";
   o << "    constexpr double w[M] = {";
   for (int k = 0; k < d.m; ++k) o << (k ? ", " : "") << lit(d.inertia[k]);
@@ -221,6 +438,7 @@ std::string generate_source(const SystemDesc& d) {
   if (ntrig_f == 0) o << "-1";
   o << "};\n    return w[slot];\n  }\n";
   o << "  static constexpr bool TRIG_ALL_INPUTS = " << (all_inputs ? "true" : "false") << ";\n";
+  emit_reverse(o, d);
   o << "  static constexpr int NTRIG_F = " << ntrig_f << ";\n";
   o << "  static constexpr int NTRIG_U = " << ntrig_u << ";\n";
   o << "};\n\n";

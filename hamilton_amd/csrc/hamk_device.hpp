@@ -435,55 +435,23 @@ template <int MODE, class A, class TC> HAMK_DEV A cos(const A& x, TC& tc, int k)
   trig_pair<MODE>(val(x), tc, k);
   return chain(x, tc.c[k], -tc.s[k], -tc.c[k]);
 }
-template <class A> HAMK_DEV A tan(const A& x) {
-  const double t = ::tan(val(x)); const double d = fma(t, t, 1.0);
-  return chain(x, t, d, 2.0 * t * d);
-}
-template <class A> HAMK_DEV A asin(const A& x) {
-  const double v = val(x), w = fma(-v, v, 1.0), r = ::rsqrt(w);
-  return chain(x, ::asin(v), r, v * r / w);
-}
-template <class A> HAMK_DEV A acos(const A& x) {
-  const double v = val(x), w = fma(-v, v, 1.0), r = ::rsqrt(w);
-  return chain(x, ::acos(v), -r, -v * r / w);
-}
-template <class A> HAMK_DEV A atan(const A& x) {
-  const double v = val(x), w = 1.0 / fma(v, v, 1.0);
-  return chain(x, ::atan(v), w, -2.0 * v * w * w);
-}
-template <class A> HAMK_DEV A sinh(const A& x) {
-  const double s = ::sinh(val(x)), c = ::cosh(val(x));
-  return chain(x, s, c, s);
-}
-template <class A> HAMK_DEV A cosh(const A& x) {
-  const double s = ::sinh(val(x)), c = ::cosh(val(x));
-  return chain(x, c, s, c);
-}
-template <class A> HAMK_DEV A tanh(const A& x) {
-  const double t = ::tanh(val(x)); const double d = fma(-t, t, 1.0);
-  return chain(x, t, d, -2.0 * t * d);
-}
-template <class A> HAMK_DEV A asinh(const A& x) {
-  const double v = val(x), w = fma(v, v, 1.0), r = ::rsqrt(w);
-  return chain(x, ::asinh(v), r, -v * r / w);
-}
-template <class A> HAMK_DEV A acosh(const A& x) {
-  const double v = val(x), w = fma(v, v, -1.0), r = ::rsqrt(w);
-  return chain(x, ::acosh(v), r, -v * r / w);
-}
-template <class A> HAMK_DEV A atanh(const A& x) {
-  const double v = val(x), w = 1.0 / fma(-v, v, 1.0);
-  return chain(x, ::atanh(v), w, 2.0 * v * w * w);
-}
-template <class A> HAMK_DEV A exp(const A& x) { const double e = ::exp(val(x)); return chain(x, e, e, e); }
-template <class A> HAMK_DEV A log(const A& x) {
-  const double r = 1.0 / val(x);
-  return chain(x, ::log(val(x)), r, -r * r);
-}
-template <class A> HAMK_DEV A sqrt(const A& x) {
-  const double r = ::sqrt(val(x)); const double g1 = 0.5 / r;
-  return chain(x, r, g1, -0.5 * g1 / val(x));
-}
+// value, first and second derivative of every elementary function at a plain double: the one
+// place the derivative rules live.  The jet overloads below and the generated reverse sweep
+// (hamk_codegen.cpp, MODE_R) both use them.
+HAMK_DEV void d2_recip(double x, double& g0, double& g1, double& g2) { const double r = frcp(x), r2 = r * r; g0 = r; g1 = -r2; g2 = 2.0 * r2 * r; }
+HAMK_DEV void d2_tan(double x, double& g0, double& g1, double& g2) { const double t = ::tan(x), d = fma(t, t, 1.0); g0 = t; g1 = d; g2 = 2.0 * t * d; }
+HAMK_DEV void d2_asin(double x, double& g0, double& g1, double& g2) { const double w = fma(-x, x, 1.0), r = ::rsqrt(w); g0 = ::asin(x); g1 = r; g2 = x * r / w; }
+HAMK_DEV void d2_acos(double x, double& g0, double& g1, double& g2) { const double w = fma(-x, x, 1.0), r = ::rsqrt(w); g0 = ::acos(x); g1 = -r; g2 = -x * r / w; }
+HAMK_DEV void d2_atan(double x, double& g0, double& g1, double& g2) { const double w = 1.0 / fma(x, x, 1.0); g0 = ::atan(x); g1 = w; g2 = -2.0 * x * w * w; }
+HAMK_DEV void d2_sinh(double x, double& g0, double& g1, double& g2) { const double s = ::sinh(x), c = ::cosh(x); g0 = s; g1 = c; g2 = s; }
+HAMK_DEV void d2_cosh(double x, double& g0, double& g1, double& g2) { const double s = ::sinh(x), c = ::cosh(x); g0 = c; g1 = s; g2 = c; }
+HAMK_DEV void d2_tanh(double x, double& g0, double& g1, double& g2) { const double t = ::tanh(x), d = fma(-t, t, 1.0); g0 = t; g1 = d; g2 = -2.0 * t * d; }
+HAMK_DEV void d2_asinh(double x, double& g0, double& g1, double& g2) { const double w = fma(x, x, 1.0), r = ::rsqrt(w); g0 = ::asinh(x); g1 = r; g2 = -x * r / w; }
+HAMK_DEV void d2_acosh(double x, double& g0, double& g1, double& g2) { const double w = fma(x, x, -1.0), r = ::rsqrt(w); g0 = ::acosh(x); g1 = r; g2 = -x * r / w; }
+HAMK_DEV void d2_atanh(double x, double& g0, double& g1, double& g2) { const double w = 1.0 / fma(-x, x, 1.0); g0 = ::atanh(x); g1 = w; g2 = 2.0 * x * w * w; }
+HAMK_DEV void d2_exp(double x, double& g0, double& g1, double& g2) { const double e = ::exp(x); g0 = e; g1 = e; g2 = e; }
+HAMK_DEV void d2_log(double x, double& g0, double& g1, double& g2) { const double r = 1.0 / x; g0 = ::log(x); g1 = r; g2 = -r * r; }
+HAMK_DEV void d2_sqrt(double x, double& g0, double& g1, double& g2) { const double r = ::sqrt(x); g0 = r; g1 = 0.5 / r; g2 = -0.5 * g1 / x; }
 
 // k is a literal after inlining: folds to a multiply chain.  No recursion -- a recursive helper
 // is not inlined and becomes a real device function call (call frame in scratch).
@@ -494,20 +462,41 @@ HAMK_DEV double ipow(double x, int k) {
   return (k < 0) ? frcp(r) : r;
 }
 // x ^ K, integral K: valid for negative x (Examples.hs:154 `x ** 2` with x < 0)
-template <int K, class A> HAMK_DEV A powi(const A& x) {
-  const double v = val(x);
-  return chain(x, ipow(v, K), K * ipow(v, K - 1), (double)K * (K - 1) * ipow(v, K - 2));
+template <int K> HAMK_DEV void d2_powi(double x, double& g0, double& g1, double& g2) {
+  g0 = ipow(x, K); g1 = K * ipow(x, K - 1); g2 = (double)K * (K - 1) * ipow(x, K - 2);
 }
 // x ** c, constant real c
+HAMK_DEV void d2_powc(double x, double c, double& g0, double& g1, double& g2) {
+  g0 = ::pow(x, c); g1 = c * ::pow(x, c - 1.0); g2 = c * (c - 1.0) * ::pow(x, c - 2.0);
+}
+// two-argument functions: value and all first/second partials
+HAMK_DEV void d2_pow(double a, double b, double& f0, double& fa, double& fb, double& faa, double& fab, double& fbb) {
+  const double z = ::pow(a, b), la = ::log(a), ia = 1.0 / a;     // a ** b, a > 0
+  f0 = z; fa = b * z * ia; fb = z * la; faa = b * (b - 1.0) * z * ia * ia; fab = z * ia * fma(b, la, 1.0); fbb = z * la * la;
+}
+HAMK_DEV void d2_atan2(double y, double x, double& f0, double& fa, double& fb, double& faa, double& fab, double& fbb) {
+  const double i2 = 1.0 / fma(y, y, x * x);
+  f0 = ::atan2(y, x); fa = x * i2; fb = -y * i2; faa = -2.0 * y * x * i2 * i2; fab = (y * y - x * x) * i2 * i2; fbb = -faa;
+}
+
+#define HAMK_UNARY(name)                                                                    \
+  template <class A> HAMK_DEV A name(const A& x) {                                          \
+    double g0, g1, g2; d2_##name(val(x), g0, g1, g2); return chain(x, g0, g1, g2);          \
+  }
+HAMK_UNARY(tan) HAMK_UNARY(asin) HAMK_UNARY(acos) HAMK_UNARY(atan) HAMK_UNARY(sinh) HAMK_UNARY(cosh)
+HAMK_UNARY(tanh) HAMK_UNARY(asinh) HAMK_UNARY(acosh) HAMK_UNARY(atanh) HAMK_UNARY(exp) HAMK_UNARY(log) HAMK_UNARY(sqrt)
+#undef HAMK_UNARY
+
+template <int K, class A> HAMK_DEV A powi(const A& x) {
+  double g0, g1, g2; d2_powi<K>(val(x), g0, g1, g2); return chain(x, g0, g1, g2);
+}
 template <class A> HAMK_DEV A powc(const A& x, double c) {
-  const double v = val(x);
-  return chain(x, ::pow(v, c), c * ::pow(v, c - 1.0), c * (c - 1.0) * ::pow(v, c - 2.0));
+  double g0, g1, g2; d2_powc(val(x), c, g0, g1, g2); return chain(x, g0, g1, g2);
 }
 // x ** y, both variable (x > 0)
 template <class A> HAMK_DEV A pow(const A& a, const A& b) {
-  const double av = val(a), bv = val(b);
-  const double z = ::pow(av, bv), la = ::log(av), ia = 1.0 / av;
-  return chain2(a, b, z, bv * z * ia, z * la, bv * (bv - 1.0) * z * ia * ia, z * ia * fma(bv, la, 1.0), z * la * la);
+  double f0, fa, fb, faa, fab, fbb; d2_pow(val(a), val(b), f0, fa, fb, faa, fab, fbb);
+  return chain2(a, b, f0, fa, fb, faa, fab, fbb);
 }
 template <class A> HAMK_DEV A pow(const A& a, double c) { return powc(a, c); }
 template <class A> HAMK_DEV A pow(double c, const A& b) {      // c ** y = exp(y log c)
@@ -516,10 +505,8 @@ template <class A> HAMK_DEV A pow(double c, const A& b) {      // c ** y = exp(y
 }
 HAMK_DEV double pow(double a, double b) { return ::pow(a, b); }
 template <class A> HAMK_DEV A atan2(const A& y, const A& x) {
-  const double yv = val(y), xv = val(x);
-  const double i2 = 1.0 / fma(yv, yv, xv * xv);
-  const double faa = -2.0 * yv * xv * i2 * i2;
-  return chain2(y, x, ::atan2(yv, xv), xv * i2, -yv * i2, faa, (yv * yv - xv * xv) * i2 * i2, -faa);
+  double f0, fa, fb, faa, fab, fbb; d2_atan2(val(y), val(x), f0, fa, fb, faa, fab, fbb);
+  return chain2(y, x, f0, fa, fb, faa, fab, fbb);
 }
 template <class A> HAMK_DEV A atan2(const A& y, double x) { return atan2(y, lift<A>(x)); }
 template <class A> HAMK_DEV A atan2(double y, const A& x) { return atan2(lift<A>(y), x); }
@@ -781,21 +768,27 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
     mass_matrix<S>(xj, K);
     solve_spd<N>(K, p, v, st);
     grad_potential<S>(qj, xj, gU, U);
-    Jet2<N> q2[N], x2[M];
+    if constexpr (S::MODE_R) {
+      // MODE_R: the contraction is a gradient -- one forward (value, tangent along qd) pass and one
+      // reverse pass over the tape (generated, S::dT_reverse), O(tape) instead of O(n * tape)
+      S::dT_reverse(q, v, tc, dT);
+    } else {
+      Jet2<N> q2[N], x2[M];
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      q2[j] = lift<Jet2<N>>(q[j]);
-      q2[j].d[j] = 1.0;
-      q2[j].dv = v[j];
-    }
-    S::template coords<Jet2<N>, TRIG_REUSE>(q2, x2, tc);  // primal sincos pairs from the first sweep
+      for (int j = 0; j < N; ++j) {
+        q2[j] = lift<Jet2<N>>(q[j]);
+        q2[j].d[j] = 1.0;
+        q2[j].dv = v[j];
+      }
+      S::template coords<Jet2<N>, TRIG_REUSE>(q2, x2, tc);  // primal sincos pairs from the first sweep
 #pragma unroll
-    for (int i = 0; i < N; ++i) dT[i] = 0.0;
+      for (int i = 0; i < N; ++i) dT[i] = 0.0;
 #pragma unroll
-    for (int k = 0; k < M; ++k) {
-      const double uk = S::inertia(k) * x2[k].dv;           // (M J qd)_k
+      for (int k = 0; k < M; ++k) {
+        const double uk = S::inertia(k) * x2[k].dv;           // (M J qd)_k
 #pragma unroll
-      for (int i = 0; i < N; ++i) dT[i] = fma(-uk, x2[k].dd[i], dT[i]);
+        for (int i = 0; i < N; ++i) dT[i] = fma(-uk, x2[k].dd[i], dT[i]);
+      }
     }
   }
 #pragma unroll

@@ -11,6 +11,7 @@ namespace hamk_host {
 struct SystemDesc {
   int m = 0, n = 0, u_space = 0;
   bool mode_h = true;
+  bool mode_r = false;          // second sweep in reverse mode (generated adjoint code) instead of Jet2<N>
   bool rk4_stage_loop = false;
   bool rkf_stage_loop = false;
   bool wave = false;            // wave-cooperative kernels (hamk_wave.hpp) instead of one trajectory per lane

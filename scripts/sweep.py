@@ -6,7 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hamilton_amd import api, examples as E
 
 def run(name, B, nsteps, mode, loop, reps=3):
-    os.environ["HAMK_AD_MODE"] = mode; os.environ["HAMK_RK4_LOOP"] = loop
+    os.environ["HAMK_AD_MODE"] = mode
+    if loop: os.environ["HAMK_RK4_LOOP"] = loop
+    else: os.environ.pop("HAMK_RK4_LOOP", None)
     spec = E.get(name)
     t0 = time.time(); s = api.system_from_spec(spec); tc = time.time() - t0
     q, qd = E.sample_config(spec, 0, B)
@@ -25,13 +27,14 @@ def run(name, B, nsteps, mode, loop, reps=3):
 if __name__ == "__main__":
     cfgs = [("doublePendulum", 1 << 20, 100), ("twoBody", 1 << 20, 100), ("spring", 1 << 20, 100),
             ("pendulum", 1 << 20, 100), ("room", 1 << 20, 100), ("bezier", 1 << 20, 100),
-            ("threeBodyPolar", 1 << 18, 50), ("chain4", 1 << 16, 50), ("chain8", 1 << 16, 20)]
+            ("threeBodyPolar", 1 << 18, 50), ("chain4", 1 << 16, 50), ("chain8", 1 << 16, 20), ("chain12", 1 << 16, 20),
+            ("chain16", 1 << 16, 10), ("opcodeZoo", 1 << 18, 20)]
     only = sys.argv[1:]
     for name, B, ns in cfgs:
         if only and name not in only: continue
-        for mode in ("H", "D"):
+        for mode in ("H", "D", "R"):
             if mode == "H" and E.get(name).n > 6: continue
-            for loop in ("0", "1"):
+            for loop in (("0", "1") if os.environ.get("SWEEP_LOOPS") else ("",)):
                 try:
                     print(json.dumps(run(name, B, ns, mode, loop)), flush=True)
                 except Exception as ex:

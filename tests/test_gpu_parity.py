@@ -303,9 +303,10 @@ def test_full_size_properties(api, systems):
 # ---------------------------------------------------------------- every code-generation variant
 @pytest.mark.parametrize("name", ["opcodeZoo", "doublePendulum", "spring", "threeBodyPolar"])
 def test_all_codegen_variants_agree(api, oracle_lib, name, monkeypatch):
-    """MODE_H (full second-order jets) and MODE_D (two sweeps, directional jets, trig cache), each
-    with the unrolled and the stage-loop RK4 body, against the oracle: every derivative rule of
-    every jet type is exercised by opcodeZoo (all 27 tape opcodes)."""
+    """MODE_H (full second-order jets), MODE_D (two sweeps, directional jets, trig cache) and MODE_R
+    (second sweep in reverse mode: generated adjoint code), each with the unrolled and the
+    stage-loop RK4 body, against the oracle: every derivative rule of every jet type and of the
+    reverse sweep is exercised by opcodeZoo (all 27 tape opcodes)."""
     spec = E.get(name)
     o = oracle_lib.OracleSystem(spec)
     B = 257
@@ -314,12 +315,13 @@ def test_all_codegen_variants_agree(api, oracle_lib, name, monkeypatch):
     odq, odp, _ = o.hameqs_batch(q, p)
     oq, op = o.rk4_steps_batch(q, p, spec.dt, 3)
     sq, sp, sns = o.step_ham_batch(q, p, 0.01)
-    for mode in ("H", "D"):
+    for mode in ("H", "D", "R"):
         for loop in ("0", "1"):
             monkeypatch.setenv("HAMK_AD_MODE", mode)
             monkeypatch.setenv("HAMK_RK4_LOOP", loop)
             s = api.system_from_spec(spec)
             assert f"MODE_H = {'true' if mode == 'H' else 'false'}" in s.source
+            assert f"MODE_R = {'true' if mode == 'R' else 'false'}" in s.source
             dq, dp = api.hamEqs(s, api.Phase(q, p))
             assert relerr(dq, odq) < 1e-11 and relerr(dp, odp) < 1e-11, (name, mode, loop, relerr(dp, odp))
             ph = api.rk4Steps(spec.dt, 3, s, api.Phase(q, p))
