@@ -289,6 +289,7 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   if (const char* e = std::getenv("HAMK_WAVE")) s->desc.wave = (e[0] == '1');      // experiments / tests
   s->desc.rk4_stage_loop = (n >= 7);
   if (const char* e = std::getenv("HAMK_RK4_LOOP")) s->desc.rk4_stage_loop = (e[0] == '1');
+  if (const char* e = std::getenv("HAMK_RK4_WAVES")) s->desc.rk4_min_waves = std::atoi(e);
   s->desc.rkf_stage_loop = (n >= 4);
   if (const char* e = std::getenv("HAMK_RKF_LOOP")) s->desc.rkf_stage_loop = (e[0] == '1');
   const bool forced_rk4 = std::getenv("HAMK_RK4_LOOP") != nullptr, forced_rkf = std::getenv("HAMK_RKF_LOOP") != nullptr;

@@ -382,6 +382,7 @@ static void emit_reverse(std::ostringstream& o, const SystemDesc& d) {
 std::string generate_source(const SystemDesc& d) {
   std::ostringstream o;
   o << "// generated by libhamk (hamk_codegen.cpp) from the expression tape of one System " << d.m << " " << d.n << "\n";
+  if (d.rk4_min_waves > 1) o << "#define HAMK_RK4_MIN_WAVES " << d.rk4_min_waves << "\n";
   o << (d.wave ? "#include \"hamk_wave.hpp\"\n\n" : "#include \"hamk_device.hpp\"\n\n");
   o << "struct HamkSys {\n";
   o << "  static constexpr int N = " << d.n << ";\n";

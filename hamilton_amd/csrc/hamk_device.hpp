@@ -1209,8 +1209,11 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
 
 // Instantiates the extern "C" kernels of one system; the generated translation
 // unit ends with HAMK_INSTANTIATE(HamkSys).
+#ifndef HAMK_RK4_MIN_WAVES
+#define HAMK_RK4_MIN_WAVES 1
+#endif
 #define HAMK_INSTANTIATE(S)                                                                                      \
-  extern "C" __global__ void __launch_bounds__(256) hamk_rk4_steps_k(double* q, double* p, long long B,          \
+  extern "C" __global__ void __launch_bounds__(256, HAMK_RK4_MIN_WAVES) hamk_rk4_steps_k(double* q, double* p, long long B, \
                                                                       double dt, int nsteps, int* status) {      \
     hamk::rk4_body<S>(q, p, B, dt, nsteps, status);                                                              \
   }                                                                                                              \
