@@ -392,6 +392,9 @@ std::string generate_source(const SystemDesc& d) {
   o << "  static constexpr bool RK4_STAGE_LOOP = " << (d.rk4_stage_loop ? "true" : "false") << ";\n";
   o << "  static constexpr bool RKF_STAGE_LOOP = " << (d.rkf_stage_loop ? "true" : "false") << ";\n";
   o << "  static constexpr bool MODE_R = " << (d.mode_r ? "true" : "false") << ";\n";
+  bool inertia_pos = true;
+  for (double w : d.inertia) inertia_pos = inertia_pos && (w > 0.0);
+  o << "  static constexpr bool INERTIA_POS = " << (inertia_pos ? "true" : "false") << ";\n";
   o << "  __device__ __forceinline__ static constexpr double inertia(int k) {\n";
   o << "    constexpr double w[M] = {";
   for (int k = 0; k < d.m; ++k) o << (k ? ", " : "") << lit(d.inertia[k]);

@@ -566,10 +566,15 @@ template <int N> HAMK_DEV void solve_lu(const double (&K)[N][N], const double (&
   }
 }
 
-template <int N> HAMK_DEV void solve_spd(const double (&K)[N][N], const double (&p)[N], double (&v)[N], int& st) {
+// POS: every inertia is positive, so K = J^T M J is positive semi-definite by construction and a
+// non-positive pivot can only mean "singular" -- which pivoting cannot repair either: the lane is
+// flagged by a select and the pivoting fallback (a divergent branch per evaluation) is not emitted.
+template <int N, bool POS = false>
+HAMK_DEV void solve_spd(const double (&K)[N][N], const double (&p)[N], double (&v)[N], int& st) {
   if constexpr (N == 1) {
     v[0] = p[0] * frcp(K[0][0]);
-    if (!(K[0][0] > 0.0)) solve_lu<N>(K, p, v, st);
+    if constexpr (POS) st |= (K[0][0] > 0.0) ? 0 : ST_SINGULAR;
+    else if (!(K[0][0] > 0.0)) solve_lu<N>(K, p, v, st);
     return;
   } else if constexpr (N == 2) {
     // adjugate form: one reciprocal instead of LDL^T's two (positive definite <=> K00 > 0, det > 0)
@@ -577,7 +582,8 @@ template <int N> HAMK_DEV void solve_spd(const double (&K)[N][N], const double (
     const double id = frcp(det);
     v[0] = fma(K[1][1], p[0], -(K[0][1] * p[1])) * id;
     v[1] = fma(K[0][0], p[1], -(K[0][1] * p[0])) * id;
-    if (!(K[0][0] > 0.0 && det > 0.0)) solve_lu<N>(K, p, v, st);
+    if constexpr (POS) st |= (K[0][0] > 0.0 && det > 0.0) ? 0 : ST_SINGULAR;
+    else if (!(K[0][0] > 0.0 && det > 0.0)) solve_lu<N>(K, p, v, st);
     return;
   }
   double a[N][N];   // lower triangle: L (unit diagonal implied); diagonal: 1/d_j
@@ -618,7 +624,8 @@ template <int N> HAMK_DEV void solve_spd(const double (&K)[N][N], const double (
     for (int k = i + 1; k < N; ++k) s = fma(-a[k][i], v[k], s);
     v[i] = s;
   }
-  if (!ok) solve_lu<N>(K, p, v, st);   // rare, lane-divergent
+  if constexpr (POS) st |= ok ? 0 : ST_SINGULAR;
+  else if (!ok) solve_lu<N>(K, p, v, st);   // rare, lane-divergent
 }
 
 // ===========================================================================
@@ -694,7 +701,7 @@ template <class S> HAMK_DEV void velocities(const double (&q)[S::N], const doubl
   S::template coords<Jet1<N>, TRIG_FULL>(qj, xj, tc);
   double K[N][N];
   mass_matrix<S>(xj, K);
-  solve_spd<N>(K, p, qd, st);
+  solve_spd<N, S::INERTIA_POS>(K, p, qd, st);
 }
 
 template <class S> HAMK_DEV double potential_value(const double (&q)[S::N]) {
@@ -743,7 +750,7 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
       for (int i = 0; i < N; ++i) xj[k].d[i] = xh[k].d[i];
     }
     mass_matrix<S>(xj, K);
-    solve_spd<N>(K, p, v, st);
+    solve_spd<N, S::INERTIA_POS>(K, p, v, st);
     grad_potential<S>(qj, xj, gU, U);
 #pragma unroll
     for (int i = 0; i < N; ++i) dT[i] = 0.0;
@@ -766,7 +773,7 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
     seed1<S>(q, qj);
     S::template coords<Jet1<N>, TRIG>(qj, xj, tc);
     mass_matrix<S>(xj, K);
-    solve_spd<N>(K, p, v, st);
+    solve_spd<N, S::INERTIA_POS>(K, p, v, st);
     grad_potential<S>(qj, xj, gU, U);
     if constexpr (S::MODE_R) {
       // MODE_R: the contraction is a gradient -- one forward (value, tangent along qd) pass and one

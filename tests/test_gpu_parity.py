@@ -362,3 +362,19 @@ def test_single_trajectory_frame_loop(api, systems):
         q, p = ph.positions, ph.momenta
         oq, op = o.step_ham(1.0 / 12.0, oq, op)
     assert relerr(q, oq) < 1e-7 and relerr(p, op) < 1e-7
+
+
+def test_rank_deficient_jacobian_is_flagged(api):
+    """Positive inertias but dependent coordinates: K = J^T M J is singular (det = 0).  With all
+    inertias positive the pivoting fallback is compiled out and the lane is flagged by a select."""
+    s = api.mkSystem([1.0, 2.0], lambda q: [q[0] + q[1], q[0] + q[1]], lambda q: q[0] * q[0], n=2)
+    assert "INERTIA_POS = true" in s.source
+    q = np.array([[0.1, 0.2], [0.3, 0.4]]); p = np.ones((2, 2))
+    api.hamEqs(s, api.Phase(q, p))
+    assert np.all(np.asarray(s.last_status) & 1)
+    with pytest.raises(api.SingularSystem):
+        api.velocities(s, api.Phase(np.array([0.1, 0.3]), np.array([1.0, 1.0])))
+    # three coordinates, the generic LDL^T path
+    s3 = api.mkSystem([1.0, 1.0, 1.0], lambda q: [q[0] + q[1], q[1] + q[2], q[0] + 2 * q[1] + q[2]], lambda q: q[0], n=3)
+    api.hamEqs(s3, api.Phase(np.ones((3, 4)), np.ones((3, 4))))
+    assert np.all(np.asarray(s3.last_status) & 3)
