@@ -808,7 +808,11 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
 // TRIG_INCR pays only where sincos is a large share of the right-hand side and the anchors fit
 // in registers; elsewhere the stage evaluations stay TRIG_FULL.
 template <class S> struct StageTrig {
+#ifdef HAMK_NO_INCR
+  static constexpr bool on = false;
+#else
   static constexpr bool on = (S::NTRIG_F >= 1 && S::NTRIG_F <= 4);
+#endif
   static constexpr int anchor = on ? TRIG_ANCHOR : TRIG_FULL;
   static constexpr int incr = on ? TRIG_INCR : TRIG_FULL;
 };
@@ -1216,11 +1220,16 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
 
 // Instantiates the extern "C" kernels of one system; the generated translation
 // unit ends with HAMK_INSTANTIATE(HamkSys).
-#ifndef HAMK_RK4_MIN_WAVES
-#define HAMK_RK4_MIN_WAVES 1
+// NOTE: do not spell the default as __launch_bounds__(256, 1): with an explicit "1 wave per SIMD"
+// hint hipcc/ROCm 7.2 produced a WRONG unrolled RK4 kernel for the 27-opcode test system (error
+// 1e-4 after one step, every lane, status clean; correct with no hint and with hints >= 2).
+#ifdef HAMK_RK4_MIN_WAVES
+#define HAMK_RK4_BOUNDS __launch_bounds__(256, HAMK_RK4_MIN_WAVES)
+#else
+#define HAMK_RK4_BOUNDS __launch_bounds__(256)
 #endif
 #define HAMK_INSTANTIATE(S)                                                                                      \
-  extern "C" __global__ void __launch_bounds__(256, HAMK_RK4_MIN_WAVES) hamk_rk4_steps_k(double* q, double* p, long long B, \
+  extern "C" __global__ void HAMK_RK4_BOUNDS hamk_rk4_steps_k(double* q, double* p, long long B,                 \
                                                                       double dt, int nsteps, int* status) {      \
     hamk::rk4_body<S>(q, p, B, dt, nsteps, status);                                                              \
   }                                                                                                              \
