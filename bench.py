@@ -45,8 +45,8 @@ FP64_PEAK_TFLOPS = 78.6        # vector fp64 = 1/2 of the 157.3 TF fp32 vector p
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--system", default="doublePendulum")
     ap.add_argument("--batch", type=int, default=1 << 20, help="trajectories per GPU")
     ap.add_argument("--rk4-per-step", type=int, default=100, help="RK4 steps fused into one launch")
