@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--system", default="doublePendulum")
     ap.add_argument("--batch", type=int, default=1 << 20, help="trajectories per GPU")
     ap.add_argument("--rk4-per-step", type=int, default=100, help="RK4 steps fused into one launch")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the driver's contract): every rank owns --batch trajectories; "
+                         "strong: --batch is the whole ensemble, sharded contiguously over the ranks")
     ap.add_argument("--dt", type=float, default=None)
     ap.add_argument("--integrator", choices=["rk4", "stepham"], default="rk4",
                     help="rk4: the BASELINE metric (hamk_rk4_steps).  stepham: the reference's own stepper "
@@ -136,10 +139,15 @@ def main():
     spec = examples.get(a.system)
     dt = a.dt if a.dt is not None else spec.dt
     s = api.system_from_spec(spec)                       # tape -> hiprtc gfx950 module (outside timed region)
-    B, n = a.batch, spec.n
-
-    # this rank's shard of the global ensemble: indices [rank*B, (rank+1)*B), per-index RNG
-    lo, hi = ensemble.weak_bounds(B, rank)
+    n = spec.n
+    # this rank's shard of the global ensemble (contiguous global indices, per-index RNG)
+    if a.scaling == "strong":
+        if a.batch % world:
+            raise SystemExit("--scaling strong needs --batch divisible by the number of ranks (equal shards for the gather)")
+        lo, hi = ensemble.shard_bounds(a.batch, world, rank)
+    else:
+        lo, hi = ensemble.weak_bounds(a.batch, rank)
+    B = hi - lo
     q_h, qd_h = examples.sample_config(spec, lo, hi - lo)
     q = torch.from_numpy(q_h).to(dev)
     qd = torch.from_numpy(qd_h).to(dev)
@@ -193,7 +201,8 @@ def main():
         drift = float(t[0])
 
     if rank == 0:
-        units = world * B * a.rk4_per_step * a.steps     # trajectory-steps in the timed region
+        total = a.batch if a.scaling == "strong" else world * a.batch
+        units = total * a.rk4_per_step * a.steps         # trajectory-steps in the timed region
         value = units / elapsed
         per_gpu_rate = B * a.rk4_per_step / kernel_s
         alg_bytes = 32.0 * n                             # read + write one Phase n per step
@@ -208,7 +217,7 @@ def main():
         out = {
             "metric": "RK4 phase-space steps/sec (ensemble)", "value": value, "unit": "trajectory-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (per-index splitmix64 initial conditions, seed 20241008)",
             "config": {"workload": f"{a.system} (System {spec.m} {spec.n}) ensemble, BASELINE.json configs[1]",
                        "trajectories_per_gpu": B, "rk4_steps_per_launch": a.rk4_per_step, "dt": dt,

@@ -12,9 +12,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <mutex>
 #include <string>
 #include <vector>
+
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "hamk_internal.h"
 
@@ -69,6 +73,45 @@ struct hamk_system {
 // ---------------------------------------------------------------------------
 // specialisation
 // ---------------------------------------------------------------------------
+// On-disk cache of compiled code objects, keyed by everything that determines them (generated
+// source, both device headers, the option list, the hiprtc version): the same System built twice
+// -- another process, another rank of the same job -- costs one compile.  HAMK_CACHE_DIR overrides
+// the location ($XDG_CACHE_HOME/hamk, else /tmp/hamk-cache-<uid>); HAMK_CACHE=0 disables it.
+static uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
+  const unsigned char* p = (const unsigned char*)data;
+  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+static std::string cache_dir() {
+  if (const char* e = std::getenv("HAMK_CACHE")) if (e[0] == '0') return std::string();
+  std::string d;
+  if (const char* e = std::getenv("HAMK_CACHE_DIR")) d = e;
+  else if (const char* x = std::getenv("XDG_CACHE_HOME")) d = std::string(x) + "/hamk";
+  else d = "/tmp/hamk-cache-" + std::to_string((long)getuid());
+  ::mkdir(d.c_str(), 0700);
+  struct stat st;
+  if (::stat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return std::string();
+  return d;
+}
+
+static std::string cache_path(const hamk_system* s, const std::vector<const char*>& opts) {
+  const std::string dir = cache_dir();
+  if (dir.empty()) return dir;
+  uint64_t h = 1469598103934665603ull;
+  h = fnv1a(s->source.data(), s->source.size(), h);
+  h = fnv1a(kDeviceHeader, sizeof kDeviceHeader, h);
+  h = fnv1a(kWaveHeader, sizeof kWaveHeader, h);
+  for (const char* o : opts) h = fnv1a(o, std::strlen(o) + 1, h);
+  int major = 0, minor = 0;
+  hiprtcVersion(&major, &minor);
+  h = fnv1a(&major, sizeof major, h);
+  h = fnv1a(&minor, sizeof minor, h);
+  char name[64];
+  std::snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
+  return dir + name;
+}
+
 static int compile_module(hamk_system* s) {
   hiprtcProgram prog = nullptr;
   const char* hdr_src[] = {kDeviceHeader, kWaveHeader};
@@ -96,6 +139,19 @@ static int compile_module(hamk_system* s) {
     }
     for (auto& t : extra_tok) opts.push_back(t.c_str());
   }
+  const std::string cpath = cache_path(s, opts);
+  if (!cpath.empty()) {
+    std::ifstream in(cpath, std::ios::binary);
+    if (in) {
+      std::vector<char> blob((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+      if (blob.size() > 64 && std::memcmp(blob.data(), "\177ELF", 4) == 0) {
+        s->code.swap(blob);
+        s->build_log = "cache hit: " + cpath;
+        hiprtcDestroyProgram(&prog);
+        return HAMK_OK;
+      }
+    }
+  }
   r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   size_t logsz = 0;
   hiprtcGetProgramLogSize(prog, &logsz);
@@ -113,6 +169,15 @@ static int compile_module(hamk_system* s) {
   s->code.resize(sz);
   hiprtcGetCode(prog, s->code.data());
   hiprtcDestroyProgram(&prog);
+  if (!cpath.empty()) {                                  // publish atomically: write aside, rename
+    const std::string tmp = cpath + ".tmp." + std::to_string((long)getpid());
+    std::ofstream out(tmp, std::ios::binary);
+    if (out) {
+      out.write(s->code.data(), (std::streamsize)s->code.size());
+      out.close();
+      if (!out || std::rename(tmp.c_str(), cpath.c_str()) != 0) std::remove(tmp.c_str());
+    }
+  }
   return HAMK_OK;
 }
 
