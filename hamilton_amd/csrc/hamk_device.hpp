@@ -13,14 +13,19 @@
 //     device-side counterpart of the reference's rank-2 polymorphic arguments
 //     (`forall a. RealFloat a => ...`, Hamilton.hs:212,215): the same function
 //     instantiated at double, Jet1, JetH, Jet2;
-//   * K = J^T M J, solved (never inverted) by an unrolled in-register LDL^T with
-//     an LU-partial-pivoting fallback lane path (reference: hmatrix `inv`,
-//     LAPACK dgesv; Hamilton.hs:321,381);
+//   * K = J^T M J, solved (never inverted) in registers: 1x1, adjugate 2x2,
+//     unrolled LDL^T; an LU-partial-pivoting fallback lane path exists only for
+//     systems with a non-positive inertia (reference: hmatrix `inv`, LAPACK
+//     dgesv; Hamilton.hs:321,381);
 //   * dT/dq_i = -(M J qd) . ((dJ/dq_i) qd): the contraction the reference writes
 //     as p.K^-1 J^T M (dJ/dq_i) K^-1 p (Hamilton.hs:382-385) without forming
 //     K^-1 or the m x n x n Hessian tensor;
 //   * classic RK4 (BASELINE.json north_star) and GSL-semantics adaptive RKF45
-//     (stepHam/evolveHam, Hamilton.hs:390-462) stepping loops around it.
+//     (stepHam/evolveHam, Hamilton.hs:390-462) stepping loops around it;
+//   * an fp64 sincos written for this path (sincos_f64) and its anchored
+//     incremental form for Runge-Kutta stage points (sincos_incr).
+// Systems with more than 16 coordinates use the wave-cooperative kernels of
+// hamk_wave.hpp instead (same generated f/U code, one AD direction per lane).
 //
 // Memory: ensemble state is SoA fp64, q[j*B + i]; a wave reads 64 consecutive
 // doubles (512 B) per component -- fully coalesced.  Algorithmic HBM traffic is
@@ -836,11 +841,6 @@ HAMK_DEV bool is_nonfinite_bits(double x) {
   unsigned int hi = (unsigned int)__double2hiint(x);
   asm volatile("" : "+v"(hi));
   return (hi & 0x7ff00000u) == 0x7ff00000u;
-}
-
-template <int D> HAMK_DEV void load_soa(const double* __restrict__ a, i64 B, i64 i, double (&y)[D], int off) {
-#pragma unroll
-  for (int j = 0; j < D; ++j) y[off + j] = a[(i64)j * B + i];
 }
 
 // ===========================================================================
