@@ -103,3 +103,32 @@ def test_random_system_vs_oracle(api, oracle_lib, seed):
     assert same.mean() > 0.9
     e3 = np.maximum(np.abs(st.positions - sq).max(0), np.abs(st.momenta - sp).max(0)) / np.maximum(1.0, np.abs(sp).max(0))
     assert np.all(e3[same] <= 100 * tol[same]), (seed, float(np.max(e3[same] / tol[same])))
+
+
+@pytest.mark.parametrize("variant", ["R", "wave"])
+@pytest.mark.parametrize("seed", [0, 1, 4, 7, 12, 15])
+def test_random_system_other_code_paths(api, oracle_lib, monkeypatch, seed, variant):
+    """The same random systems through the reverse-sweep variant (MODE_R) and through the
+    wave-cooperative kernels (forced on small n)."""
+    if variant == "R":
+        monkeypatch.setenv("HAMK_AD_MODE", "R")
+    else:
+        monkeypatch.setenv("HAMK_WAVE", "1")
+    spec = random_spec(seed)
+    s = api.system_from_spec(spec)
+    assert ("MODE_R = true" in s.source) if variant == "R" else ("HAMK_INSTANTIATE_WAVE" in s.source)
+    o = oracle_lib.OracleSystem(spec)
+    B = 70
+    q, qd = E.sample_config(spec, 5, B)
+    p = o.to_phase_batch(q, qd)
+    odq, odp, _ = o.hameqs_batch(q, p)
+    dq, dp = api.hamEqs(s, api.Phase(q, p))
+    cond = np.array([np.linalg.cond(o.jacobian(q[:, i]).T @ np.diag(spec.inertia) @ o.jacobian(q[:, i])) for i in range(B)])
+    tol = 1e-11 * np.maximum(1.0, cond / 100.0)
+    err = np.maximum(np.abs(dq - odq).max(0) / np.maximum(1.0, np.abs(odq).max(0)),
+                     np.abs(dp - odp).max(0) / np.maximum(1.0, np.abs(odp).max(0)))
+    assert np.all(err <= tol), (seed, variant, float(np.max(err / tol)))
+    ph = api.rk4Steps(spec.dt, 2, s, api.Phase(q, p))
+    oq, op = o.rk4_steps_batch(q, p, spec.dt, 2)
+    e2 = np.maximum(np.abs(ph.positions - oq).max(0), np.abs(ph.momenta - op).max(0)) / np.maximum(1.0, np.abs(op).max(0))
+    assert np.all(e2 <= 10 * tol), (seed, variant, float(np.max(e2 / tol)))
