@@ -68,6 +68,8 @@ struct hamk_system {
   double* d_ts = nullptr;
   size_t d_ts_cap = 0;
   std::vector<double> h_ts;
+  bool self_checked = false;
+  int self_check_rebuilds = 0;
 };
 
 // ---------------------------------------------------------------------------
@@ -212,6 +214,153 @@ static size_t kernel_code_bytes(const std::vector<char>& elf, const char* name) 
   return name ? 0 : nfunc;
 }
 
+
+static int launch(hamk_system* s, KernelId k, int64_t B, void** args);
+static int compile_module(hamk_system* s);
+
+// ---------------------------------------------------------------------------
+// First-use self-check of the stepping kernels against the (small, separately compiled) hamEqs
+// kernel: one RK4 step of the fused kernel must equal four hamEqs launches combined on the host,
+// one accepted RKF45 sub-step must equal its six stage evaluations combined on the host.  A JIT
+// product cannot take the code generator's word for it: on this toolchain one large unrolled
+// stepping kernel was observed to be silently wrong.  On a mismatch the
+// module is rebuilt once with the stage-loop bodies; if that does not help, the system is refused.
+// HAMK_SELFCHECK=0 skips it.
+// ---------------------------------------------------------------------------
+static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
+  const int n = s->desc.n;
+  const int64_t B = 64;
+  const size_t cnt = (size_t)n * B;
+  std::vector<double> q(cnt), p(cnt), k(2 * cnt), acc(2 * cnt), yt(2 * cnt);
+  for (int j = 0; j < n; ++j)
+    for (int64_t i = 0; i < B; ++i) {
+      q[(size_t)j * B + i] = 0.31 + 0.07 * j + 0.011 * (double)i;
+      p[(size_t)j * B + i] = 0.23 - 0.05 * j + 0.007 * (double)i;
+    }
+  double *d_q, *d_p, *d_dq, *d_dp, *d_ts; int32_t* d_st;
+  HIP_TRY(hipMalloc((void**)&d_q, cnt * 8)); HIP_TRY(hipMalloc((void**)&d_p, cnt * 8));
+  HIP_TRY(hipMalloc((void**)&d_dq, cnt * 8)); HIP_TRY(hipMalloc((void**)&d_dp, cnt * 8));
+  HIP_TRY(hipMalloc((void**)&d_ts, 2 * 8)); HIP_TRY(hipMalloc((void**)&d_st, B * 4));
+  auto cleanup = [&]() { hipFree(d_q); hipFree(d_p); hipFree(d_dq); hipFree(d_dp); hipFree(d_ts); hipFree(d_st); };
+  long long b = B;
+  auto rhs = [&](const std::vector<double>& y, std::vector<double>& out) -> int {   // out = hamEqs(y), y = [q; p]
+    HIP_TRY(hipMemcpy(d_q, y.data(), cnt * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_p, y.data() + cnt, cnt * 8, hipMemcpyHostToDevice));
+    const double *cq = d_q, *cp = d_p; int32_t* st = d_st;
+    void* args[] = {&cq, &cp, &d_dq, &d_dp, &b, &st};
+    int rc = launch(s, K_HAMEQS, B, args);
+    if (rc != HAMK_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(out.data(), d_dq, cnt * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out.data() + cnt, d_dp, cnt * 8, hipMemcpyDeviceToHost));
+    return HAMK_OK;
+  };
+  auto close_enough = [&](const std::vector<double>& a, const std::vector<double>& ref, bool* usable) {
+    double worst = 0.0; *usable = true;
+    for (size_t i = 0; i < 2 * cnt; ++i) {
+      if (!std::isfinite(ref[i])) { *usable = false; return true; }     // test points outside the system's domain: cannot judge
+      const double e = std::fabs(a[i] - ref[i]) / std::fmax(1.0, std::fabs(ref[i]));
+      if (!(e <= worst)) worst = e;
+    }
+    return worst <= 1e-9;
+  };
+  std::vector<double> y0(2 * cnt), got(2 * cnt), ref(2 * cnt);
+  std::copy(q.begin(), q.end(), y0.begin()); std::copy(p.begin(), p.end(), y0.begin() + cnt);
+  int rc = HAMK_OK;
+  bool usable = true;
+  // ---- RK4: one step of dt -------------------------------------------------------------------
+  const double dt = 1e-3;
+  {
+    const double a[4] = {0.0, 0.5 * dt, 0.5 * dt, dt}, w[4] = {dt / 6, dt / 3, dt / 3, dt / 6};
+    ref = y0;
+    std::fill(k.begin(), k.end(), 0.0);
+    for (int sg = 0; sg < 4 && rc == HAMK_OK; ++sg) {
+      for (size_t i = 0; i < 2 * cnt; ++i) yt[i] = y0[i] + a[sg] * k[i];
+      rc = rhs(yt, k);
+      for (size_t i = 0; i < 2 * cnt; ++i) ref[i] += w[sg] * k[i];
+    }
+    if (rc == HAMK_OK) {
+      hipMemcpy(d_q, q.data(), cnt * 8, hipMemcpyHostToDevice); hipMemcpy(d_p, p.data(), cnt * 8, hipMemcpyHostToDevice);
+      double ddt = dt; int ns = 1; int32_t* st = d_st;
+      void* args[] = {&d_q, &d_p, &b, &ddt, &ns, &st};
+      rc = launch(s, K_RK4, B, args);
+      if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RK4 kernel failed");
+      hipMemcpy(got.data(), d_q, cnt * 8, hipMemcpyDeviceToHost); hipMemcpy(got.data() + cnt, d_p, cnt * 8, hipMemcpyDeviceToHost);
+      *rk4_ok = close_enough(got, ref, &usable);
+    }
+  }
+  // ---- RKF45: one accepted sub-step (h = dt, huge tolerances, t: 0 -> dt) ---------------------
+  if (rc == HAMK_OK && usable) {
+    static const double A[5][5] = {{1.0 / 4, 0, 0, 0, 0},
+                                   {3.0 / 32, 9.0 / 32, 0, 0, 0},
+                                   {1932.0 / 2197, -7200.0 / 2197, 7296.0 / 2197, 0, 0},
+                                   {8341.0 / 4104, -32832.0 / 4104, 29440.0 / 4104, -845.0 / 4104, 0},
+                                   {-6080.0 / 20520, 41040.0 / 20520, -28352.0 / 20520, 9295.0 / 20520, -5643.0 / 20520}};
+    static const double C[6] = {902880.0 / 7618050, 0, 3953664.0 / 7618050, 3855735.0 / 7618050, -1371249.0 / 7618050, 277020.0 / 7618050};
+    std::vector<std::vector<double>> ks(6, std::vector<double>(2 * cnt));
+    rc = rhs(y0, ks[0]);
+    for (int sg = 1; sg < 6 && rc == HAMK_OK; ++sg) {
+      for (size_t i = 0; i < 2 * cnt; ++i) {
+        double t = 0.0;
+        for (int j2 = 0; j2 < sg; ++j2) t += A[sg - 1][j2] * ks[j2][i];
+        yt[i] = y0[i] + dt * t;
+      }
+      rc = rhs(yt, ks[sg]);
+    }
+    if (rc == HAMK_OK) {
+      for (size_t i = 0; i < 2 * cnt; ++i) {
+        double t = 0.0;
+        for (int j2 = 0; j2 < 6; ++j2) t += C[j2] * ks[j2][i];
+        ref[i] = y0[i] + dt * t;
+      }
+      hipMemcpy(d_q, q.data(), cnt * 8, hipMemcpyHostToDevice); hipMemcpy(d_p, p.data(), cnt * 8, hipMemcpyHostToDevice);
+      const double ts[2] = {0.0, dt};
+      hipMemcpy(d_ts, ts, sizeof ts, hipMemcpyHostToDevice);
+      double h0 = dt, ea = 1e30, er = 1e30;
+      int nt = 2, row0 = 1, inplace = 1, max_sub = 8;
+      const double *cq = d_q, *cp = d_p, *cts = d_ts; int32_t* st = d_st; int32_t* ns = nullptr;
+      void* args[] = {&cq, &cp, &d_q, &d_p, &b, &nt, &cts, &h0, &ea, &er, &row0, &inplace, &max_sub, &st, &ns};
+      rc = launch(s, K_RKF45, B, args);
+      if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RKF45 kernel failed");
+      hipMemcpy(got.data(), d_q, cnt * 8, hipMemcpyDeviceToHost); hipMemcpy(got.data() + cnt, d_p, cnt * 8, hipMemcpyDeviceToHost);
+      *rkf_ok = close_enough(got, ref, &usable);
+    }
+  }
+  if (!usable) { *rk4_ok = true; *rkf_ok = true; }
+  if (const char* e = std::getenv("HAMK_SELFCHECK_FAULT")) {        // test hook: pretend the unrolled body is wrong
+    if (std::strstr(e, "rk4") && !s->desc.rk4_stage_loop) *rk4_ok = false;
+    if (std::strstr(e, "rkf") && !s->desc.rkf_stage_loop) *rkf_ok = false;
+  }
+  cleanup();
+  return rc;
+}
+
+static int self_check(hamk_system* s) {
+  if (const char* e = std::getenv("HAMK_SELFCHECK")) if (e[0] == '0') return HAMK_OK;
+  if (s->self_checked) return HAMK_OK;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    bool rk4_ok = true, rkf_ok = true;
+    int rc = self_check_once(s, &rk4_ok, &rkf_ok);
+    if (rc != HAMK_OK) return rc;
+    if (rk4_ok && rkf_ok) { s->self_checked = true; return HAMK_OK; }
+    const bool can_retry = attempt == 0 && !s->desc.wave && ((!rk4_ok && !s->desc.rk4_stage_loop) || (!rkf_ok && !s->desc.rkf_stage_loop));
+    if (!can_retry)
+      return fail(HAMK_ERR_COMPILE, std::string("self-check failed: the fused ") + (!rk4_ok ? "RK4" : "RKF45") +
+                                        " kernel disagrees with the hamEqs kernel (miscompiled module?)");
+    if (!rk4_ok) s->desc.rk4_stage_loop = true;            // rebuild with the stage-loop bodies
+    if (!rkf_ok) s->desc.rkf_stage_loop = true;
+    s->source = generate_source(s->desc);
+    rc = compile_module(s);
+    if (rc != HAMK_OK) return rc;
+    hipModuleUnload(s->module);
+    s->module = nullptr;
+    HIP_TRY(hipModuleLoadData(&s->module, s->code.data()));
+    for (int k = 0; k < K__COUNT; ++k) HIP_TRY(hipModuleGetFunction(&s->fn[k], s->module, kKernelNames[k]));
+    s->self_check_rebuilds++;
+  }
+  return fail(HAMK_ERR_COMPILE, "self-check failed");
+}
+
 static int bind_device(hamk_system* s) {
   int dev = -1;
   hipError_t e = hipGetDevice(&dev);
@@ -231,7 +380,7 @@ static int bind_device(hamk_system* s) {
   HIP_TRY(hipModuleLoadData(&s->module, s->code.data()));
   for (int k = 0; k < K__COUNT; ++k) HIP_TRY(hipModuleGetFunction(&s->fn[k], s->module, kKernelNames[k]));
   s->device = dev;
-  return HAMK_OK;
+  return self_check(s);
 }
 
 static int launch(hamk_system* s, KernelId k, int64_t B, void** args) {

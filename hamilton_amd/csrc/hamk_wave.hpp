@@ -589,8 +589,11 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
 }  // namespace hamk
 
 // Same eight kernel names as HAMK_INSTANTIATE, wave-cooperative bodies.
+#ifndef HAMK_RK4_MIN_WAVES
+#define HAMK_RK4_MIN_WAVES 2
+#endif
 #define HAMK_INSTANTIATE_WAVE(S)                                                                                 \
-  extern "C" __global__ void __launch_bounds__(256, 2) hamk_rk4_steps_k(double* q, double* p, long long B,       \
+  extern "C" __global__ void __launch_bounds__(256, HAMK_RK4_MIN_WAVES) hamk_rk4_steps_k(double* q, double* p, long long B, \
                                                                          double dt, int nsteps, int* status) {   \
     HAMK_WAVE_SMEM(S);                                                                                           \
     hamk::wave::rk4_body<S>(smem, q, p, B, dt, nsteps, status);                                                  \

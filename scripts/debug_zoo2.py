@@ -7,7 +7,9 @@ spec = E.get("opcodeZoo"); o = oracle.OracleSystem(spec)
 B = 257
 q, qd = E.sample_config(spec, 2024, B)
 p = o.to_phase_batch(q, qd)
-for mode, loop, flags, waves in (("H", "0", "", ""), ("H", "0", "-DHAMK_NO_INCR", ""), ("H", "0", "", "2"), ("H", "0", "-DHAMK_NO_INCR", "2")):
+for mode, loop, flags, waves in (("H", "0", "", ""), ("H", "0", "-fhonor-nans -fsigned-zeros", ""), ("H", "0", "-O1", ""), ("H", "0", "-O2", ""),
+                                 ("H", "0", "-mllvm -amdgpu-use-divergent-register-indexing", ""), ("H", "0", "-mllvm -amdgpu-spill-sgpr-to-vgpr=0", ""),
+                                 ("H", "0", "-mllvm -amdgpu-spill-vgpr-to-agpr=0", "")):
     os.environ["HAMK_AD_MODE"] = mode; os.environ["HAMK_RK4_LOOP"] = loop
     os.environ["HAMK_HIPRTC_FLAGS"] = flags
     if waves: os.environ["HAMK_RK4_WAVES"] = waves

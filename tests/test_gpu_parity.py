@@ -386,3 +386,23 @@ def test_rank_deficient_jacobian_is_flagged(api):
     s3 = api.mkSystem([1.0, 1.0, 1.0], lambda q: [q[0] + q[1], q[1] + q[2], q[0] + 2 * q[1] + q[2]], lambda q: q[0], n=3)
     api.hamEqs(s3, api.Phase(np.ones((3, 4)), np.ones((3, 4))))
     assert np.all(np.asarray(s3.last_status) & 3)
+
+
+def test_first_use_self_check_and_recovery(api, oracle_lib, monkeypatch):
+    """At first use the fused RK4 / RKF45 kernels are checked against the hamEqs kernel (four resp.
+    six launches combined on the host).  With the test hook pretending the unrolled bodies are
+    wrong, the module is rebuilt with the stage-loop bodies and still gives the oracle's numbers."""
+    spec = E.get("doublePendulum")
+    o = oracle_lib.OracleSystem(spec)
+    q, qd = E.sample_config(spec, 8, 100)
+    p = o.to_phase_batch(q, qd)
+    monkeypatch.setenv("HAMK_SELFCHECK_FAULT", "rk4,rkf")
+    s = api.system_from_spec(spec)
+    assert "RK4_STAGE_LOOP = false" in s.source
+    ph = api.rk4Steps(0.01, 5, s, api.Phase(q, p))               # first use: self-check -> rebuild
+    assert "RK4_STAGE_LOOP = true" in s.source and "RKF_STAGE_LOOP = true" in s.source
+    oq, op = o.rk4_steps_batch(q, p, 0.01, 5)
+    assert relerr(ph.positions, oq) < 1e-12 and relerr(ph.momenta, op) < 1e-12
+    st = api.stepHam(0.01, s, api.Phase(q, p))
+    sq, sp, _ = o.step_ham_batch(q, p, 0.01)
+    assert relerr(st.positions, sq) < 1e-12
