@@ -16,7 +16,8 @@ final state runs after the timed region (reported as gather_ms).
 
 Prints ONE JSON line on rank 0.  `roofline.achieved` follows SURVEY.md section 8d: 32*n
 algorithmic bytes per trajectory-step (charged per RK4 step even though rk4-per-step steps
-are fused per launch; `roofline.launch_bytes` is the true per-launch read+write), divided by
+are fused per launch; `roofline.state_bytes_moved_per_launch` is what a launch really reads and
+writes, matched by the PMC figure in `traffic`), divided by
 the kernel's average duration measured with HIP events on the launch stream.  The path is
 FP64-VALU bound, not HBM bound: the fp64 object next to it is the figure
 that says how good the kernel is.
@@ -219,14 +220,16 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (per-index splitmix64 initial conditions, seed 20241008)",
-            "config": {"workload": f"{a.system} (System {spec.m} {spec.n}) ensemble, BASELINE.json configs[1]",
+            "config": {"workload": f"{a.system} (System {spec.m} {spec.n}) ensemble"
+                                   + (", BASELINE.json configs[1]" if a.system == "doublePendulum" and a.batch == (1 << 20) else ""),
                        "trajectories_per_gpu": B, "rk4_steps_per_launch": a.rk4_per_step, "dt": dt,
                        "parallelism": f"ensemble-shard x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "hamk_rk4_steps_k", "kernel_ms": kernel_s * 1e3,
                          "algorithmic_bytes_per_trajectory_step": alg_bytes,
-                         "launch_bytes": alg_bytes * B,
+                         "algorithmic_bytes_per_launch": alg_bytes * B * a.rk4_per_step,
+                         "state_bytes_moved_per_launch": alg_bytes * B + 4 * B,
                          "note": "charged 32n B per RK4 step (SURVEY 8d); fp64-VALU bound, see fp64"},
             "fp64": {"per_gpu_steps_per_s": per_gpu_rate, "peak_tflops": FP64_PEAK_TFLOPS},
             "status_flagged": bad, "max_rel_energy_drift": drift,

@@ -64,6 +64,12 @@ struct hamk_system {
   // where a hipMalloc/hipFree pair per array per call would dominate
   std::vector<void*> stage_buf;
   std::vector<size_t> stage_cap;
+  // pinned, device-mapped arena for SMALL host-pointer calls (the reference's one-trajectory
+  // stepHam per frame): the kernel reads and writes host memory directly over PCIe -- a launch
+  // and a stream synchronisation per call, no hipMemcpy at all
+  char* pin = nullptr;          // host address
+  char* pin_dev = nullptr;      // the same block as the device sees it
+  bool pin_failed = false;
   // small device scratch for evolveHam's time grid
   double* d_ts = nullptr;
   size_t d_ts_cap = 0;
@@ -318,12 +324,10 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
         ref[i] = y0[i] + dt * t;
       }
       hipMemcpy(d_q, q.data(), cnt * 8, hipMemcpyHostToDevice); hipMemcpy(d_p, p.data(), cnt * 8, hipMemcpyHostToDevice);
-      const double ts[2] = {0.0, dt};
-      hipMemcpy(d_ts, ts, sizeof ts, hipMemcpyHostToDevice);
-      double h0 = dt, ea = 1e30, er = 1e30;
+      double h0 = dt, ea = 1e30, er = 1e30, t0 = 0.0, t1 = dt;
       int nt = 2, row0 = 1, inplace = 1, max_sub = 8;
-      const double *cq = d_q, *cp = d_p, *cts = d_ts; int32_t* st = d_st; int32_t* ns = nullptr;
-      void* args[] = {&cq, &cp, &d_q, &d_p, &b, &nt, &cts, &h0, &ea, &er, &row0, &inplace, &max_sub, &st, &ns};
+      const double *cq = d_q, *cp = d_p, *cts = nullptr; int32_t* st = d_st; int32_t* ns = nullptr;
+      void* args[] = {&cq, &cp, &d_q, &d_p, &b, &nt, &cts, &t0, &t1, &h0, &ea, &er, &row0, &inplace, &max_sub, &st, &ns};
       rc = launch(s, K_RKF45, B, args);
       if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RKF45 kernel failed");
       hipMemcpy(got.data(), d_q, cnt * 8, hipMemcpyDeviceToHost); hipMemcpy(got.data() + cnt, d_p, cnt * 8, hipMemcpyDeviceToHost);
@@ -376,6 +380,7 @@ static int bind_device(hamk_system* s) {
     if (s->d_ts) { hipFree(s->d_ts); s->d_ts = nullptr; s->d_ts_cap = 0; }
     for (void*& b : s->stage_buf) if (b) { hipFree(b); b = nullptr; }
     s->stage_cap.assign(s->stage_cap.size(), 0);
+    if (s->pin) { hipHostFree(s->pin); s->pin = s->pin_dev = nullptr; }
   }
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
@@ -403,9 +408,12 @@ namespace {
 struct Staged {
   void* dev = nullptr;
   void* host = nullptr;
+  void* pinned = nullptr;      // non-null: `dev` aliases this pinned host block
   size_t bytes = 0;
   bool out = false;
 };
+constexpr size_t kPinArena = 256 << 10;    // bytes of pinned arena per handle
+constexpr size_t kPinMaxBuf = 32 << 10;    // larger arrays go through device staging
 class Stager {
  public:
   explicit Stager(hamk_system* s, int mem) : s_(s), host_(mem == HAMK_MEM_HOST) {}
@@ -413,11 +421,21 @@ class Stager {
   template <class T> int in(const T* p, size_t count, T** dev) { return add((void*)p, count * sizeof(T), true, false, (void**)dev); }
   template <class T> int out(T* p, size_t count, T** dev) { return add((void*)p, count * sizeof(T), false, true, (void**)dev); }
   template <class T> int inout(T* p, size_t count, T** dev) { return add((void*)p, count * sizeof(T), true, true, (void**)dev); }
+  // small read-only side input (evolveHam's time grid): pinned copy, or nullptr if it does not fit
+  const double* side_input(const double* p, size_t count) {
+    if (!host_) return nullptr;
+    void* host = nullptr; void* dev = nullptr;
+    if (!pin_alloc(count * sizeof(double), &host, &dev)) return nullptr;
+    std::memcpy(host, p, count * sizeof(double));
+    return (const double*)dev;
+  }
   int finish() {
     if (!host_) return HAMK_OK;
     for (auto& b : bufs_)
-      if (b.out) HIP_TRY(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, s_->stream));
+      if (b.out && !b.pinned) HIP_TRY(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, s_->stream));
     HIP_TRY(hipStreamSynchronize(s_->stream));
+    for (auto& b : bufs_)
+      if (b.out && b.pinned) std::memcpy(b.host, b.pinned, b.bytes);
     return HAMK_OK;
   }
 
@@ -425,7 +443,13 @@ class Stager {
   int add(void* p, size_t bytes, bool copy_in, bool copy_out, void** dev) {
     if (!p || !host_ || bytes == 0) { *dev = p; return HAMK_OK; }
     Staged b; b.host = p; b.bytes = bytes; b.out = copy_out;
-    const size_t slot = bufs_.size();
+    if (bytes <= kPinMaxBuf && pin_alloc(bytes, &b.pinned, &b.dev)) {
+      if (copy_in) std::memcpy(b.pinned, p, bytes);
+      bufs_.push_back(b);
+      *dev = b.dev;
+      return HAMK_OK;
+    }
+    const size_t slot = nstaged_++;
     if (slot >= s_->stage_buf.size()) { s_->stage_buf.push_back(nullptr); s_->stage_cap.push_back(0); }
     if (s_->stage_cap[slot] < bytes) {
       HIP_TRY(hipStreamSynchronize(s_->stream));          // nobody may still be using the old block
@@ -440,8 +464,32 @@ class Stager {
     *dev = b.dev;
     return HAMK_OK;
   }
+  // bump allocation in the handle's pinned arena; every host-pointer call ends with a stream
+  // synchronisation (finish), so the arena is free again when the next call starts
+  bool pin_alloc(size_t bytes, void** host, void** dev) {
+    if (s_->pin_failed) return false;
+    if (!s_->pin) {
+      static const bool off = [] { const char* e = std::getenv("HAMK_PINNED"); return e && e[0] == '0'; }();
+      void* h = nullptr; void* d = nullptr;
+      if (off || hipHostMalloc(&h, kPinArena, hipHostMallocMapped) != hipSuccess ||
+          hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+        if (h) hipHostFree(h);
+        (void)hipGetLastError();
+        s_->pin_failed = true;
+        return false;
+      }
+      s_->pin = (char*)h; s_->pin_dev = (char*)d;
+    }
+    const size_t at = (pin_used_ + 255) & ~(size_t)255;
+    if (at + bytes > kPinArena) return false;
+    pin_used_ = at + bytes;
+    *host = s_->pin + at; *dev = s_->pin_dev + at;
+    return true;
+  }
   hamk_system* s_;
   bool host_;
+  size_t pin_used_ = 0;
+  size_t nstaged_ = 0;
   std::vector<Staged> bufs_;
 };
 }  // namespace
@@ -534,6 +582,7 @@ void hamk_system_destroy(hamk_system* s) {
   if (s->module) hipModuleUnload(s->module);
   if (s->d_ts) hipFree(s->d_ts);
   for (void* b : s->stage_buf) if (b) hipFree(b);
+  if (s->pin) hipHostFree(s->pin);
   delete s;
 }
 
@@ -719,11 +768,18 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
   if (nt < 2) return fail(HAMK_ERR_INVALID, "evolveHam needs at least two times (2 <= s, Hamilton.hs:435)");
   if (B == 0) return HAMK_OK;
   TRY(bind_device(s));
-  TRY(upload_times(s, nt, ts));
   if (!(h0 > 0.0)) h0 = (ts[1] - ts[0]) / 100.0;          // Hamilton.hs:447
   if (!(eps_abs > 0.0)) eps_abs = kRefEps;
   if (!(eps_rel > 0.0)) eps_rel = kRefEps;
   Stager st(s, mem);
+  // time grid: two times travel as kernel arguments; a longer grid as a pinned side input of a
+  // small host-pointer call, else through the handle's device scratch
+  double ts0 = ts[0], ts1 = ts[1];
+  const double* dts = nullptr;
+  if (nt > 2) {
+    dts = (size_t)nt * sizeof(double) <= kPinMaxBuf ? st.side_input(ts, (size_t)nt) : nullptr;
+    if (!dts) { TRY(upload_times(s, nt, ts)); dts = s->d_ts; }
+  }
   const size_t cnt = (size_t)s->desc.n * B;
   const double *xq, *xp; double *xqo, *xpo; int32_t *dst, *dns;
   TRY(st.in(q0, cnt, (double**)&xq));
@@ -734,8 +790,7 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
   TRY(st.out(nsub, (size_t)B, &dns));
   long long b = B;
   int nt_ = nt, row0 = 0, inplace = 0, max_sub = kMaxSub;
-  const double* dts = s->d_ts;
-  void* args[] = {&xq, &xp, &xqo, &xpo, &b, &nt_, &dts, &h0, &eps_abs, &eps_rel, &row0, &inplace, &max_sub, &dst, &dns};
+  void* args[] = {&xq, &xp, &xqo, &xpo, &b, &nt_, &dts, &ts0, &ts1, &h0, &eps_abs, &eps_rel, &row0, &inplace, &max_sub, &dst, &dns};
   TRY(launch(s, K_RKF45, B, args));
   return st.finish();
 }
@@ -746,8 +801,7 @@ int hamk_step_ham_batch(hamk_system* s, int64_t B, double* q, double* p, double 
   if (!q || !p) return fail(HAMK_ERR_INVALID, "null q / p");
   if (B == 0) return HAMK_OK;
   TRY(bind_device(s));
-  const double ts[2] = {0.0, dt};                           // Hamilton.hs:401
-  TRY(upload_times(s, 2, ts));
+  double ts0 = 0.0, ts1 = dt;                               // evolveHam over (0, r), Hamilton.hs:401
   double h0 = dt / 100.0, eps_abs = kRefEps, eps_rel = kRefEps;
   Stager st(s, mem);
   const size_t cnt = (size_t)s->desc.n * B;
@@ -758,9 +812,9 @@ int hamk_step_ham_batch(hamk_system* s, int64_t B, double* q, double* p, double 
   TRY(st.out(nsub, (size_t)B, &dns));
   long long b = B;
   int nt_ = 2, row0 = 1, inplace = 1, max_sub = kMaxSub;
-  const double* dts = s->d_ts;
+  const double* dts = nullptr;
   const double *cq = xq, *cp = xp;
-  void* args[] = {&cq, &cp, &xq, &xp, &b, &nt_, &dts, &h0, &eps_abs, &eps_rel, &row0, &inplace, &max_sub, &dst, &dns};
+  void* args[] = {&cq, &cp, &xq, &xp, &b, &nt_, &dts, &ts0, &ts1, &h0, &eps_abs, &eps_rel, &row0, &inplace, &max_sub, &dst, &dns};
   TRY(launch(s, K_RKF45, B, args));
   return st.finish();
 }

@@ -1034,7 +1034,7 @@ HAMK_DEV void observe_config_body(const double* __restrict__ q, const double* __
 // stepHam in place (rows are written only for r >= row0).
 // ---------------------------------------------------------------------------
 template <class S>
-HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt, const double* __restrict__ ts, double h0,
+HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt, const double* __restrict__ ts, double ts0, double ts1, double h0,
                          double eps_abs, double eps_rel, int row0, int inplace, int max_sub,
                          int* __restrict__ status, int* __restrict__ nsub) {
   constexpr int N = S::N, D = 2 * N;
@@ -1048,14 +1048,15 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
     for (int j = 0; j < N; ++j) { qout[(i64)j * B + i] = y[j]; pout[(i64)j * B + i] = y[N + j]; }
   }
   int st = 0, attempts = 0;
-  double t = ts[0], h = h0;
+  // time grid: ts[0..nt), or -- ts == nullptr, nt == 2: stepHam -- the two kernel arguments
+  double t = ts ? ts[0] : ts0, h = h0;
   TrigCache<S::NTRIG_F> tc;
   // sincos anchors follow dydt_in/dydt_out: the stage points of an attempt sit within h |f| of
   // the point where dydt_in was evaluated (after a rejection: of the rejected end point, still
   // close; TRIG_INCR falls back to the full evaluation when it is not)
   rhs<S, StageTrig<S>::anchor>(y, f0, st, tc);        // dydt_in at the initial state
   for (int r = 1; r < nt; ++r) {
-    const double ti = ts[r];
+    const double ti = ts ? ts[r] : ts1;
     while (t < ti && attempts < max_sub) {
       ++attempts;
       const double dt = ti - t;
@@ -1263,7 +1264,8 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
   }                                                                                                              \
   extern "C" __global__ void __launch_bounds__(256) hamk_rkf45_k(                                                \
       const double* q0, const double* p0, double* qout, double* pout, long long B, int nt, const double* ts,     \
-      double h0, double eps_abs, double eps_rel, int row0, int inplace, int max_sub, int* status, int* nsub) {   \
-    hamk::rkf45_body<S>(q0, p0, qout, pout, B, nt, ts, h0, eps_abs, eps_rel, row0, inplace, max_sub, status,     \
-                        nsub);                                                                                   \
+      double ts0, double ts1, double h0, double eps_abs, double eps_rel, int row0, int inplace, int max_sub,     \
+      int* status, int* nsub) {                                                                                  \
+    hamk::rkf45_body<S>(q0, p0, qout, pout, B, nt, ts, ts0, ts1, h0, eps_abs, eps_rel, row0, inplace, max_sub,   \
+                        status, nsub);                                                                           \
   }

@@ -473,8 +473,8 @@ template <class S> HAMK_DEV void coords_body(double* smem, const double* q, doub
 // the six evaluations of an attempt through a stage switch.
 template <class S>
 HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt,
-                         const double* ts, double h0, double eps_abs, double eps_rel, int row0, int inplace,
-                         int max_sub, int* status, int* nsub) {
+                         const double* ts, double ts0, double ts1, double h0, double eps_abs, double eps_rel,
+                         int row0, int inplace, int max_sub, int* status, int* nsub) {
   constexpr int N = S::N, NP = Geo<N>::NP;
   Where<S> w(smem, B);
   const int j = (w.c.li < N) ? w.c.li : 0;
@@ -482,11 +482,11 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
   double yq = q0[(i64)j * B + w.t], yp = p0[(i64)j * B + w.t];
   if (row0 == 0 && w.live) { qout[(i64)j * B + w.t] = yq; pout[(i64)j * B + w.t] = yp; }
   int st = 0, attempts = 0;
-  double t = ts[0], h = h0;
+  double t = ts ? ts[0] : ts0, h = h0;
   double fq, fp;
   ham_eqs<S>(w.c, yq, yp, fq, fp, st);                    // dydt_in at the initial state
   for (int r = 1; r < nt; ++r) {
-    const double ti = ts[r];
+    const double ti = ts ? ts[r] : ts1;
     for (;;) {
       const bool active = (t < ti) && (attempts < max_sub);
       if (!__any(active)) break;                           // wave-uniform exit
@@ -631,8 +631,9 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
   }                                                                                                              \
   extern "C" __global__ void __launch_bounds__(256) hamk_rkf45_k(                                                \
       const double* q0, const double* p0, double* qout, double* pout, long long B, int nt, const double* ts,     \
-      double h0, double eps_abs, double eps_rel, int row0, int inplace, int max_sub, int* status, int* nsub) {   \
+      double ts0, double ts1, double h0, double eps_abs, double eps_rel, int row0, int inplace, int max_sub,     \
+      int* status, int* nsub) {                                                                                  \
     HAMK_WAVE_SMEM(S);                                                                                           \
-    hamk::wave::rkf45_body<S>(smem, q0, p0, qout, pout, B, nt, ts, h0, eps_abs, eps_rel, row0, inplace, max_sub, \
-                              status, nsub);                                                                     \
+    hamk::wave::rkf45_body<S>(smem, q0, p0, qout, pout, B, nt, ts, ts0, ts1, h0, eps_abs, eps_rel, row0,         \
+                              inplace, max_sub, status, nsub);                                                   \
   }

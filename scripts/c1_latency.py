@@ -12,6 +12,19 @@ t0 = time.perf_counter()
 for _ in range(1000):
     ph = api.stepHam(0.01, s, api.Phase(q, p)); q, p = ph.positions, ph.momenta
 g = time.perf_counter() - t0
+# the same through the bare C ABI (no Python object churn): what a compiled host pays per call
+import ctypes
+from hamilton_amd import _abi
+lib = _abi.lib()
+rq, rp = np.array(spec.q0), np.zeros(2); st = np.zeros(1, np.int32); ns = np.zeros(1, np.int32)
+dp = ctypes.POINTER(ctypes.c_double); ip = ctypes.POINTER(ctypes.c_int32)
+args = (s._h, 1, rq.ctypes.data_as(dp), rp.ctypes.data_as(dp), ctypes.c_double(0.01), st.ctypes.data_as(ip), ns.ctypes.data_as(ip), 0)
+t0 = time.perf_counter()
+for _ in range(1000):
+    lib.hamk_step_ham_batch(*args)
+raw = time.perf_counter() - t0
+assert max(np.max(np.abs(rq - q)), np.max(np.abs(rp - p))) == 0.0
+print(f"C1 bare C ABI: {raw*1e3:.1f} us/call (HAMK_PINNED={os.environ.get('HAMK_PINNED', '1')})")
 oq, op = np.array(spec.q0), np.zeros(2)
 t0 = time.perf_counter()
 for _ in range(1000):
