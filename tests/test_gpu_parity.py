@@ -256,6 +256,40 @@ def test_device_pointers_equal_host_staging(api, systems):
     np.testing.assert_array_equal(tq.cpu().numpy(), host.positions)
 
 
+@pytest.mark.parametrize("B", [1, 7, 300, 20000])
+def test_host_pointer_paths_equal_device_path(api, systems, B):
+    """Host-pointer calls take the pinned, device-mapped arena when the arrays are small (B = 1, 7,
+    300: the kernel reads/writes host memory directly) and staged copies when large (B = 20000),
+    mixed in between; every entry point must give the bits of the HAMK_MEM_DEVICE path."""
+    import torch
+    spec, s, o = systems["spring"]
+    q, qd = E.sample_config(spec, 4242, B)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    eq = lambda d, h: np.testing.assert_array_equal(d.cpu().numpy(), h)
+    ph_h = api.toPhase(s, api.Config(q, qd)); ph_d = api.toPhase(s, api.Config(T(q), T(qd)))
+    eq(ph_d.momenta, ph_h.momenta)
+    p = ph_h.momenta
+    eq(api.fromPhase(s, api.Phase(T(q), T(p))).velocities, api.fromPhase(s, api.Phase(q, p)).velocities)
+    eq(api.underlyingPos(s, T(q)), api.underlyingPos(s, q))
+    eq(api.hamiltonian(s, api.Phase(T(q), T(p))), api.hamiltonian(s, api.Phase(q, p)))
+    eq(api.lagrangian(s, api.Config(T(q), T(qd))), api.lagrangian(s, api.Config(q, qd)))
+    dq_h, dp_h = api.hamEqs(s, api.Phase(q, p)); dq_d, dp_d = api.hamEqs(s, api.Phase(T(q), T(p)))
+    eq(dq_d, dq_h); eq(dp_d, dp_h)
+    r_h = api.rk4Steps(0.01, 7, s, api.Phase(q, p)); r_d = api.rk4Steps(0.01, 7, s, api.Phase(T(q), T(p)))
+    eq(r_d.positions, r_h.positions); eq(r_d.momenta, r_h.momenta)
+    s_h = api.stepHam(0.05, s, api.Phase(q, p)); n_h = np.asarray(s.last_nsub).copy()
+    s_d = api.stepHam(0.05, s, api.Phase(T(q), T(p))); eq(s.last_nsub, n_h)
+    eq(s_d.positions, s_h.positions); eq(s_d.momenta, s_h.momenta)
+    # a 3-point grid (pinned side input for small host calls) and a 6000-point one (48 KB: device scratch)
+    for ts in (np.array([0.0, 0.02, 0.05]), np.linspace(0.0, 0.03, 6000)):
+        if B > 300 and len(ts) > 3:
+            continue
+        e_h = api.evolveHam(s, api.Phase(q, p), ts); e_d = api.evolveHam(s, api.Phase(T(q), T(p)), ts)
+        for r in (0, 1, len(ts) - 1):
+            eq(e_d[r].positions, e_h[r].positions); eq(e_d[r].momenta, e_h[r].momenta)
+    torch.cuda.synchronize()
+
+
 # ---------------------------------------------------------------- BASELINE.json full size: properties
 def test_full_size_properties(api, systems):
     """Config 2 at full size (1,048,576 double-pendulum trajectories): size-independent properties.
