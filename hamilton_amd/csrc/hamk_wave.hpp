@@ -111,6 +111,9 @@ template <class S, int NP> struct SinkK {          // sweep 1: K += m_k J[k][.]^
   int li;                                          //   b[li + d] never wraps: one base register + immediate
   double rot[NP / 2 + 1];                          //   offsets.  rot[d] = K[li][(li+d) mod NP].  One buffer is
   template <int K> HAMK_DEV void put(const Jet1<1>& v) {   // enough: DS operations of a wave execute in order.
+#ifdef HAMK_PROBE_SKIP_KACC                                // timing probes (scripts/wave_attrib.py): wrong results
+    rot[K % (NP / 2 + 1)] += v.d[0]; return;
+#endif
     double* b = buf + li;
     b[0] = v.d[0];
     b[NP] = v.d[0];
@@ -172,10 +175,20 @@ template <class S> HAMK_DEV void cooperative_trig(const Ctx<S>& c, double qi) {
   }
 }
 
-// Sweep 1 (with K accumulated in the sink) + LDL^T.  On return: `row` holds L[li][j] (j < li),
-// `dinv` = 1/d_li; gU = dU/dq_li; the tile holds L (row-major, stride NP+1).
+// Sweep 1 (with K accumulated in the sink) + LDL^T, with the forward substitution of one right-hand
+// side riding along.  On return: `row` holds L[li][j] (j < li), `dinv` = 1/d_li, z = (L^-1 rhs)_li;
+// gU = dU/dq_li; the tile holds L (row-major, stride NP+1).
+//
+// Rows are distributed over lanes and only the lower triangle is kept (lane i: K[i][k], k <= i).
+// The update of pivot j, K[i][k] -= l_ij K[k][j], needs column j as every lane k holds it in its
+// own row -- so before the pivot each lane drops its current K[li][j] (and its z) into a column
+// buffer in LDS and all lanes read what they need back as BROADCAST loads with immediate offsets:
+// one write and (N-1-j)/2 wide reads per pivot, against two ds_bpermute per element before (992 of
+// them at N = 32, 56 % of the evaluation's time).  DS operations of a wave execute in order, so the
+// buffer needs no double-buffering.
 template <class S>
-HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& dinv, double& gU, double& U, int& st) {
+HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& dinv, double& gU, double& U, int& st,
+                     double& z) {
   constexpr int N = S::N, NP = Ctx<S>::NP;
   constexpr int TRIG1 = (S::TRIG_ALL_INPUTS && S::NTRIG_F > 0) ? TRIG_REUSE : TRIG_FULL;
   const int li = c.li;
@@ -205,21 +218,27 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
   lds_sync();
 #pragma unroll
   for (int b = 0; b < N; ++b) row[b] = c.tile()[li * (NP + 1) + b];
-  // LDL^T, right-looking, rows distributed over lanes
+  // LDL^T, right-looking
   bool ok = true;
   dinv = 0.0;
+  double* col = c.rowbuf();                                // [NP] column j, [NP] z (the row buffer is free here)
+#ifdef HAMK_PROBE_SKIP_FACTOR
+  dinv = frcp(row[0] + 2.0);
+  if (0)
+#endif
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    const double dj = bcast4(row[j], c.grp4(), j);
+    col[li] = row[j];
+    col[NP + li] = z;
+    lds_sync();
+    const double dj = col[j];
     ok = ok && (dj > 0.0);
     const double inv = frcp(dj);
-    const double lij = row[j] * inv;
+    const double lij = (li > j) ? row[j] * inv : 0.0;       // 0: lanes at or above the pivot do not update
     if (li == j) dinv = inv;
+    z = fma(-lij, col[NP + j], z);                           // L z = rhs, one term per pivot
 #pragma unroll
-    for (int k = j + 1; k < N; ++k) {
-      const double rjk = bcast4(row[k], c.grp4(), j);             // K[j][k] after the first j updates
-      if (li > j) row[k] = fma(-lij, rjk, row[k]);
-    }
+    for (int k = j + 1; k < N; ++k) row[k] = fma(-lij, col[k], row[k]);   // (entries k > li are never read)
     if (li > j) row[j] = lij;
   }
   if (!ok && li < N) st |= ST_SINGULAR;                    // no pivoting fallback in the wave kernels
@@ -231,17 +250,14 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
   lds_sync();
 }
 
-// Solve K v = rhs with the factorisation left by `factor`; returns v_li.
+// Finish K v = rhs after `factor` (which left z = L^-1 rhs): D y = z, L^T v = y; returns v_li.
 template <class S>
-HAMK_DEV double solve(const Ctx<S>& c, const double (&row)[S::N], double dinv, double rhs) {
+HAMK_DEV double solve_back(const Ctx<S>& c, double dinv, double z) {
   constexpr int N = S::N, NP = Ctx<S>::NP;
   const int li = c.li;
-  double z = rhs;
-#pragma unroll
-  for (int j = 0; j < N; ++j) {                            // L z = rhs
-    const double zj = bcast4(z, c.grp4(), j);
-    if (li > j) z = fma(-row[j], zj, z);
-  }
+#ifdef HAMK_PROBE_SKIP_SOLVE
+  return z * dinv;
+#endif
   double v = z * dinv;                                     // D y = z
 #pragma unroll
   for (int k = N - 1; k >= 0; --k) {                       // L^T v = y
@@ -260,8 +276,9 @@ HAMK_DEV void ham_eqs(const Ctx<S>& c0, double qi, double pi, double& dqi, doubl
   lds_sync();
   c.ga()[c.li] = qi;                                        // all-gather q through LDS; it stays there
   lds_sync();
-  factor<S>(c, qi, row, dinv, gU, U, st);
-  const double vi = solve<S>(c, row, dinv, pi);
+  double z = pi;
+  factor<S>(c, qi, row, dinv, gU, U, st, z);
+  const double vi = solve_back<S>(c, dinv, z);
   lds_sync();
   c.gb()[c.li] = vi;                                        // ... and qd
   lds_sync();
@@ -272,7 +289,9 @@ HAMK_DEV void ham_eqs(const Ctx<S>& c0, double qi, double pi, double& dqi, doubl
   InJet2 q2{c2.ga(), c2.gb(), c2.li};
   SinkT<S> sink;
   TrigLds tl = c2.trig();
+#ifndef HAMK_PROBE_SKIP_SWEEP2
   S::template coords_sink<Jet2<1>, TRIG_REUSE>(q2, tl, sink);   // sincos pairs of sweep 1, from LDS
+#endif
   dqi = vi;
   dpi = -(sink.dT + gU);
 }
@@ -380,8 +399,9 @@ HAMK_DEV double velocity(const Ctx<S>& c0, double qi, double pi, double& U, int&
   lds_sync();
   c.ga()[c.li] = qi;
   lds_sync();
-  factor<S>(c, qi, row, dinv, gU, U, st);
-  return solve<S>(c, row, dinv, pi);
+  double z = pi;
+  factor<S>(c, qi, row, dinv, gU, U, st, z);
+  return solve_back<S>(c, dinv, z);
 }
 
 template <class S>
