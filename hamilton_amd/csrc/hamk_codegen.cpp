@@ -78,8 +78,9 @@ std::string validate_tape(const hamk_op* ops, int nops, int n_in, const int32_t*
 // stay plain doubles so the jet overloads never multiply by a lifted zero jet.
 // Returns the number of trig-cache slots (one per distinct sincos operand) the body uses.
 // sink_outs (optional): value id -> list of output slots; each output is handed to
-// `sink.template put<K>(value)` right after the op that defines it, so a consumer that only
-// accumulates never keeps all M outputs live (wave kernels, M up to 64).
+// `sink.template put<K, SEQ>(value)` right after the op that defines it (SEQ = 0, 1, ... in the
+// order of emission), so a consumer that only accumulates never keeps all M outputs live (wave
+// kernels, M up to 64).
 // input_exprs (optional): expression to use for INPUT j instead of in[j] (composition u . f);
 // tc_name: the trig cache variable the body's sincos sites use.
 static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const char* pfx,
@@ -93,6 +94,7 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
     if (ops[i].op == HAMK_OP_COS && cos_of[ops[i].a] < 0) cos_of[ops[i].a] = i;
   }
   std::vector<char> done(nops, 0);
+  int put_seq = 0;
   std::vector<int> slot_of(nops, -1);          // operand value id -> trig cache slot
   int nslots = 0;
   auto slot = [&](int operand) {
@@ -142,7 +144,7 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
       // a fused sincos defines two values at once: flush every defined value's outputs
       for (int j = 0; j < nops; ++j)
         if (done[j] == 1) {
-          for (int k : (*sink_outs)[j]) o << "    sink.template put<" << k << ">(hamk::lift<A>(" << v(j) << "));\n";
+          for (int k : (*sink_outs)[j]) o << "    sink.template put<" << k << ", " << put_seq++ << ">(hamk::lift<A>(" << v(j) << "));\n";
           done[j] = 2;
         }
     }

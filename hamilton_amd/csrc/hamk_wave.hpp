@@ -106,30 +106,106 @@ struct InJet2 {                                    // q_j along the common direc
 };
 
 // ---- sinks for coords_sink -------------------------------------------------------------------
-template <class S, int NP> struct SinkK {          // sweep 1: K += m_k J[k][.]^T J[k][.], circulant storage
-  double* buf;                                     // [2*NP]: the row stored twice back to back so that
-  int li;                                          //   b[li + d] never wraps: one base register + immediate
-  double rot[NP / 2 + 1];                          //   offsets.  rot[d] = K[li][(li+d) mod NP].  One buffer is
-  template <int K> HAMK_DEV void put(const Jet1<1>& v) {   // enough: DS operations of a wave execute in order.
-#ifdef HAMK_PROBE_SKIP_KACC                                // timing probes (scripts/wave_attrib.py): wrong results
-    rot[K % (NP / 2 + 1)] += v.d[0]; return;
-#endif
-    double* b = buf + li;
-    b[0] = v.d[0];
-    b[NP] = v.d[0];
-    lds_sync();
-    const double a = S::inertia(K) * v.d[0];
+// Sweep 1: K = sum_k m_k J[k][.]^T J[k][.] on the matrix cores.  Lane i of a group learns J[k][i]
+// the moment x_k is defined; four consecutive rows are staged in LDS (in the tile, which is free
+// during the sweep) and consumed by v_mfma_f64_16x16x4_f64, whose operand layout is exactly
+// "four rows, sixteen columns": A[i][kk] and B[kk][j] both sit in lane 16*kk + i -- ONE 8-byte LDS
+// read per lane per 16-column block per four rows, where the FMA formulation needs every lane to
+// read every column of every row (17 reads per row in circulant form: LDS bandwidth, not FP64 rate,
+// bounded it at 58 % of the evaluation).  The f64 MFMA rate itself is lower than the VALU's on this
+// chip (profiles/r01_mfma_f64_probe.txt); what the matrix core buys here is the operand broadcast.
+// A wavefront holds G = 64/NP trajectories; each MFMA serves one of them with all 64 lanes, the
+// accumulators of all G stay in registers: D[i][j] of block (ib, jb) is K[16 ib + i][16 jb + j],
+// lane l / register r holding i = 4 r + l/16, j = l%16 (scripts/probes/mfma_f64_layout.hip).
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+template <class S, int NP> struct SinkK {
+  static constexpr int G = 64 / NP, NB = NP / 16, NBLK = NB * (NB + 1) / 2;
+  static constexpr int PER = Lds<S>::PER_TRAJ;
+  HAMK_DEV static constexpr int blk_of(int ib, int jb) { return ib * NB - ib * (ib - 1) / 2 + (jb - ib); }   // ib <= jb
+  double* mine;            // staging rows of this lane's trajectory: [4][NP], + li
+  const double* rd;        // staging of the wave's first trajectory, + (lane/16)*NP + lane%16
+  int kq;                  // lane / 16: which of the four staged rows this lane feeds to the MFMA
+  double m0, m1, m2, m3;   // inertias of the staged rows (scalars: an array invites a dynamically indexed load)
+  mfma_d4 acc[G][NBLK];
+  HAMK_DEV void init(double* smem, int off, int offw, int li, int lw) {
+    mine = smem + off + li;
+    kq = lw >> 4;
+    rd = smem + offw + kq * NP + (lw & 15);
 #pragma unroll
-    for (int d = 0; d <= NP / 2; ++d) rot[d] = fma(a, b[d], rot[d]);
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) acc[g][b] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  }
+  template <int R> HAMK_DEV void set_m(double m) {
+    if constexpr (R == 0) m0 = m; else if constexpr (R == 1) m1 = m; else if constexpr (R == 2) m2 = m; else m3 = m;
+  }
+  // SEQ: position of this output in the order of emission (the generator numbers its puts)
+  template <int K, int SEQ> HAMK_DEV void put(const Jet1<1>& v) {
+#ifdef HAMK_PROBE_SKIP_KACC                                // timing probes (scripts/wave_attrib.py): wrong results
+    acc[0][0][K & 3] += v.d[0]; return;
+#endif
+    mine[(SEQ & 3) * NP] = v.d[0];
+    set_m<SEQ & 3>(S::inertia(K));
+    if constexpr ((SEQ & 3) == 3) flush();
+  }
+  HAMK_DEV void finish() {                                 // M not a multiple of four: zero rows
+    if constexpr ((S::M & 3) != 0) {
+#pragma unroll
+      for (int r = (S::M & 3); r < 4; ++r) mine[r * NP] = 0.0;
+      if constexpr ((S::M & 3) <= 1) m1 = 0.0;
+      if constexpr ((S::M & 3) <= 2) m2 = 0.0;
+      m3 = 0.0;
+      flush();
+    }
+  }
+  HAMK_DEV void flush() {
+    lds_sync();
+    // inertia of the row this lane feeds (folds when all are equal).  All four are read
+    // unconditionally and blended as VALUES: a conditional read is turned into one read through a
+    // selected address before inlining, and that dynamic index then pins the whole sink in scratch.
+    const double a0 = m0, a1 = m1, a2 = m2, a3 = m3;
+    const double m01 = (kq & 1) ? a1 : a0, m23 = (kq & 1) ? a3 : a2;
+    const double m = (kq & 2) ? m23 : m01;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      double a[NB], am[NB];
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) { a[cb] = rd[g * PER + 16 * cb]; am[cb] = m * a[cb]; }
+#pragma unroll
+      for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+        for (int jb = ib; jb < NB; ++jb)
+          acc[g][blk_of(ib, jb)] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[ib], a[jb], acc[g][blk_of(ib, jb)], 0, 0, 0);
+    }
+    lds_sync();                                            // the next rows overwrite the staging area
+  }
+  // K of every trajectory of the wave into its tile (row-major, stride NP+1), both triangles
+  HAMK_DEV void store(double* smem, int offw, int lw) const {
+    double* direct = smem + offw + (lw >> 4) * (NP + 1) + (lw & 15);
+    double* transp = smem + offw + (lw & 15) * (NP + 1) + (lw >> 4);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+        for (int jb = ib; jb < NB; ++jb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double kv = acc[g][blk_of(ib, jb)][r];
+            direct[g * PER + (16 * ib + 4 * r) * (NP + 1) + 16 * jb] = kv;
+            if (ib != jb) transp[g * PER + (16 * jb) * (NP + 1) + 16 * ib + 4 * r] = kv;
+          }
+    }
   }
 };
 template <class S> struct SinkT {                  // sweep 2: dT/dq_i = -sum_k m_k x_k.dv x_k.dd
   double dT = 0.0;
-  template <int K> HAMK_DEV void put(const Jet2<1>& v) { dT = fma(-(S::inertia(K) * v.dv), v.dd[0], dT); }
+  template <int K, int SEQ> HAMK_DEV void put(const Jet2<1>& v) { dT = fma(-(S::inertia(K) * v.dv), v.dd[0], dT); }
 };
 template <class S> struct SinkP {                  // momenta: p_i = sum_k J[k][i] m_k (J qd)_k
   double p = 0.0;
-  template <int K> HAMK_DEV void put(const Jet2<1>& v) { p = fma(S::inertia(K) * v.dv, v.d[0], p); }
+  template <int K, int SEQ> HAMK_DEV void put(const Jet2<1>& v) { p = fma(S::inertia(K) * v.dv, v.d[0], p); }
 };
 
 // ---- per-group context -------------------------------------------------------------------------
@@ -142,6 +218,8 @@ template <class S> struct Ctx {
   static constexpr int N = S::N, M = S::M, NP = Geo<N>::NP;
   double* smem;      // the block's __shared__ array
   int off;           // this trajectory's offset into it (doubles)
+  int offw;          // offset of the wavefront's first trajectory
+  int lw;            // lane within the wavefront
   int li;            // lane within the group = AD direction
   HAMK_DEV double* tile() const { return smem + off; }                                   // [TILE] K, then L
   HAMK_DEV double* rowbuf() const { return smem + off + Lds<S>::TILE; }                  // [2*NP] J row buffer
@@ -152,7 +230,7 @@ template <class S> struct Ctx {
   }
   int g4;            // 4 * (first lane of the group within the wavefront)
   HAMK_DEV int grp4() const { return g4; }
-  HAMK_DEV Ctx launder() const { Ctx c = *this; asm volatile("" : "+v"(c.off), "+v"(c.li), "+v"(c.g4)); return c; }
+  HAMK_DEV Ctx launder() const { Ctx c = *this; asm volatile("" : "+v"(c.off), "+v"(c.li), "+v"(c.g4), "+v"(c.offw), "+v"(c.lw)); return c; }
 };
 
 // Fill the LDS-resident sincos pairs cooperatively when every site's operand is an input.
@@ -193,31 +271,21 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
   constexpr int TRIG1 = (S::TRIG_ALL_INPUTS && S::NTRIG_F > 0) ? TRIG_REUSE : TRIG_FULL;
   const int li = c.li;
   cooperative_trig<S>(c, qi);
-  double rot[NP / 2 + 1];
   {
     InJet1 qj{c.ga(), li};                                  // q lives in the gather buffer a
     SinkK<S, NP> sink;
-    sink.buf = c.rowbuf(); sink.li = li;
-#pragma unroll
-    for (int d = 0; d <= NP / 2; ++d) sink.rot[d] = 0.0;
+    lds_sync();                                             // readers of the tile (L of the last solve) are done:
+    sink.init(c.smem, c.off, c.offw, li, c.lw);             //   its first 4*NP doubles stage the rows of J
     TrigCache<S::NTRIG_U> tu;
     TrigLds tl = c.trig();
     const Jet1<1> u = S::template coords_sink_u<Jet1<1>, TRIG1>(qj, tl, tu, sink);
     gU = u.d[0]; U = u.v;
-#pragma unroll
-    for (int d = 0; d <= NP / 2; ++d) rot[d] = sink.rot[d];
-  }
-  // circulant -> full symmetric K in the tile, then each lane takes its row
-  lds_sync();                                             // previous readers of the tile (L of the last solve) are done
-#pragma unroll
-  for (int d = 0; d <= NP / 2; ++d) {
-    const int b = (li + d) & (NP - 1);
-    c.tile()[li * (NP + 1) + b] = rot[d];
-    c.tile()[b * (NP + 1) + li] = rot[d];
+    sink.finish();
+    sink.store(c.smem, c.offw, c.lw);                       // accumulators -> full symmetric K in the tiles
   }
   lds_sync();
 #pragma unroll
-  for (int b = 0; b < N; ++b) row[b] = c.tile()[li * (NP + 1) + b];
+  for (int b = 0; b < N; ++b) row[b] = c.tile()[li * (NP + 1) + b];   // each lane takes its row
   // LDL^T, right-looking
   bool ok = true;
   dinv = 0.0;
@@ -313,6 +381,8 @@ template <class S> struct Where {
     t = (tt < B) ? tt : B - 1;
     c.smem = smem;
     c.off = (wv * G + grp) * Lds<S>::PER_TRAJ;
+    c.offw = wv * G * Lds<S>::PER_TRAJ;
+    c.lw = lane;
     c.g4 = 4 * grp * NP;
   }
 };
