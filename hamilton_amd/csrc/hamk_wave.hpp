@@ -7,16 +7,14 @@
 // generated f/U code -- uniform control flow, the SIMT-friendly way to run forward mode --
 // at the one-direction jets Jet1<1> / Jet2<1>, with its own seed:
 //
-//   sweep 1  Jet1<1>, seed d = delta(i, lane): lane i gets column i of J (and dU/dq_i).  Each
-//            row J[k][.] passes through a 2 x NP-double LDS buffer the moment x_k is defined
-//            (coords_sink_u hands outputs to a sink) and is consumed at once:
-//   K        K = J^T M J accumulates inside the sink, one rank-1 update per x_k, in circulant
-//            form: lane i keeps K[i][(i+d) mod NP], d = 0..NP/2 -- every unordered pair once
-//            (half the 2 m n^2 flops of the dense contraction), rotated LDS reads are
-//            conflict-free.  No J tile, no second pass over it.
-//   solve    LDL^T across the group: pivot row broadcast with wavefront shuffles (width NP),
-//            rank-1 update of the row each lane keeps in registers; forward substitution by
-//            shuffles; back substitution reads L^T from a padded LDS tile (conflict-free).
+//   sweep 1  Jet1<1>, seed d = delta(i, lane): lane i gets column i of J (and dU/dq_i), one row
+//            J[k][.] at a time: coords_sink_u hands each output to a sink the moment it is defined;
+//   K        K = J^T M J on the f64 matrix cores: four rows are staged in LDS and consumed by
+//            v_mfma_f64_16x16x4_f64 (SinkK) -- one 8-byte LDS read per lane per 16-column block per
+//            four rows.  No J tile, no second pass over it.
+//   solve    LDL^T with rows distributed over lanes: per pivot, every lane drops its entry of the
+//            pivot column into an LDS buffer and reads what it needs back as broadcast loads; the
+//            forward substitution rides along; back substitution reads L^T from a padded LDS tile.
 //   sweep 2  Jet2<1> along the common runtime direction qd with own e_i: lane i accumulates
 //            dT/dq_i = -sum_k m_k (J qd)_k ((dJ/dq_i) qd)_k directly in the sink -- the m x n x n
 //            Hessian tensor of the reference (Hamilton.hs:222, 512 KiB per point at N = 32)
@@ -27,7 +25,7 @@
 //            instead of every lane recomputing all n of them.
 //
 // State stays SoA in HBM (q[j*B + t]); a group loads/stores one value per lane.  LDS per
-// trajectory: NP*(NP+1) (K, then L) + 4*NP + 2*NTRIG doubles (9.75 KiB at N = 32): two 256-thread
+// trajectory: NP*(NP+1) (row staging, then K, then L) + 4*NP + 2*NTRIG doubles (9.75 KiB at N = 32): two 256-thread
 // blocks per CU, i.e. two wavefronts per SIMD.
 #pragma once
 #include "hamk_device.hpp"
@@ -45,7 +43,7 @@ template <class S> struct Lds {
   static constexpr int NP = Geo<S::N>::NP;
   static constexpr int NT = (S::NTRIG_F > 0) ? S::NTRIG_F : 1;
   static constexpr int TILE = NP * (NP + 1);            // K (row-major, stride NP+1), then L
-  static constexpr int PER_TRAJ = TILE + 4 * NP + 2 * NT;   // + row buffer (row stored twice) + two all-gather buffers + sincos pairs
+  static constexpr int PER_TRAJ = TILE + 4 * NP + 2 * NT;   // + 2*NP scratch row (sincos exchange, pivot column + z) + two all-gather buffers + sincos pairs
 };
 
 // sincos pairs of the trajectory's current point, resident in LDS (same member syntax as
@@ -222,7 +220,7 @@ template <class S> struct Ctx {
   int lw;            // lane within the wavefront
   int li;            // lane within the group = AD direction
   HAMK_DEV double* tile() const { return smem + off; }                                   // [TILE] K, then L
-  HAMK_DEV double* rowbuf() const { return smem + off + Lds<S>::TILE; }                  // [2*NP] J row buffer
+  HAMK_DEV double* rowbuf() const { return smem + off + Lds<S>::TILE; }                  // [2*NP] exchange buffer
   HAMK_DEV double* ga() const { return smem + off + Lds<S>::TILE + 2 * NP; }             // [NP] q
   HAMK_DEV double* gb() const { return smem + off + Lds<S>::TILE + 3 * NP; }             // [NP] qd
   HAMK_DEV TrigLds trig() const {
@@ -286,28 +284,54 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
   lds_sync();
 #pragma unroll
   for (int b = 0; b < N; ++b) row[b] = c.tile()[li * (NP + 1) + b];   // each lane takes its row
-  // LDL^T, right-looking
+  // LDL^T, right-looking, TWO pivots per LDS round trip: the serial chain (write column, read it
+  // back, reciprocal, update) is what bounds this phase, not its flops.  With a = K[j][j],
+  // b = K[j+1][j], c = K[j+1][j+1] (all before pivot j), l = b/a:
+  //   d_j = a, d_j+1 = c - l b = det/a;   l_i,j = K[i][j]/a;   l_i,j+1 = (K[i][j+1] - l_i,j b)/d_j+1;
+  //   K[i][k] -= l_i,j K[k][j] + l_i,j+1 (K[k][j+1] - l K[k][j])  =  (l_i,j - l_i,j+1 l) K[k][j] + l_i,j+1 K[k][j+1]
+  // -- the same L and D as the scalar recurrence, the same number of FMAs, on the columns as they
+  // were before the pair; the two reciprocals (1/a, 1/det) are independent.
   bool ok = true;
   dinv = 0.0;
-  double* col = c.rowbuf();                                // [NP] column j, [NP] z (the row buffer is free here)
+  double* cA = c.rowbuf();                                 // [NP] column j   (the exchange buffer is free here,
+  double* cB = c.rowbuf() + NP;                            // [NP] column j+1   and so is the qd gather buffer)
+  double* cZ = c.gb();                                     // [NP] z
 #ifdef HAMK_PROBE_SKIP_FACTOR
   dinv = frcp(row[0] + 2.0);
   if (0)
 #endif
+  {
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    col[li] = row[j];
-    col[NP + li] = z;
-    lds_sync();
-    const double dj = col[j];
-    ok = ok && (dj > 0.0);
-    const double inv = frcp(dj);
-    const double lij = (li > j) ? row[j] * inv : 0.0;       // 0: lanes at or above the pivot do not update
-    if (li == j) dinv = inv;
-    z = fma(-lij, col[NP + j], z);                           // L z = rhs, one term per pivot
+    for (int j = 0; j + 1 < N; j += 2) {
+      cA[li] = row[j];
+      cB[li] = row[j + 1];
+      cZ[li] = z;
+      lds_sync();
+      const double a = cA[j], b = cA[j + 1], cc = cB[j + 1], zj = cZ[j], zj1 = cZ[j + 1];
+      const double det = fma(a, cc, -(b * b));
+      ok = ok && (a > 0.0) && (det > 0.0);                  // d_j > 0 and d_j+1 = det/a > 0
+      const double inv_a = frcp(a), inv_det = frcp(det);
+      const double inv_c = a * inv_det;                      // 1/d_j+1
+      const double l = b * inv_a;                            // L[j+1][j]
+      const double zj1p = fma(-l, zj, zj1);                  // z_j+1 once pivot j is applied
+      const double l0 = (li > j) ? row[j] * inv_a : 0.0;     // 0: lanes at or above the pivot do not update
+      const double l1 = (li > j + 1) ? fma(-l0, b, row[j + 1]) * inv_c : 0.0;
+      if (li == j) dinv = inv_a;
+      if (li == j + 1) dinv = inv_c;
+      z = fma(-l1, zj1p, fma(-l0, zj, z));                   // L z = rhs, two terms per pair
+      const double al = fma(-l1, l, l0);
 #pragma unroll
-    for (int k = j + 1; k < N; ++k) row[k] = fma(-lij, col[k], row[k]);   // (entries k > li are never read)
-    if (li > j) row[j] = lij;
+      for (int k = j + 2; k < N; ++k) row[k] = fma(-al, cA[k], fma(-l1, cB[k], row[k]));   // (entries k > li are never read)
+      if (li > j) row[j] = l0;
+      if (li > j + 1) row[j + 1] = l1;
+    }
+    if constexpr ((N & 1) != 0) {                            // last pivot of an odd N: nothing below it
+      cA[li] = row[N - 1];
+      lds_sync();
+      const double dj = cA[N - 1];
+      ok = ok && (dj > 0.0);
+      if (li == N - 1) dinv = frcp(dj);
+    }
   }
   if (!ok && li < N) st |= ST_SINGULAR;                    // no pivoting fallback in the wave kernels
   // L over K in the tile (stride NP+1: conflict-free for these row writes and for the column
@@ -319,18 +343,43 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
 }
 
 // Finish K v = rhs after `factor` (which left z = L^-1 rhs): D y = z, L^T v = y; returns v_li.
+// Four unknowns per LDS round trip: the lanes exchange their partial sums through a buffer and each
+// resolves the 4 x 4 triangle at the head of the block itself (six FMAs on broadcast reads of L).
 template <class S>
 HAMK_DEV double solve_back(const Ctx<S>& c, double dinv, double z) {
-  constexpr int N = S::N, NP = Ctx<S>::NP;
+  constexpr int N = S::N, NP = Ctx<S>::NP, R = N & 3, W = NP + 1;
   const int li = c.li;
 #ifdef HAMK_PROBE_SKIP_SOLVE
   return z * dinv;
 #endif
   double v = z * dinv;                                     // D y = z
+  double* cV = c.gb();
+  const double* T = c.tile();
 #pragma unroll
-  for (int k = N - 1; k >= 0; --k) {                       // L^T v = y
-    const double vk = bcast4(v, c.grp4(), k);
-    if (li < k) v = fma(-c.tile()[k * (NP + 1) + li], vk, v);
+  for (int k = N - 1; k >= N - R; --k) {                   // the top N mod 4 unknowns one at a time
+    cV[li] = v;
+    lds_sync();
+    const double vk = cV[k];
+    if (li < k) v = fma(-T[k * W + li], vk, v);
+  }
+#pragma unroll
+  for (int kb = N - R - 4; kb >= 0; kb -= 4) {
+    cV[li] = v;
+    lds_sync();
+    const double p0 = cV[kb], p1 = cV[kb + 1], p2 = cV[kb + 2], v3 = cV[kb + 3];
+    const double v2 = fma(-T[(kb + 3) * W + kb + 2], v3, p2);
+    const double v1 = fma(-T[(kb + 2) * W + kb + 1], v2, fma(-T[(kb + 3) * W + kb + 1], v3, p1));
+    const double v0 = fma(-T[(kb + 1) * W + kb], v1, fma(-T[(kb + 2) * W + kb], v2, fma(-T[(kb + 3) * W + kb], v3, p0)));
+    if (li < kb) {
+      v = fma(-T[(kb + 3) * W + li], v3, v);
+      v = fma(-T[(kb + 2) * W + li], v2, v);
+      v = fma(-T[(kb + 1) * W + li], v1, v);
+      v = fma(-T[kb * W + li], v0, v);
+    } else {
+      if (li == kb) v = v0;
+      if (li == kb + 1) v = v1;
+      if (li == kb + 2) v = v2;
+    }
   }
   return v;
 }
