@@ -60,6 +60,13 @@ SIGNATURES = {
     "hamk_last_error": (ctypes.c_char_p, []),
     "hamk_version": (ctypes.c_char_p, []),
     "hamk_device_count": (ctypes.c_int, []),
+    "hamk_set_device": (ctypes.c_int, [_i32]),
+    "hamk_get_device": (ctypes.c_int, [ctypes.POINTER(_i32)]),
+    "hamk_device_malloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _i64]),
+    "hamk_device_free": (ctypes.c_int, [ctypes.c_void_p]),
+    "hamk_memcpy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _i64, _i32]),
+    "hamk_gather_batch": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_void_p),
+                                         ctypes.c_void_p, _i32]),
 }
 
 _lib = None

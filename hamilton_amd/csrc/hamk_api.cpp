@@ -517,6 +517,86 @@ int hamk_device_count(void) {
   return n;
 }
 
+int hamk_set_device(int32_t device) {
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(HAMK_ERR_NODEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  return HAMK_OK;
+}
+
+int hamk_get_device(int32_t* device) {
+  if (!device) return fail(HAMK_ERR_INVALID, "null device");
+  int d = 0;
+  hipError_t e = hipGetDevice(&d);
+  if (e != hipSuccess) return fail(HAMK_ERR_NODEVICE, std::string("hipGetDevice: ") + hipGetErrorString(e));
+  *device = d;
+  return HAMK_OK;
+}
+
+int hamk_device_malloc(void** ptr, int64_t bytes) {
+  if (!ptr || bytes < 0) return fail(HAMK_ERR_INVALID, "hamk_device_malloc: null ptr / negative size");
+  *ptr = nullptr;
+  if (bytes == 0) return HAMK_OK;
+  HIP_TRY(hipMalloc(ptr, (size_t)bytes));
+  return HAMK_OK;
+}
+
+int hamk_device_free(void* ptr) {
+  if (ptr) HIP_TRY(hipFree(ptr));
+  return HAMK_OK;
+}
+
+int hamk_memcpy(void* dst, const void* src, int64_t bytes, int32_t kind) {
+  if (bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(HAMK_ERR_INVALID, "hamk_memcpy: null pointer / negative size");
+  if (bytes == 0) return HAMK_OK;
+  hipMemcpyKind k;
+  switch (kind) {
+    case HAMK_COPY_H2D: k = hipMemcpyHostToDevice; break;
+    case HAMK_COPY_D2H: k = hipMemcpyDeviceToHost; break;
+    case HAMK_COPY_D2D: k = hipMemcpyDefault; break;        // unified addressing: same device or a peer
+    default: return fail(HAMK_ERR_INVALID, "hamk_memcpy: kind must be HAMK_COPY_H2D / D2H / D2D");
+  }
+  HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, k));
+  return HAMK_OK;
+}
+
+int hamk_gather_batch(int32_t nparts, int32_t n, const int64_t* B_parts, const double* const* parts, double* out,
+                      int32_t out_mem) {
+  if (nparts < 0 || n <= 0 || (nparts > 0 && (!B_parts || !parts)))
+    return fail(HAMK_ERR_INVALID, "hamk_gather_batch: bad nparts / n / null arrays");
+  if (out_mem != HAMK_MEM_HOST && out_mem != HAMK_MEM_DEVICE) return fail(HAMK_ERR_INVALID, "out_mem must be HAMK_MEM_HOST or HAMK_MEM_DEVICE");
+  int64_t total = 0;
+  for (int g = 0; g < nparts; ++g) {
+    if (B_parts[g] < 0 || (B_parts[g] > 0 && !parts[g])) return fail(HAMK_ERR_INVALID, "hamk_gather_batch: negative size / null part");
+    total += B_parts[g];
+  }
+  if (total == 0) return HAMK_OK;
+  if (!out) return fail(HAMK_ERR_INVALID, "hamk_gather_batch: null out");
+  int here = 0;
+  HIP_TRY(hipGetDevice(&here));
+  int64_t at = 0;
+  for (int g = 0; g < nparts; ++g) {
+    const int64_t Bg = B_parts[g];
+    if (Bg == 0) continue;
+    if (out_mem == HAMK_MEM_DEVICE) {                       // direct xGMI DMA where the devices are peers
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, parts[g]) == hipSuccess && attr.device != here) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, here, attr.device) == hipSuccess && can) {
+          hipError_t e = hipDeviceEnablePeerAccess(attr.device, 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        }
+      }
+      (void)hipGetLastError();
+    }
+    // row j of the part goes to columns [at, at + Bg) of row j of the output
+    HIP_TRY(hipMemcpy2DAsync(out + at, (size_t)total * sizeof(double), parts[g], (size_t)Bg * sizeof(double),
+                             (size_t)Bg * sizeof(double), (size_t)n, hipMemcpyDefault, nullptr));
+    at += Bg;
+  }
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return HAMK_OK;
+}
+
 int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_op* f_ops, int32_t f_nops,
                        const int32_t* f_outs, const hamk_op* u_ops, int32_t u_nops, int32_t u_out, int32_t u_space,
                        hamk_system** out) {

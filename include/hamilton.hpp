@@ -101,7 +101,7 @@ inline double powi(double x, int k) {
   return r;
 }
 inline Var binary(int32_t op, const Var& a, const Var& b) {
-  double ca, cb;
+  double ca = 0.0, cb = 0.0;
   const bool ka = a.is_const(&ca), kb = b.is_const(&cb);
   if (ka && kb) {
     switch (op) {
@@ -358,6 +358,81 @@ inline Phase rk4Steps(double dt, int nsteps, System& s, const Phase& ph) {
   Phase out = ph;
   s.last_status.assign((size_t)ph.B, 0);
   check(hamk_rk4_steps(s.handle(), ph.B, out.positions.data(), out.momenta.data(), dt, nsteps, s.last_status.data(), HAMK_MEM_HOST));
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------
+// Ensembles resident in HBM (no reference counterpart: the reference holds one trajectory on the
+// Haskell heap).  DevicePhase owns SoA device arrays on the device that was current when it was
+// made; the steppers advance it in place, asynchronously on the System's stream.  One System per
+// device + hamk_set_device + gather() is the single-process form of the node-level sharding.
+// ---------------------------------------------------------------------------------------
+class DeviceArray {
+ public:
+  DeviceArray() = default;
+  explicit DeviceArray(int64_t bytes) : bytes_(bytes) { void* p = nullptr; check(hamk_device_malloc(&p, bytes)); p_ = p; }
+  DeviceArray(const DeviceArray&) = delete;
+  DeviceArray& operator=(const DeviceArray&) = delete;
+  DeviceArray(DeviceArray&& o) noexcept : p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; o.bytes_ = 0; }
+  DeviceArray& operator=(DeviceArray&& o) noexcept { if (this != &o) { release(); p_ = o.p_; bytes_ = o.bytes_; o.p_ = nullptr; o.bytes_ = 0; } return *this; }
+  ~DeviceArray() { release(); }
+  template <class T> T* as() const { return static_cast<T*>(p_); }
+  int64_t bytes() const { return bytes_; }
+  void upload(const void* host) { check(hamk_memcpy(p_, host, bytes_, HAMK_COPY_H2D)); }
+  void download(void* host) const { check(hamk_memcpy(host, p_, bytes_, HAMK_COPY_D2H)); }
+ private:
+  void release() { if (p_) hamk_device_free(p_); p_ = nullptr; }
+  void* p_ = nullptr;
+  int64_t bytes_ = 0;
+};
+
+struct DevicePhase {
+  int n = 0; int64_t B = 0;
+  DeviceArray positions, momenta, status;
+  DevicePhase() = default;
+  DevicePhase(int n_, int64_t B_) : n(n_), B(B_), positions(8 * (int64_t)n_ * B_), momenta(8 * (int64_t)n_ * B_), status(4 * B_) {}
+  explicit DevicePhase(const Phase& h) : DevicePhase(h.n, h.B) { positions.upload(h.positions.data()); momenta.upload(h.momenta.data()); }
+  Phase download() const {
+    Phase h; h.n = n; h.B = B; h.positions.resize((size_t)n * B); h.momenta.resize((size_t)n * B);
+    positions.download(h.positions.data()); momenta.download(h.momenta.data());
+    return h;
+  }
+  std::vector<int32_t> download_status() const { std::vector<int32_t> st((size_t)B); status.download(st.data()); return st; }
+};
+
+// toPhase on the device: q, qd uploaded, p computed there                              :279-284
+inline DevicePhase toPhaseDevice(const System& s, const Config& c) {
+  DevicePhase d(c.n, c.B);
+  DeviceArray qd(8 * (int64_t)c.n * c.B);
+  d.positions.upload(c.positions.data()); qd.upload(c.velocities.data());
+  check(hamk_to_phase_batch(s.handle(), c.B, d.positions.as<double>(), qd.as<double>(), d.momenta.as<double>(), HAMK_MEM_DEVICE));
+  check(hamk_synchronize(s.handle()));                      // qd is freed on return
+  return d;
+}
+inline void rk4Steps(double dt, int nsteps, System& s, DevicePhase& d) {      // in place, asynchronous
+  check(hamk_rk4_steps(s.handle(), d.B, d.positions.as<double>(), d.momenta.as<double>(), dt, nsteps, d.status.as<int32_t>(), HAMK_MEM_DEVICE));
+}
+inline void stepHam(double r, System& s, DevicePhase& d) {                     // :390-402, in place, asynchronous
+  check(hamk_step_ham_batch(s.handle(), d.B, d.positions.as<double>(), d.momenta.as<double>(), r, d.status.as<int32_t>(), nullptr, HAMK_MEM_DEVICE));
+}
+inline void synchronize(const System& s) { check(hamk_synchronize(s.handle())); }
+inline std::vector<double> hamiltonian(System& s, const DevicePhase& d) {      // :353-361
+  DeviceArray h(8 * d.B), st(4 * d.B);
+  check(hamk_observe_batch(s.handle(), d.B, d.positions.as<double>(), d.momenta.as<double>(), nullptr, nullptr, h.as<double>(), st.as<int32_t>(), HAMK_MEM_DEVICE));
+  check(hamk_synchronize(s.handle()));
+  std::vector<double> out((size_t)d.B); h.download(out.data());
+  return out;
+}
+// final gather of shards (possibly on several devices) into one host ensemble, part order
+inline Phase gather(const std::vector<const DevicePhase*>& parts) {
+  Phase out;
+  if (parts.empty()) return out;
+  out.n = parts[0]->n;
+  std::vector<int64_t> Bs; std::vector<const double*> qs, ps;
+  for (auto* d : parts) { Bs.push_back(d->B); qs.push_back(d->positions.as<double>()); ps.push_back(d->momenta.as<double>()); out.B += d->B; }
+  out.positions.resize((size_t)out.n * out.B); out.momenta.resize((size_t)out.n * out.B);
+  check(hamk_gather_batch((int32_t)parts.size(), out.n, Bs.data(), qs.data(), out.positions.data(), HAMK_MEM_HOST));
+  check(hamk_gather_batch((int32_t)parts.size(), out.n, Bs.data(), ps.data(), out.momenta.data(), HAMK_MEM_HOST));
   return out;
 }
 

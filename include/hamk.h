@@ -203,6 +203,28 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
                           double h0, double eps_abs, double eps_rel,
                           int32_t* status, int32_t* nsub, int32_t mem);
 
+/* ---- devices and device memory ---------------------------------------------
+ * For hosts that do not link HIP themselves (the Haskell shim, plain C): with these an ensemble
+ * can live in HBM across calls (HAMK_MEM_DEVICE) and one process can drive every GPU of a node --
+ * one handle per device, the calling thread's current device selects where a handle runs.  The
+ * reference has no counterpart (it is a single-trajectory CPU library); they exist because the
+ * north_star's "state resident in HBM" and "shard over 8 GPUs, gather at the end" must be reachable
+ * through the C ABI alone.                                                                      */
+int hamk_set_device(int32_t device);                 /* current device of the calling thread      */
+int hamk_get_device(int32_t* device);
+int hamk_device_malloc(void** ptr, int64_t bytes);   /* on the current device                     */
+int hamk_device_free(void* ptr);
+#define HAMK_COPY_H2D 0
+#define HAMK_COPY_D2H 1
+#define HAMK_COPY_D2D 2   /* same or another device (peer copy over xGMI)                        */
+int hamk_memcpy(void* dst, const void* src, int64_t bytes, int32_t kind);   /* synchronous        */
+/* Final gather of a sharded ensemble: part g is a structure-of-arrays block [n][B_parts[g]] in
+ * device memory (any device); out is [n][sum_g B_parts[g]], trajectories in part order -- in host
+ * memory (out_mem = HAMK_MEM_HOST) or on the current device (HAMK_MEM_DEVICE; peer copies over
+ * xGMI).  One array per call (q, then p).  Synchronous.                                         */
+int hamk_gather_batch(int32_t nparts, int32_t n, const int64_t* B_parts, const double* const* parts,
+                      double* out, int32_t out_mem);
+
 /* ---- diagnostics ---------------------------------------------------------- */
 const char* hamk_last_error(void);
 const char* hamk_version(void);

@@ -78,6 +78,28 @@ def test_calls_fail_loudly_without_a_gpu(hamk_lib):
         api.hamEqs(s, api.Phase(np.array([0.1]), np.array([0.2])))
 
 
+def test_device_memory_entry_points_without_a_gpu(hamk_lib):
+    """Device selection / memory / gather: argument checks work anywhere; without a GPU the calls that
+    need one return an error code and a message instead of crashing."""
+    from hamilton_amd import _abi
+    L = hamk_lib
+    assert L.hamk_memcpy(None, None, -1, 0) == _abi.HAMK_ERR_INVALID
+    assert L.hamk_memcpy(None, None, 0, 0) == _abi.HAMK_OK
+    buf = (ctypes.c_double * 4)()
+    assert L.hamk_memcpy(buf, buf, 32, 9) == _abi.HAMK_ERR_INVALID          # unknown kind
+    assert L.hamk_gather_batch(-1, 2, None, None, None, 0) == _abi.HAMK_ERR_INVALID
+    assert L.hamk_gather_batch(0, 2, None, None, None, 0) == _abi.HAMK_OK     # nothing to gather
+    assert L.hamk_gather_batch(0, 0, None, None, None, 0) == _abi.HAMK_ERR_INVALID
+    p = ctypes.c_void_p()
+    assert L.hamk_device_malloc(ctypes.byref(p), 0) == _abi.HAMK_OK and not p.value
+    assert L.hamk_device_free(None) == _abi.HAMK_OK
+    if L.hamk_device_count() == 0:
+        d = ctypes.c_int32(-7)
+        assert L.hamk_set_device(0) < 0 and L.hamk_last_error()
+        assert L.hamk_get_device(ctypes.byref(d)) < 0
+        assert L.hamk_device_malloc(ctypes.byref(p), 64) < 0 and not p.value
+
+
 def test_argument_checks(hamk_lib):
     from hamilton_amd import api
     s = api.system_from_spec(E.get("pendulum"))

@@ -290,6 +290,58 @@ def test_host_pointer_paths_equal_device_path(api, systems, B):
     torch.cuda.synchronize()
 
 
+def test_device_memory_and_gather_through_the_abi(api, systems, hamk_lib):
+    """A host without HIP or torch: hamk_device_malloc / hamk_memcpy keep the ensemble in HBM across
+    calls, hamk_gather_batch reassembles SoA shards (here three unequal ones on the one device) in
+    part order -- into host memory and into device memory."""
+    import ctypes
+    L = hamk_lib
+    spec, s, o = systems["spring"]
+    n = spec.n
+    sizes = [257, 1, 1000]
+    dev = ctypes.c_int32(-1)
+    assert L.hamk_get_device(ctypes.byref(dev)) == 0 and dev.value >= 0
+    assert L.hamk_set_device(dev.value) == 0
+    parts_q, parts_p, want_q, want_p, ptrs = [], [], [], [], []
+    start = 0
+    for Bg in sizes:
+        q, qd = E.sample_config(spec, start, Bg)
+        p = o.to_phase_batch(q, qd)
+        start += Bg
+        dq, dp, dst = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        for ptr, nbytes in ((dq, q.nbytes), (dp, p.nbytes), (dst, 4 * Bg)):
+            assert L.hamk_device_malloc(ctypes.byref(ptr), nbytes) == 0 and ptr.value
+            ptrs.append(ptr)
+        assert L.hamk_memcpy(dq, q.ctypes.data, q.nbytes, 0) == 0
+        assert L.hamk_memcpy(dp, p.ctypes.data, p.nbytes, 0) == 0
+        assert L.hamk_rk4_steps(s._h, Bg, dq, dp, ctypes.c_double(0.01), 5, dst, 1) == 0      # HAMK_MEM_DEVICE
+        ref = api.rk4Steps(0.01, 5, s, api.Phase(q, p))
+        want_q.append(ref.positions); want_p.append(ref.momenta)
+        parts_q.append(dq); parts_p.append(dp)
+    assert L.hamk_synchronize(s._h) == 0
+    total = sum(sizes)
+    Bs = (ctypes.c_int64 * 3)(*sizes)
+    for parts, want in ((parts_q, want_q), (parts_p, want_p)):
+        arr = (ctypes.c_void_p * 3)(*[p.value for p in parts])
+        out = np.empty((n, total))
+        assert L.hamk_gather_batch(3, n, Bs, arr, out.ctypes.data, 0) == 0                       # to host
+        np.testing.assert_array_equal(out, np.concatenate(want, axis=1))
+        dout = ctypes.c_void_p()
+        assert L.hamk_device_malloc(ctypes.byref(dout), out.nbytes) == 0
+        assert L.hamk_gather_batch(3, n, Bs, arr, dout, 1) == 0                                  # to the current device
+        back = np.empty_like(out)
+        assert L.hamk_memcpy(back.ctypes.data, dout, out.nbytes, 1) == 0
+        np.testing.assert_array_equal(back, out)
+        d2 = ctypes.c_void_p()
+        assert L.hamk_device_malloc(ctypes.byref(d2), out.nbytes) == 0
+        assert L.hamk_memcpy(d2, dout, out.nbytes, 2) == 0                                       # D2D
+        assert L.hamk_memcpy(back.ctypes.data, d2, out.nbytes, 1) == 0
+        np.testing.assert_array_equal(back, out)
+        ptrs += [dout, d2]
+    for ptr in ptrs:
+        assert L.hamk_device_free(ptr) == 0
+
+
 # ---------------------------------------------------------------- BASELINE.json full size: properties
 def test_full_size_properties(api, systems):
     """Config 2 at full size (1,048,576 double-pendulum trajectories): size-independent properties.
