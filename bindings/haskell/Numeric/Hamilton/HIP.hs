@@ -35,6 +35,15 @@ module Numeric.Hamilton.HIP
   , stepHamBatch
   , rk4StepsBatch
   , evolveHamEnsemble
+    -- * ensembles resident in HBM, several GPUs from one process
+  , DeviceEnsemble
+  , setDevice
+  , uploadEnsemble
+  , downloadEnsemble
+  , rk4StepsDevice
+  , stepHamDevice
+  , synchronize
+  , gatherEnsembles
   , UntraceableFunction (..)
   ) where
 
@@ -91,9 +100,22 @@ foreign import ccall safe "hamk_evolve_ham_batch"
                -> Double -> Double -> Double -> Ptr Int32 -> Ptr Int32 -> Int32 -> IO CInt
 foreign import ccall unsafe "hamk_last_error"
   c_last_error :: IO CString
+foreign import ccall safe "hamk_synchronize"
+  c_synchronize :: Ptr HamkSystem -> IO CInt
+foreign import ccall unsafe "hamk_set_device"
+  c_set_device :: Int32 -> IO CInt
+foreign import ccall unsafe "hamk_device_malloc"
+  c_device_malloc :: Ptr (Ptr Double) -> Int64 -> IO CInt
+foreign import ccall "&hamk_device_free"
+  p_device_free :: FunPtr (Ptr Double -> IO ())
+foreign import ccall safe "hamk_memcpy"
+  c_memcpy :: Ptr Double -> Ptr Double -> Int64 -> Int32 -> IO CInt
+foreign import ccall safe "hamk_gather_batch"
+  c_gather :: Int32 -> Int32 -> Ptr Int64 -> Ptr (Ptr Double) -> Ptr Double -> Int32 -> IO CInt
 
-memHost :: Int32
+memHost, memDevice :: Int32
 memHost = 0
+memDevice = 1
 
 check :: String -> CInt -> IO ()
 check what rc = when (rc /= 0) $ do
@@ -299,3 +321,71 @@ evolveHamEnsemble (HipSystem h) e ts
         c_evolve_ham s b pq pp (fromIntegral nt) pts a c 0 0 0 nullPtr nullPtr memHost >>= check "evolveHam"
       qf <- VS.unsafeFreeze qo; pf <- VS.unsafeFreeze po
       return [Ensemble (ensSize e) (VS.slice (r * cnt) cnt qf) (VS.slice (r * cnt) cnt pf) | r <- [0 .. nt - 1]]
+
+-- ---------------------------------------------------------------------------
+-- ensembles resident in HBM (HAMK_MEM_DEVICE) and node-level sharding
+-- ---------------------------------------------------------------------------
+-- | An ensemble whose arrays live in device memory of the device that was current
+--   ('setDevice') when it was uploaded; freed by the garbage collector through
+--   @hamk_device_free@.  Steppers advance it in place and return at once: the launch is
+--   asynchronous on the system's stream ('synchronize' waits).
+data DeviceEnsemble (n :: Nat) = DeviceEnsemble
+  { devSize :: !Int
+  , devPositions :: !(ForeignPtr Double)
+  , devMomenta :: !(ForeignPtr Double)
+  }
+
+-- | Select the GPU the calling thread's next calls run on (one 'HipSystem' per device).
+setDevice :: Int -> IO ()
+setDevice d = c_set_device (fromIntegral d) >>= check "setDevice"
+
+deviceArray :: Int -> IO (ForeignPtr Double)
+deviceArray count = alloca $ \pp -> do
+  c_device_malloc pp (fromIntegral (8 * count)) >>= check "deviceMalloc"
+  peek pp >>= newForeignPtr p_device_free
+
+uploadEnsemble :: forall n. KnownNat n => Ensemble n -> IO (DeviceEnsemble n)
+uploadEnsemble e = do
+  let cnt = VS.length (ensPositions e)
+  dq <- deviceArray cnt; dp <- deviceArray cnt
+  withEns e $ \_ pq pp -> withForeignPtr dq $ \a -> withForeignPtr dp $ \b -> do
+    c_memcpy a pq (fromIntegral (8 * cnt)) 0 >>= check "upload"     -- HAMK_COPY_H2D
+    c_memcpy b pp (fromIntegral (8 * cnt)) 0 >>= check "upload"
+  return (DeviceEnsemble (ensSize e) dq dp)
+
+downloadEnsemble :: forall n. KnownNat n => DeviceEnsemble n -> IO (Ensemble n)
+downloadEnsemble (DeviceEnsemble b dq dp) = do
+  let cnt = b * fromIntegral (natVal (Proxy @n))
+  q <- newOut cnt; p <- newOut cnt
+  VSM.unsafeWith q $ \pq -> VSM.unsafeWith p $ \pp -> withForeignPtr dq $ \a -> withForeignPtr dp $ \c -> do
+    c_memcpy pq a (fromIntegral (8 * cnt)) 1 >>= check "download"   -- HAMK_COPY_D2H
+    c_memcpy pp c (fromIntegral (8 * cnt)) 1 >>= check "download"
+  Ensemble b <$> VS.unsafeFreeze q <*> VS.unsafeFreeze p
+
+-- | k classic RK4 steps, in place in HBM (the BASELINE.json hot loop).
+rk4StepsDevice :: forall m n. KnownNat n => Double -> Int -> HipSystem m n -> DeviceEnsemble n -> IO ()
+rk4StepsDevice dt k (HipSystem h) (DeviceEnsemble b dq dp) =
+  withForeignPtr h $ \s -> withForeignPtr dq $ \pq -> withForeignPtr dp $ \pp ->
+    c_rk4_steps s (fromIntegral b) pq pp dt (fromIntegral k) nullPtr memDevice >>= check "rk4Steps"
+
+-- | 'stepHam' (Hamilton.hs:390-402) for every member, in place in HBM.
+stepHamDevice :: forall m n. KnownNat n => Double -> HipSystem m n -> DeviceEnsemble n -> IO ()
+stepHamDevice r (HipSystem h) (DeviceEnsemble b dq dp) =
+  withForeignPtr h $ \s -> withForeignPtr dq $ \pq -> withForeignPtr dp $ \pp ->
+    c_step_ham s (fromIntegral b) pq pp r nullPtr nullPtr memDevice >>= check "stepHam"
+
+synchronize :: HipSystem m n -> IO ()
+synchronize (HipSystem h) = withForeignPtr h $ \s -> c_synchronize s >>= check "synchronize"
+
+-- | Final gather of the shards of one ensemble (each possibly on another GPU) into one host
+--   ensemble, trajectories in shard order.  The only inter-device traffic of the path.
+gatherEnsembles :: forall n. KnownNat n => [DeviceEnsemble n] -> IO (Ensemble n)
+gatherEnsembles parts = do
+  let n = fromIntegral (natVal (Proxy @n)) :: Int
+      total = sum (map devSize parts)
+      one sel out = withMany withForeignPtr (map sel parts) $ \ptrs ->
+        withArrayLen (map (fromIntegral . devSize) parts) $ \g bs -> withArray ptrs $ \pa ->
+          VSM.unsafeWith out $ \po -> c_gather (fromIntegral g) (fromIntegral n) bs pa po memHost >>= check "gather"
+  q <- newOut (n * total); p <- newOut (n * total)
+  one devPositions q; one devMomenta p
+  Ensemble total <$> VS.unsafeFreeze q <*> VS.unsafeFreeze p
