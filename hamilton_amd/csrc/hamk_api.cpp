@@ -66,7 +66,10 @@ struct hamk_system {
   std::vector<size_t> stage_cap;
   // pinned, device-mapped arena for SMALL host-pointer calls (the reference's one-trajectory
   // stepHam per frame): the kernel reads and writes host memory directly over PCIe -- a launch
-  // and a stream synchronisation per call, no hipMemcpy at all
+  // and a stream synchronisation per call, no hipMemcpy at all.  The block must be COHERENT
+  // (fine-grained, uncached on the device): it is rewritten by the CPU before every call, and with
+  // the default (hipHostMallocMapped alone = non-coherent) the device's L2 served the previous
+  // call's lines -- stale inputs, seen as run-to-run differences on small ensembles.
   char* pin = nullptr;          // host address
   char* pin_dev = nullptr;      // the same block as the device sees it
   bool pin_failed = false;
@@ -233,7 +236,10 @@ static int compile_module(hamk_system* s);
 // module is rebuilt once with the stage-loop bodies; if that does not help, the system is refused.
 // HAMK_SELFCHECK=0 skips it.
 // ---------------------------------------------------------------------------
+static const double kRefEpsilon = 1.49012e-08;   // Hamilton.hs:448
+static thread_local std::string g_selfcheck_detail;
 static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
+  g_selfcheck_detail.clear();
   const int n = s->desc.n;
   const int64_t B = 64;
   const size_t cnt = (size_t)n * B;
@@ -335,6 +341,75 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
     }
   }
   if (!usable || flagged) { *rk4_ok = true; *rkf_ok = true; }
+  // ---- adaptive stepper end to end ---------------------------------------------------------------
+  // stepHam(T) with the reference's tolerances and step-size control on 256 trajectories, TWICE:
+  // the two runs must agree bit for bit (lanes are independent: a difference is a broken kernel, and
+  // exactly that was seen once -- an unrolled RKF45 body whose results changed from run to run),
+  // and both must agree with 64 fixed RK4 steps of T/64 (the kernel checked above) to well within
+  // what the controller's tolerance allows.
+  if (rc == HAMK_OK && *rk4_ok && *rkf_ok) {
+    const int64_t B3 = 256;
+    const size_t c3 = (size_t)n * B3;
+    const double T = 0.02;
+    std::vector<double> q3(c3), p3(c3), ref3(2 * c3), run[2] = {std::vector<double>(2 * c3), std::vector<double>(2 * c3)};
+    std::vector<int32_t> st_ref((size_t)B3), st_run[2] = {std::vector<int32_t>((size_t)B3), std::vector<int32_t>((size_t)B3)},
+        ns_run[2] = {std::vector<int32_t>((size_t)B3), std::vector<int32_t>((size_t)B3)};
+    for (int j = 0; j < n; ++j)
+      for (int64_t i = 0; i < B3; ++i) {
+        q3[(size_t)j * B3 + i] = 0.31 + 0.07 * j + 0.004 * (double)i;
+        p3[(size_t)j * B3 + i] = 0.23 - 0.05 * j + 0.003 * (double)i;
+      }
+    double *e_q = nullptr, *e_p = nullptr; int32_t *e_st = nullptr, *e_ns = nullptr;
+    bool alloc_ok = hipMalloc((void**)&e_q, c3 * 8) == hipSuccess && hipMalloc((void**)&e_p, c3 * 8) == hipSuccess &&
+                    hipMalloc((void**)&e_st, B3 * 4) == hipSuccess && hipMalloc((void**)&e_ns, B3 * 4) == hipSuccess;
+    long long b3 = B3;
+    auto upload = [&]() { hipMemcpy(e_q, q3.data(), c3 * 8, hipMemcpyHostToDevice); hipMemcpy(e_p, p3.data(), c3 * 8, hipMemcpyHostToDevice); };
+    auto download = [&](std::vector<double>& y) { hipMemcpy(y.data(), e_q, c3 * 8, hipMemcpyDeviceToHost); hipMemcpy(y.data() + c3, e_p, c3 * 8, hipMemcpyDeviceToHost); };
+    if (alloc_ok) {
+      upload();
+      double ddt = T / 64; int ns = 64;
+      void* a4[] = {&e_q, &e_p, &b3, &ddt, &ns, &e_st};
+      rc = launch(s, K_RK4, B3, a4);
+      if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RK4 kernel failed");
+      download(ref3);
+      hipMemcpy(st_ref.data(), e_st, B3 * 4, hipMemcpyDeviceToHost);
+      for (int r = 0; r < 2 && rc == HAMK_OK; ++r) {
+        upload();
+        double h0 = T / 100, ea = kRefEpsilon, er = kRefEpsilon, t0 = 0.0, t1 = T;
+        int nt = 2, row0 = 1, inplace = 1, max_sub = 4096;
+        const double *cq = e_q, *cp = e_p, *cts = nullptr;
+        void* a5[] = {&cq, &cp, &e_q, &e_p, &b3, &nt, &cts, &t0, &t1, &h0, &ea, &er, &row0, &inplace, &max_sub, &e_st, &e_ns};
+        rc = launch(s, K_RKF45, B3, a5);
+        if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RKF45 kernel failed");
+        download(run[r]);
+        hipMemcpy(st_run[r].data(), e_st, B3 * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(ns_run[r].data(), e_ns, B3 * 4, hipMemcpyDeviceToHost);
+      }
+      if (rc == HAMK_OK) {
+        bool same = std::memcmp(run[0].data(), run[1].data(), 2 * c3 * 8) == 0 && ns_run[0] == ns_run[1] && st_run[0] == st_run[1];
+        double worst = 0.0;
+        for (int64_t i = 0; i < B3; ++i) {
+          if (st_ref[(size_t)i] != 0 || st_run[0][(size_t)i] != 0) continue;       // outside the system's domain: cannot judge
+          if (ns_run[0][(size_t)i] > 16) continue;       // a hard stretch: 64 RK4 steps are no yardstick there
+          for (int j = 0; j < 2 * n; ++j) {
+            const double a = run[0][(size_t)j * B3 + i], f = ref3[(size_t)j * B3 + i];
+            const double e = std::fabs(a - f) / std::fmax(1.0, std::fabs(f));
+            if (!(e <= worst)) worst = e;
+          }
+        }
+        if (!same || !(worst <= 1e-4)) {
+          *rkf_ok = false;
+          char msg[160];
+          std::snprintf(msg, sizeof msg, "adaptive end-to-end check: two runs %s, worst deviation from 64 RK4 steps %.3g",
+                        same ? "agree" : "DIFFER", worst);
+          g_selfcheck_detail = msg;
+          if (std::getenv("HAMK_SELFCHECK_VERBOSE")) std::fprintf(stderr, "hamk self-check: %s\n", msg);
+        }
+      }
+    }
+    hipFree(e_q); hipFree(e_p); hipFree(e_st); hipFree(e_ns);
+    (void)hipGetLastError();
+  }
   if (const char* e = std::getenv("HAMK_SELFCHECK_FAULT")) {        // test hook: pretend the unrolled body is wrong
     if (std::strstr(e, "rk4") && !s->desc.rk4_stage_loop) *rk4_ok = false;
     if (std::strstr(e, "rkf") && !s->desc.rkf_stage_loop) *rkf_ok = false;
@@ -354,7 +429,8 @@ static int self_check(hamk_system* s) {
     const bool can_retry = attempt == 0 && !s->desc.wave && ((!rk4_ok && !s->desc.rk4_stage_loop) || (!rkf_ok && !s->desc.rkf_stage_loop));
     if (!can_retry)
       return fail(HAMK_ERR_COMPILE, std::string("self-check failed: the fused ") + (!rk4_ok ? "RK4" : "RKF45") +
-                                        " kernel disagrees with the hamEqs kernel (miscompiled module?)");
+                                        " kernel disagrees with the hamEqs kernel (miscompiled module?)" +
+                                        (g_selfcheck_detail.empty() ? "" : " [" + g_selfcheck_detail + "]"));
     if (!rk4_ok) s->desc.rk4_stage_loop = true;            // rebuild with the stage-loop bodies
     if (!rkf_ok) s->desc.rkf_stage_loop = true;
     s->source = generate_source(s->desc);
@@ -471,7 +547,8 @@ class Stager {
     if (!s_->pin) {
       static const bool off = [] { const char* e = std::getenv("HAMK_PINNED"); return e && e[0] == '0'; }();
       void* h = nullptr; void* d = nullptr;
-      if (off || hipHostMalloc(&h, kPinArena, hipHostMallocMapped) != hipSuccess ||
+      static const bool noncoh = [] { const char* e = std::getenv("HAMK_PINNED"); return e && e[0] == 'n'; }();   // test hook: the broken variant
+      if (off || hipHostMalloc(&h, kPinArena, hipHostMallocMapped | (noncoh ? 0u : hipHostMallocCoherent)) != hipSuccess ||
           hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
         if (h) hipHostFree(h);
         (void)hipGetLastError();
@@ -838,7 +915,16 @@ static int upload_times(hamk_system* s, int32_t nt, const double* ts) {
 }
 
 static const double kRefEps = 1.49012e-08;   // Hamilton.hs:448
-static const int kMaxSub = 1 << 24;
+// sub-step budget per call and trajectory (HAMK_ST_MAXSTEPS when exhausted); HAMK_MAX_SUBSTEPS lowers it
+// (test suites: a kernel gone wrong must end, not spin through 16M attempts per lane)
+static int max_substeps() {
+  static const int v = [] {
+    const char* e = std::getenv("HAMK_MAX_SUBSTEPS");
+    const long k = e ? std::atol(e) : 0;
+    return (k > 0 && k < (1L << 24)) ? (int)k : (1 << 24);
+  }();
+  return v;
+}
 
 int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const double* p0, int32_t nt, const double* ts,
                           double* qout, double* pout, double h0, double eps_abs, double eps_rel, int32_t* status,
@@ -869,7 +955,7 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
   TRY(st.out(status, (size_t)B, &dst));
   TRY(st.out(nsub, (size_t)B, &dns));
   long long b = B;
-  int nt_ = nt, row0 = 0, inplace = 0, max_sub = kMaxSub;
+  int nt_ = nt, row0 = 0, inplace = 0, max_sub = max_substeps();
   void* args[] = {&xq, &xp, &xqo, &xpo, &b, &nt_, &dts, &ts0, &ts1, &h0, &eps_abs, &eps_rel, &row0, &inplace, &max_sub, &dst, &dns};
   TRY(launch(s, K_RKF45, B, args));
   return st.finish();
@@ -891,7 +977,7 @@ int hamk_step_ham_batch(hamk_system* s, int64_t B, double* q, double* p, double 
   TRY(st.out(status, (size_t)B, &dst));
   TRY(st.out(nsub, (size_t)B, &dns));
   long long b = B;
-  int nt_ = 2, row0 = 1, inplace = 1, max_sub = kMaxSub;
+  int nt_ = 2, row0 = 1, inplace = 1, max_sub = max_substeps();
   const double* dts = nullptr;
   const double *cq = xq, *cp = xp;
   void* args[] = {&cq, &cp, &xq, &xp, &b, &nt_, &dts, &ts0, &ts1, &h0, &eps_abs, &eps_rel, &row0, &inplace, &max_sub, &dst, &dns};

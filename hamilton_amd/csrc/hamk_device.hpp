@@ -1033,6 +1033,26 @@ HAMK_DEV void observe_config_body(const double* __restrict__ q, const double* __
 // qout/pout: [nt][N][B], row 0 = initial state.  nt == 2 and qout == q0 gives
 // stepHam in place (rows are written only for r >= row0).
 // ---------------------------------------------------------------------------
+// 0.9 * r^(-1/ORD) for the step-size controller (cstd.c: r = max |yerr/D|, ORD = 5 on a rejection,
+// 6 on growth), without the general pow (~200 instructions, twice under divergence): a single-
+// precision seed exp2(-log2 r / ORD) from the hardware transcendental units and two Newton steps on
+// y^-ORD = r in fp64 (relative error 2e-7 -> 1e-13 -> rounding).  r is clamped to [2^-100, 2^100]
+// first: outside, the controller's own clamps (factor <= 5, >= 0.2) decide the result anyway.
+template <int ORD> HAMK_DEV double rpow_inv(double r) {
+#ifdef HAMK_PROBE_LIBM_POW
+  return 1.0 / ::pow(r, 1.0 / (double)ORD);
+#endif
+  r = (r < 0x1p-100) ? 0x1p-100 : ((r > 0x1p100) ? 0x1p100 : r);
+  double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)r) * (-1.0f / (float)ORD));
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double y2 = y * y, y4 = y2 * y2;
+    const double yo = (ORD == 5) ? y4 * y : y4 * y2;       // y^ORD
+    y = fma(y * (1.0 / (double)ORD), fma(-r, yo, 1.0), y);
+  }
+  return y;
+}
+
 template <class S>
 HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt, const double* __restrict__ ts, double ts0, double ts1, double h0,
                          double eps_abs, double eps_rel, int row0, int inplace, int max_sub,
@@ -1185,12 +1205,12 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
       const double h_old = hh;
       bool reject = false;
       if (rmax > 1.1) {
-        double rr = 0.9 / ::pow(rmax, 1.0 / 5.0);
+        double rr = 0.9 * rpow_inv<5>(rmax);
         if (rr < 0.2) rr = 0.2;
         const double hdec = rr * h_old;
         if (fabs(hdec) < fabs(h_old) && (tnew + hdec) != tnew) { reject = true; hh = hdec; }
       } else if (rmax < 0.5) {
-        double rr = 0.9 / ::pow(rmax, 1.0 / 6.0);
+        double rr = 0.9 * rpow_inv<6>(rmax);
         if (rr > 5.0) rr = 5.0;
         if (rr < 1.0) rr = 1.0;
         hh = rr * h_old;

@@ -687,12 +687,12 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
       const double h_old = hh;
       bool reject = false;
       if (rmax > 1.1) {
-        double rr = 0.9 / ::pow(rmax, 1.0 / 5.0);
+        double rr = 0.9 * rpow_inv<5>(rmax);
         if (rr < 0.2) rr = 0.2;
         const double hdec = rr * h_old;
         if (fabs(hdec) < fabs(h_old) && (tnew + hdec) != tnew) { reject = true; hh = hdec; }
       } else if (rmax < 0.5) {
-        double rr = 0.9 / ::pow(rmax, 1.0 / 6.0);
+        double rr = 0.9 * rpow_inv<6>(rmax);
         if (rr > 5.0) rr = 5.0;
         if (rr < 1.0) rr = 1.0;
         hh = rr * h_old;

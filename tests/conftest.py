@@ -9,6 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# a kernel gone wrong must end: cap the adaptive stepper's sub-step budget for the whole suite
+# (the default, 2^24 attempts per trajectory and call, can keep a GPU busy for minutes)
+os.environ.setdefault("HAMK_MAX_SUBSTEPS", "20000")
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 REFERENCE_SYSTEMS = ["pendulum", "doublePendulum", "room", "twoBody", "spring", "bezier"]
 ALL_GOLDEN_SYSTEMS = REFERENCE_SYSTEMS + ["threeBodyPolar", "chain4", "opcodeZoo"]

@@ -290,6 +290,29 @@ def test_host_pointer_paths_equal_device_path(api, systems, B):
     torch.cuda.synchronize()
 
 
+def test_small_host_calls_see_fresh_inputs(api, systems):
+    """The pinned arena of small host-pointer calls is rewritten by the CPU before every call: the
+    device must never serve a previous call's bytes from its caches.  Alternate different inputs
+    through one handle, many times, every entry point that reuses the same arena offsets."""
+    spec, s, o = systems["doublePendulum"]
+    B = 130
+    ins = []
+    for k in range(4):
+        q, qd = E.sample_config(spec, 1000 * k, B)
+        p = o.to_phase_batch(q, qd)
+        oq, op, ons = o.step_ham_batch(q, p, 0.02)
+        rq, rp = o.rk4_steps_batch(q, p, 0.01, 3)
+        ins.append((q, p, oq, op, ons, rq, rp))
+    for it in range(40):
+        q, p, oq, op, ons, rq, rp = ins[(it * 7 + it // 3) % 4]
+        st = api.stepHam(0.02, s, api.Phase(q, p))
+        same = np.asarray(s.last_nsub) == ons
+        assert same.mean() > 0.95, (it, float(same.mean()))
+        assert relerr(st.positions[:, same], oq[:, same]) < 1e-9 and relerr(st.momenta[:, same], op[:, same]) < 1e-9, it
+        r4 = api.rk4Steps(0.01, 3, s, api.Phase(q, p))
+        assert relerr(r4.positions, rq) < 1e-11 and relerr(r4.momenta, rp) < 1e-11, it
+
+
 def test_device_memory_and_gather_through_the_abi(api, systems, hamk_lib):
     """A host without HIP or torch: hamk_device_malloc / hamk_memcpy keep the ensemble in HBM across
     calls, hamk_gather_batch reassembles SoA shards (here three unequal ones on the one device) in
