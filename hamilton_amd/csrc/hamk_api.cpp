@@ -66,10 +66,10 @@ struct hamk_system {
   std::vector<size_t> stage_cap;
   // pinned, device-mapped arena for SMALL host-pointer calls (the reference's one-trajectory
   // stepHam per frame): the kernel reads and writes host memory directly over PCIe -- a launch
-  // and a stream synchronisation per call, no hipMemcpy at all.  The block must be COHERENT
-  // (fine-grained, uncached on the device): it is rewritten by the CPU before every call, and with
-  // the default (hipHostMallocMapped alone = non-coherent) the device's L2 served the previous
-  // call's lines -- stale inputs, seen as run-to-run differences on small ensembles.
+  // and a stream synchronisation per call, no hipMemcpy at all.  The block is allocated COHERENT
+  // (fine-grained, uncached on the device): the CPU rewrites it before every call, and
+  // hipHostMallocMapped alone gives non-coherent memory whose lines the device may keep in L2
+  // across launches.
   char* pin = nullptr;          // host address
   char* pin_dev = nullptr;      // the same block as the device sees it
   bool pin_failed = false;

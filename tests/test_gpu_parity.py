@@ -291,9 +291,9 @@ def test_host_pointer_paths_equal_device_path(api, systems, B):
 
 
 def test_small_host_calls_see_fresh_inputs(api, systems):
-    """The pinned arena of small host-pointer calls is rewritten by the CPU before every call: the
-    device must never serve a previous call's bytes from its caches.  Alternate different inputs
-    through one handle, many times, every entry point that reuses the same arena offsets."""
+    """The pinned arena of small host-pointer calls is rewritten by the CPU before every call and
+    reused at the same offsets by every entry point: alternate different inputs through one handle,
+    many times, and check every result (a previous call's bytes must never be served again)."""
     spec, s, o = systems["doublePendulum"]
     B = 130
     ins = []
