@@ -347,7 +347,7 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
   // exactly that was seen once -- an unrolled RKF45 body whose results changed from run to run),
   // and both must agree with 64 fixed RK4 steps of T/64 (the kernel checked above) to well within
   // what the controller's tolerance allows.
-  if (rc == HAMK_OK && *rk4_ok && *rkf_ok) {
+  if (rc == HAMK_OK && *rk4_ok && *rkf_ok && usable && !flagged) {
     const int64_t B3 = 256;
     const size_t c3 = (size_t)n * B3;
     const double T = 0.02;
@@ -366,13 +366,20 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
     auto upload = [&]() { hipMemcpy(e_q, q3.data(), c3 * 8, hipMemcpyHostToDevice); hipMemcpy(e_p, p3.data(), c3 * 8, hipMemcpyHostToDevice); };
     auto download = [&](std::vector<double>& y) { hipMemcpy(y.data(), e_q, c3 * 8, hipMemcpyDeviceToHost); hipMemcpy(y.data() + c3, e_p, c3 * 8, hipMemcpyDeviceToHost); };
     if (alloc_ok) {
-      upload();
-      double ddt = T / 64; int ns = 64;
-      void* a4[] = {&e_q, &e_p, &b3, &ddt, &ns, &e_st};
-      rc = launch(s, K_RK4, B3, a4);
-      if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RK4 kernel failed");
-      download(ref3);
+      std::vector<double> ref3b(2 * c3);
+      for (int r = 0; r < 2 && rc == HAMK_OK; ++r) {         // the fixed-step kernel, twice as well
+        upload();
+        double ddt = T / 64; int ns = 64;
+        void* a4[] = {&e_q, &e_p, &b3, &ddt, &ns, &e_st};
+        rc = launch(s, K_RK4, B3, a4);
+        if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RK4 kernel failed");
+        download(r == 0 ? ref3 : ref3b);
+      }
       hipMemcpy(st_ref.data(), e_st, B3 * 4, hipMemcpyDeviceToHost);
+      if (rc == HAMK_OK && std::memcmp(ref3.data(), ref3b.data(), 2 * c3 * 8) != 0) {
+        *rk4_ok = false;
+        g_selfcheck_detail = "two runs of the RK4 kernel on the same input DIFFER";
+      }
       for (int r = 0; r < 2 && rc == HAMK_OK; ++r) {
         upload();
         double h0 = T / 100, ea = kRefEpsilon, er = kRefEpsilon, t0 = 0.0, t1 = T;
