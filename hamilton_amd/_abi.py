@@ -46,6 +46,7 @@ SIGNATURES = {
     "hamk_synchronize": (ctypes.c_int, [_h]),
     "hamk_system_source": (ctypes.c_char_p, [_h]),
     "hamk_system_code_size": (_i64, [_h]),
+    "hamk_system_build_info": (ctypes.c_char_p, [_h]),
     "hamk_system_kernel_bytes": (_i64, [_h, ctypes.c_char_p]),
     "hamk_coords_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _i32]),
     "hamk_to_phase_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _dp, _i32]),

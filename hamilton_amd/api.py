@@ -174,6 +174,10 @@ class System:
         return _abi.lib().hamk_system_source(self._h).decode()
 
     @property
+    def build_info(self) -> str:
+        return _abi.lib().hamk_system_build_info(self._h).decode()
+
+    @property
     def code_size(self) -> int:
         return int(_abi.lib().hamk_system_code_size(self._h))
 

@@ -52,11 +52,15 @@ static const char* kKernelNames[K__COUNT] = {"hamk_rk4_steps_k", "hamk_hameqs_k"
 struct hamk_system {
   SystemDesc desc;
   std::string source;
-  std::vector<char> code;      // gfx950 code object
+  std::vector<char> code;      // gfx950 code object (default options)
+  std::vector<char> code2;     // the same source built without MachineLICM; empty unless some kernel is taken from it
+  bool use2[K__COUNT] = {};    // kernel k comes from code2 (it spills no / fewer SGPRs there)
   std::string build_log;
+  std::string build_info;      // per kernel: which build it comes from, bytes, spilled SGPRs
   // lazily bound to a device
   int device = -1;
   hipModule_t module = nullptr;
+  hipModule_t module2 = nullptr;
   hipFunction_t fn[K__COUNT] = {};
   hipStream_t stream = nullptr;
   // grow-only device staging for HAMK_MEM_HOST calls (slot i serves the i-th staged array of a
@@ -123,7 +127,7 @@ static std::string cache_path(const hamk_system* s, const std::vector<const char
   return dir + name;
 }
 
-static int compile_module(hamk_system* s) {
+static int compile_module(hamk_system* s, bool no_machine_licm, std::vector<char>& code) {
   hiprtcProgram prog = nullptr;
   const char* hdr_src[] = {kDeviceHeader, kWaveHeader};
   const char* hdr_name[] = {"hamk_device.hpp", "hamk_wave.hpp"};
@@ -136,6 +140,10 @@ static int compile_module(hamk_system* s) {
     // straight-line wave kernels (chain32: 170 s of a 200 s build); it is an optimisation pass only
     opts.push_back("-mllvm");
     opts.push_back("-disable-cgp");
+  }
+  if (no_machine_licm) {
+    opts.push_back("-mllvm");
+    opts.push_back("-disable-machine-licm");
   }
   std::string extra;                                   // experiments: HAMK_HIPRTC_FLAGS="-mllvm -foo ..."
   std::vector<std::string> extra_tok;
@@ -156,7 +164,7 @@ static int compile_module(hamk_system* s) {
     if (in) {
       std::vector<char> blob((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
       if (blob.size() > 64 && std::memcmp(blob.data(), "\177ELF", 4) == 0) {
-        s->code.swap(blob);
+        code.swap(blob);
         s->build_log = "cache hit: " + cpath;
         hiprtcDestroyProgram(&prog);
         return HAMK_OK;
@@ -177,14 +185,14 @@ static int compile_module(hamk_system* s) {
   }
   size_t sz = 0;
   hiprtcGetCodeSize(prog, &sz);
-  s->code.resize(sz);
-  hiprtcGetCode(prog, s->code.data());
+  code.resize(sz);
+  hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
   if (!cpath.empty()) {                                  // publish atomically: write aside, rename
     const std::string tmp = cpath + ".tmp." + std::to_string((long)getpid());
     std::ofstream out(tmp, std::ios::binary);
     if (out) {
-      out.write(s->code.data(), (std::streamsize)s->code.size());
+      out.write(code.data(), (std::streamsize)code.size());
       out.close();
       if (!out || std::rename(tmp.c_str(), cpath.c_str()) != 0) std::remove(tmp.c_str());
     }
@@ -224,8 +232,89 @@ static size_t kernel_code_bytes(const std::vector<char>& elf, const char* name) 
 }
 
 
+// SGPRs a kernel spills, from the code object's metadata note (msgpack; within a kernel's map the
+// keys are sorted, so ".name" precedes ".sgpr_spill_count" and the argument maps' ".name" entries
+// come before both).  -1 if not found.
+static int sgpr_spill_count(const std::vector<char>& elf, const char* kernel) {
+  static const char kName[] = "\xa5.name", kSpill[] = "\xb1.sgpr_spill_count";
+  const size_t ln = sizeof kName - 1, ls = sizeof kSpill - 1;
+  std::string last;
+  for (size_t i = 0; i + ls + 5 < elf.size(); ++i) {
+    if (elf[i] == kName[0] && std::memcmp(&elf[i], kName, ln) == 0) {
+      const unsigned char b = (unsigned char)elf[i + ln];
+      size_t len = 0, at = 0;
+      if ((b & 0xe0) == 0xa0) { len = b & 0x1f; at = i + ln + 1; }
+      else if (b == 0xd9) { len = (unsigned char)elf[i + ln + 1]; at = i + ln + 2; }
+      else continue;
+      if (at + len <= elf.size()) last.assign(&elf[at], len);
+    } else if (elf[i] == kSpill[0] && std::memcmp(&elf[i], kSpill, ls) == 0) {
+      const unsigned char* v = (const unsigned char*)&elf[i + ls];
+      long n = -1;
+      if (v[0] < 0x80) n = v[0];
+      else if (v[0] == 0xcc) n = v[1];
+      else if (v[0] == 0xcd) n = (v[1] << 8) | v[2];
+      else if (v[0] == 0xce) n = ((long)v[1] << 24) | (v[2] << 16) | (v[3] << 8) | v[4];
+      if (last == kernel) return (int)n;
+    }
+  }
+  return -1;
+}
+
+static void describe_build(hamk_system* s);
+
+// Build the code object(s) of s->source.  Kernels that spill SGPRs under the default options are
+// taken from a second build without MachineLICM when that build spills fewer: the hoisting of the
+// 64-bit literal constants out of the stepping loops is what overflows the 102 SGPRs (each fp64
+// literal is an SGPR pair on gfx9), re-materialising them in place costs a few SALU moves, and the
+// one kernel found giving run-to-run different results is correct again
+// without its 101 spilled SGPRs.  Spill-free kernels keep the default build (the headline RK4
+// kernel is 3 % faster with the hoisting).  HAMK_NOLICM=0 / 1 forces one build for experiments.
+static int build_code(hamk_system* s) {
+  s->code2.clear();
+  for (bool& u : s->use2) u = false;
+  int rc = compile_module(s, false, s->code);
+  if (rc != HAMK_OK) return rc;
+  int force = -1;
+  if (const char* e = std::getenv("HAMK_NOLICM")) force = (e[0] == '1') ? 1 : (e[0] == '0' ? 0 : -1);
+  if (force == 0) { describe_build(s); return HAMK_OK; }
+  int spills[K__COUNT];
+  bool any = false;
+  for (int k = 0; k < K__COUNT; ++k) { spills[k] = sgpr_spill_count(s->code, kKernelNames[k]); any = any || spills[k] > 0; }
+  if (!any && force != 1) { describe_build(s); return HAMK_OK; }
+  std::vector<char> alt;
+  rc = compile_module(s, true, alt);
+  if (rc != HAMK_OK) return rc;
+  bool used = false;
+  for (int k = 0; k < K__COUNT; ++k) {
+    const int sp2 = sgpr_spill_count(alt, kKernelNames[k]);
+    s->use2[k] = force == 1 || (spills[k] > 0 && sp2 >= 0 && sp2 < spills[k]);
+    used = used || s->use2[k];
+  }
+  if (used) s->code2.swap(alt);
+  describe_build(s);
+  return HAMK_OK;
+}
+
+static void describe_build(hamk_system* s) {
+  std::string t;
+  for (int k = 0; k < K__COUNT; ++k) {
+    const std::vector<char>& c = s->use2[k] ? s->code2 : s->code;
+    char line[160];
+    std::snprintf(line, sizeof line, "%s build=%s bytes=%zu sgpr_spills=%d\n", kKernelNames[k],
+                  s->use2[k] ? "no-machine-licm" : "default", kernel_code_bytes(c, kKernelNames[k]),
+                  sgpr_spill_count(c, kKernelNames[k]));
+    t += line;
+  }
+  s->build_info = t;
+}
+
+static size_t chosen_kernel_bytes(const hamk_system* s, int k) {
+  return kernel_code_bytes(s->use2[k] ? s->code2 : s->code, kKernelNames[k]);
+}
+
 static int launch(hamk_system* s, KernelId k, int64_t B, void** args);
-static int compile_module(hamk_system* s);
+static int build_code(hamk_system* s);
+static int load_modules(hamk_system* s);
 
 // ---------------------------------------------------------------------------
 // First-use self-check of the stepping kernels against the (small, separately compiled) hamEqs
@@ -441,15 +530,23 @@ static int self_check(hamk_system* s) {
     if (!rk4_ok) s->desc.rk4_stage_loop = true;            // rebuild with the stage-loop bodies
     if (!rkf_ok) s->desc.rkf_stage_loop = true;
     s->source = generate_source(s->desc);
-    rc = compile_module(s);
+    rc = build_code(s);
     if (rc != HAMK_OK) return rc;
-    hipModuleUnload(s->module);
-    s->module = nullptr;
-    HIP_TRY(hipModuleLoadData(&s->module, s->code.data()));
-    for (int k = 0; k < K__COUNT; ++k) HIP_TRY(hipModuleGetFunction(&s->fn[k], s->module, kKernelNames[k]));
+    rc = load_modules(s);
+    if (rc != HAMK_OK) return rc;
     s->self_check_rebuilds++;
   }
   return fail(HAMK_ERR_COMPILE, "self-check failed");
+}
+
+static int load_modules(hamk_system* s) {
+  if (s->module) { hipModuleUnload(s->module); s->module = nullptr; }
+  if (s->module2) { hipModuleUnload(s->module2); s->module2 = nullptr; }
+  HIP_TRY(hipModuleLoadData(&s->module, s->code.data()));
+  if (!s->code2.empty()) HIP_TRY(hipModuleLoadData(&s->module2, s->code2.data()));
+  for (int k = 0; k < K__COUNT; ++k)
+    HIP_TRY(hipModuleGetFunction(&s->fn[k], (s->use2[k] && s->module2) ? s->module2 : s->module, kKernelNames[k]));
+  return HAMK_OK;
 }
 
 static int bind_device(hamk_system* s) {
@@ -460,6 +557,7 @@ static int bind_device(hamk_system* s) {
   if (s->module) {
     hipModuleUnload(s->module);
     s->module = nullptr;
+    if (s->module2) { hipModuleUnload(s->module2); s->module2 = nullptr; }
     if (s->d_ts) { hipFree(s->d_ts); s->d_ts = nullptr; s->d_ts_cap = 0; }
     for (void*& b : s->stage_buf) if (b) { hipFree(b); b = nullptr; }
     s->stage_cap.assign(s->stage_cap.size(), 0);
@@ -469,8 +567,10 @@ static int bind_device(hamk_system* s) {
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(HAMK_ERR_NODEVICE, std::string("device ") + prop.gcnArchName + " is not gfx950 (MI355X); libhamk has no other code path");
-  HIP_TRY(hipModuleLoadData(&s->module, s->code.data()));
-  for (int k = 0; k < K__COUNT; ++k) HIP_TRY(hipModuleGetFunction(&s->fn[k], s->module, kKernelNames[k]));
+  {
+    const int rc_load = load_modules(s);
+    if (rc_load != HAMK_OK) return rc_load;
+  }
   s->device = dev;
   return self_check(s);
 }
@@ -724,17 +824,17 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   if (const char* e = std::getenv("HAMK_RKF_LOOP")) s->desc.rkf_stage_loop = (e[0] == '1');
   const bool forced_rk4 = std::getenv("HAMK_RK4_LOOP") != nullptr, forced_rkf = std::getenv("HAMK_RKF_LOOP") != nullptr;
   s->source = generate_source(s->desc);
-  int rc = compile_module(s);
+  int rc = build_code(s);
   if (rc != HAMK_OK) { delete s; return rc; }
   // keep every kernel comfortably inside SOPP branch reach: fall back to the stage-loop bodies
   const size_t kLimit = 64 * 1024;
-  const bool big_rkf = !s->desc.wave && !forced_rkf && !s->desc.rkf_stage_loop && kernel_code_bytes(s->code, "hamk_rkf45_k") > kLimit;
-  const bool big_rk4 = !s->desc.wave && !forced_rk4 && !s->desc.rk4_stage_loop && kernel_code_bytes(s->code, "hamk_rk4_steps_k") > kLimit;
+  const bool big_rkf = !s->desc.wave && !forced_rkf && !s->desc.rkf_stage_loop && chosen_kernel_bytes(s, K_RKF45) > kLimit;
+  const bool big_rk4 = !s->desc.wave && !forced_rk4 && !s->desc.rk4_stage_loop && chosen_kernel_bytes(s, K_RK4) > kLimit;
   if (big_rkf || big_rk4) {
     if (big_rkf) s->desc.rkf_stage_loop = true;
     if (big_rk4) s->desc.rk4_stage_loop = true;
     s->source = generate_source(s->desc);
-    rc = compile_module(s);
+    rc = build_code(s);
     if (rc != HAMK_OK) { delete s; return rc; }
   }
   *out = s;
@@ -744,6 +844,7 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
 void hamk_system_destroy(hamk_system* s) {
   if (!s) return;
   if (s->module) hipModuleUnload(s->module);
+  if (s->module2) hipModuleUnload(s->module2);
   if (s->d_ts) hipFree(s->d_ts);
   for (void* b : s->stage_buf) if (b) hipFree(b);
   if (s->pin) hipHostFree(s->pin);
@@ -770,9 +871,14 @@ int hamk_synchronize(hamk_system* s) {
 }
 
 const char* hamk_system_source(const hamk_system* s) { return s ? s->source.c_str() : nullptr; }
-int64_t hamk_system_code_size(const hamk_system* s) { return s ? (int64_t)s->code.size() : 0; }
+const char* hamk_system_build_info(const hamk_system* s) { return s ? s->build_info.c_str() : ""; }
+int64_t hamk_system_code_size(const hamk_system* s) { return s ? (int64_t)(s->code.size() + s->code2.size()) : 0; }
 int64_t hamk_system_kernel_bytes(const hamk_system* s, const char* kernel_name) {
-  return s ? (int64_t)kernel_code_bytes(s->code, kernel_name) : 0;
+  if (!s) return 0;
+  if (kernel_name)
+    for (int k = 0; k < K__COUNT; ++k)
+      if (std::strcmp(kernel_name, kKernelNames[k]) == 0) return (int64_t)chosen_kernel_bytes(s, k);
+  return (int64_t)kernel_code_bytes(s->code, kernel_name);
 }
 
 int hamk_coords_batch(hamk_system* s, int64_t B, const double* q, double* x, int32_t mem) {

@@ -148,6 +148,9 @@ int hamk_synchronize(hamk_system* s);
 const char* hamk_system_source(const hamk_system* s);
 /* Number of bytes of gfx950 code object produced by the specialisation.     */
 int64_t hamk_system_code_size(const hamk_system* s);
+/* One line per kernel: which of the two builds it is taken from (default options, or without
+ * MachineLICM when that spills fewer SGPRs), its code bytes and its spilled SGPRs.             */
+const char* hamk_system_build_info(const hamk_system* s);
 /* Machine-code bytes of one kernel of the module ("hamk_rk4_steps_k", ...); 0 if unknown.
  * kernel_name == NULL: number of function symbols in the module (8 = every device function
  * was inlined into the 8 kernels).                                                          */

@@ -78,6 +78,33 @@ def test_calls_fail_loudly_without_a_gpu(hamk_lib):
         api.hamEqs(s, api.Phase(np.array([0.1]), np.array([0.2])))
 
 
+@pytest.mark.parametrize("name", ["doublePendulum", "room", "opcodeZoo", "chain8"])
+def test_kernels_come_from_the_build_that_spills_fewer_scalar_registers(hamk_lib, monkeypatch, name):
+    """Every kernel is taken from whichever of the two builds (default options / without
+    MachineLICM) spills fewer SGPRs, the default build on a tie (hamk_api.cpp::build_code).  The
+    one kernel ever seen to give run-to-run different results spilled 101 (DESIGN.md section 6b);
+    the headline RK4 kernel spills none either way and stays on the default build."""
+    from hamilton_amd import api
+
+    def spills(force):
+        if force is None:
+            monkeypatch.delenv("HAMK_NOLICM", raising=False)
+        else:
+            monkeypatch.setenv("HAMK_NOLICM", force)
+        info = api.system_from_spec(E.get(name)).build_info
+        rows = [re.match(r"(\S+) build=(\S+) bytes=(\d+) sgpr_spills=(-?\d+)", l).groups() for l in info.splitlines() if l]
+        assert len(rows) == 8
+        return {k: (b, int(n)) for k, b, _, n in rows}
+
+    dflt, nolicm, chosen = spills("0"), spills("1"), spills(None)
+    for k in chosen:
+        want = "no-machine-licm" if nolicm[k][1] < dflt[k][1] else "default"
+        assert chosen[k] == (want, min(dflt[k][1], nolicm[k][1])), (name, k, dflt[k], nolicm[k], chosen[k])
+    assert chosen["hamk_rk4_steps_k"][1] == 0
+    if name == "doublePendulum":
+        assert chosen["hamk_rk4_steps_k"][0] == "default" and chosen["hamk_rkf45_k"] == ("no-machine-licm", 0)
+
+
 def test_device_memory_entry_points_without_a_gpu(hamk_lib):
     """Device selection / memory / gather: argument checks work anywhere; without a GPU the calls that
     need one return an error code and a message instead of crashing."""
