@@ -28,10 +28,13 @@
  * Data layout: every state array is structure-of-arrays, fp64, component
  * major: q[j*B + i] is generalized coordinate j of trajectory i (j < n,
  * i < B).  Arrays are caller-owned; nothing is retained after return.
- * `mem` says where the caller's pointers live: HAMK_MEM_HOST (library stages
- * through device memory, PCIe-inclusive) or HAMK_MEM_DEVICE (pointers are HIP
- * device pointers on the current device; launch is asynchronous on the
- * handle's stream, see hamk_set_stream).
+ * `mem` says where the caller's pointers live: HAMK_MEM_HOST (PCIe-inclusive:
+ * small arrays go through a pinned arena the kernel reads and writes directly,
+ * large ones are staged through device memory; the call returns when the
+ * results are in the caller's arrays) or HAMK_MEM_DEVICE (pointers are HIP
+ * device pointers on the current device -- from the host's own runtime or from
+ * hamk_device_malloc; the launch is asynchronous on the handle's stream, see
+ * hamk_set_stream).
  *
  * User functions cross the ABI as expression tapes (hamk_op[]): the host
  * shim instantiates the reference's rank-2 polymorphic functions
@@ -48,7 +51,13 @@
  * status[B] (bit mask, HAMK_ST_*), never an exception.
  *
  * Threading: one handle is used by one host thread at a time; distinct
- * handles may be used concurrently.
+ * handles may be used concurrently.  A handle runs on the device that is
+ * current (hamk_set_device) when it is first used; one handle per device is the
+ * way to drive several GPUs from one process.
+ *
+ * First use of a handle on a device runs a short self-check of its stepping
+ * kernels against its hamEqs kernel (a JIT product does not take the code
+ * generator's word for it); HAMK_SELFCHECK=0 skips it.
  */
 #ifndef HAMK_H
 #define HAMK_H
