@@ -2,7 +2,7 @@
 Latency of the host-staged path per call vs the CPU oracle (the GPU is latency-bound at B = 1)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hamilton_amd import api, examples as E
 from oracle import oracle
 spec = E.get("doublePendulum"); s = api.system_from_spec(spec); o = oracle.OracleSystem(spec)

@@ -2,7 +2,7 @@
 high-precision fixtures) per system -- the evidence behind the tolerance ladder of DESIGN.md section 4."""
 import json, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from hamilton_amd import api, examples as E
 from oracle import oracle
