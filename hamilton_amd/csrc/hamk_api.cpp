@@ -338,11 +338,16 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
       q[(size_t)j * B + i] = 0.31 + 0.07 * j + 0.011 * (double)i;
       p[(size_t)j * B + i] = 0.23 - 0.05 * j + 0.007 * (double)i;
     }
-  double *d_q, *d_p, *d_dq, *d_dp, *d_ts; int32_t* d_st;
-  HIP_TRY(hipMalloc((void**)&d_q, cnt * 8)); HIP_TRY(hipMalloc((void**)&d_p, cnt * 8));
-  HIP_TRY(hipMalloc((void**)&d_dq, cnt * 8)); HIP_TRY(hipMalloc((void**)&d_dp, cnt * 8));
-  HIP_TRY(hipMalloc((void**)&d_ts, 2 * 8)); HIP_TRY(hipMalloc((void**)&d_st, B * 4));
-  auto cleanup = [&]() { hipFree(d_q); hipFree(d_p); hipFree(d_dq); hipFree(d_dp); hipFree(d_ts); hipFree(d_st); };
+  // device scratch of the check, released on every path out of this function
+  struct Scratch {
+    void* p[5] = {};
+    ~Scratch() { for (void* x : p) if (x) hipFree(x); }
+  } scratch;
+  HIP_TRY(hipMalloc(&scratch.p[0], cnt * 8)); HIP_TRY(hipMalloc(&scratch.p[1], cnt * 8));
+  HIP_TRY(hipMalloc(&scratch.p[2], cnt * 8)); HIP_TRY(hipMalloc(&scratch.p[3], cnt * 8));
+  HIP_TRY(hipMalloc(&scratch.p[4], B * 4));
+  double *d_q = (double*)scratch.p[0], *d_p = (double*)scratch.p[1], *d_dq = (double*)scratch.p[2], *d_dp = (double*)scratch.p[3];
+  int32_t* d_st = (int32_t*)scratch.p[4];
   long long b = B;
   bool flagged = false;
   auto rhs = [&](const std::vector<double>& y, std::vector<double>& out) -> int {   // out = hamEqs(y), y = [q; p]
@@ -510,7 +515,6 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
     if (std::strstr(e, "rk4") && !s->desc.rk4_stage_loop) *rk4_ok = false;
     if (std::strstr(e, "rkf") && !s->desc.rkf_stage_loop) *rkf_ok = false;
   }
-  cleanup();
   return rc;
 }
 
