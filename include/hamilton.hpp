@@ -423,7 +423,8 @@ inline std::vector<double> hamiltonian(System& s, const DevicePhase& d) {      /
   std::vector<double> out((size_t)d.B); h.download(out.data());
   return out;
 }
-// final gather of shards (possibly on several devices) into one host ensemble, part order
+// final gather of shards (possibly on several devices) into one host ensemble, part order;
+// synchronize() the Systems that advance the shards first
 inline Phase gather(const std::vector<const DevicePhase*>& parts) {
   Phase out;
   if (parts.empty()) return out;

@@ -233,7 +233,8 @@ int hamk_memcpy(void* dst, const void* src, int64_t bytes, int32_t kind);   /* s
 /* Final gather of a sharded ensemble: part g is a structure-of-arrays block [n][B_parts[g]] in
  * device memory (any device); out is [n][sum_g B_parts[g]], trajectories in part order -- in host
  * memory (out_mem = HAMK_MEM_HOST) or on the current device (HAMK_MEM_DEVICE; peer copies over
- * xGMI).  One array per call (q, then p).  Synchronous.                                         */
+ * xGMI).  One array per call (q, then p).  Synchronous; it does not wait for launches still
+ * running on other streams -- hamk_synchronize the handles that produce the parts first.        */
 int hamk_gather_batch(int32_t nparts, int32_t n, const int64_t* B_parts, const double* const* parts,
                       double* out, int32_t out_mem);
 
