@@ -313,6 +313,29 @@ def test_small_host_calls_see_fresh_inputs(api, systems):
         assert relerr(r4.positions, rq) < 1e-11 and relerr(r4.momenta, rp) < 1e-11, it
 
 
+@pytest.mark.parametrize("name", ["doublePendulum", "spring", "threeBodyPolar", "opcodeZoo", "room"])
+def test_steppers_are_deterministic(api, systems, name):
+    """Every lane is independent, so two runs on the same input must agree bit for bit -- for both
+    steppers, after other kernels have run (they leave other register contents behind).  An unrolled
+    RKF45 body that spilled 101 SGPRs once failed exactly this."""
+    import torch
+    spec, s, o = systems[name]
+    B = 1 << 16
+    q, qd = E.sample_config(spec, 777, B)
+    ph = api.toPhase(s, api.Config(torch.from_numpy(q).cuda(), torch.from_numpy(qd).cuda()))
+    api.hamEqs(s, ph); api.hamiltonian(s, ph)
+    runs = []
+    for _ in range(3):
+        a = api.stepHam(4 * spec.dt, s, ph); na = s.last_nsub.clone()
+        b = api.rk4Steps(spec.dt, 5, s, ph)
+        api.hamEqs(s, ph)
+        runs.append((a.positions.clone(), a.momenta.clone(), na, b.positions.clone(), b.momenta.clone()))
+    torch.cuda.synchronize()
+    for r in runs[1:]:
+        for x, y in zip(r, runs[0]):
+            assert torch.equal(x, y), name
+
+
 def test_device_memory_and_gather_through_the_abi(api, systems, hamk_lib):
     """A host without HIP or torch: hamk_device_malloc / hamk_memcpy keep the ensemble in HBM across
     calls, hamk_gather_batch reassembles SoA shards (here three unequal ones on the one device) in
