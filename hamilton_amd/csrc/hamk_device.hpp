@@ -839,7 +839,11 @@ HAMK_DEV void rhs(const double (&y)[2 * S::N], double (&dy)[2 * S::N], int& st, 
 // ---- NaN/Inf test on raw bits: immune to -fno-honor-nans folding -------------
 HAMK_DEV bool is_nonfinite_bits(double x) {
   unsigned int hi = (unsigned int)__double2hiint(x);
+#ifdef HAMK_HOST_EMULATION                                 // tests/host_emulation compiles this header for the CPU
+  asm volatile("" : "+r"(hi));
+#else
   asm volatile("" : "+v"(hi));
+#endif
   return (hi & 0x7ff00000u) == 0x7ff00000u;
 }
 

@@ -1,0 +1,139 @@
+"""CPU: the library's DEVICE code on the host.  tests/host_emulation/hip_shim.hpp supplies just
+enough of the HIP device environment to compile hamilton_amd/csrc/hamk_device.hpp plus a generated
+system with g++; the kernels are then run thread by thread and compared with the oracle.  Covers,
+without a GPU: the tape -> C++ generator, the jets of every opcode, the three AD strategies (incl.
+the generated reverse sweep), the solves, sincos_f64 / incremental sincos, the RK4 body and the
+GSL-semantics RKF45 body with its controller.  TEST INFRASTRUCTURE: nothing here is linked into
+libhamk.so and the product has no CPU path; what this cannot see is the GPU compiler."""
+import ctypes
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ALL_GOLDEN_SYSTEMS, ROOT
+from hamilton_amd import examples as E
+
+EMU = os.path.join(ROOT, "tests", "host_emulation")
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+P = lambda a: a.ctypes.data_as(_dp)
+I = lambda a: a.ctypes.data_as(_ip)
+LL = ctypes.c_longlong
+
+
+@pytest.fixture(scope="module")
+def emulate(hamk_lib, tmp_path_factory):
+    from hamilton_amd import api
+    cache = {}
+    tmp = tmp_path_factory.mktemp("emu")
+
+    def make(spec, env=None):
+        old = {}
+        for k, v in (env or {}).items():
+            old[k] = os.environ.get(k)
+            os.environ[k] = v
+        try:
+            s = api.system_from_spec(spec)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        src = s.source
+        assert "hamk_device.hpp" in src, "lane path expected (wave kernels are not emulated)"
+        key = hashlib.sha1(src.encode()).hexdigest()[:16]
+        if key not in cache:
+            cpp, so = str(tmp / f"{key}.cpp"), str(tmp / f"{key}.so")
+            with open(cpp, "w") as fh:
+                fh.write(src + open(os.path.join(EMU, "driver.inc")).read())
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-attributes",
+                                   "-include", os.path.join(EMU, "hip_shim.hpp"), "-I" + os.path.join(ROOT, "hamilton_amd", "csrc"),
+                                   "-o", so, cpp])
+            cache[key] = ctypes.CDLL(so)
+        return cache[key], src
+    return make
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.maximum(1.0, np.abs(np.asarray(b)))))
+
+
+def check_against_oracle(L, spec, o, B=48, start=11, tol=1e-11, steps=3, dt_ham=None):
+    q, qd = E.sample_config(spec, start, B)
+    p = o.to_phase_batch(q, qd)
+    st = np.zeros(B, np.int32)
+    got = np.zeros_like(q)
+    L.emu_to_phase(P(q), P(qd), P(got), LL(B))
+    assert relerr(got, p) < tol
+    odq, odp, ost = o.hameqs_batch(q, p)
+    good = ost == 0
+    cond = np.array([np.linalg.cond(o.jacobian(q[:, i]).T @ np.diag(spec.inertia) @ o.jacobian(q[:, i])) for i in range(B)])
+    scale = np.maximum(1.0, cond / 100.0)
+    dq, dp = np.zeros_like(q), np.zeros_like(q)
+    L.emu_hameqs(P(q), P(p), P(dq), P(dp), LL(B), I(st))
+    err = np.maximum(np.abs(dq - odq).max(0) / np.maximum(1.0, np.abs(odq).max(0)),
+                     np.abs(dp - odp).max(0) / np.maximum(1.0, np.abs(odp).max(0)))
+    assert np.all(err[good] <= tol * scale[good]), float(np.max(err[good] / scale[good]))
+    ke, pe, h = np.zeros(B), np.zeros(B), np.zeros(B)
+    L.emu_observe(P(q), P(p), P(ke), P(pe), P(h), LL(B), I(st))
+    oke, ope, oh = o.observe_batch(q, p)
+    assert relerr(pe, ope) < tol and np.all((np.abs(h - oh) / np.maximum(1.0, np.abs(oh)))[good] <= tol * scale[good])
+    q2, p2 = q.copy(), p.copy()
+    L.emu_rk4(P(q2), P(p2), LL(B), ctypes.c_double(spec.dt), steps, I(st))
+    oq, op = o.rk4_steps_batch(q, p, spec.dt, steps)
+    e2 = np.maximum(np.abs(q2 - oq).max(0), np.abs(p2 - op).max(0)) / np.maximum(1.0, np.abs(op).max(0))
+    assert np.all(e2[good] <= 10 * tol * scale[good]), float(np.max(e2[good] / scale[good]))
+    q3, p3, ns = q.copy(), p.copy(), np.zeros(B, np.int32)
+    dth = dt_ham if dt_ham is not None else 4 * spec.dt
+    L.emu_step_ham(P(q3), P(p3), LL(B), ctypes.c_double(dth), I(st), I(ns))
+    sq, sp, sns = o.step_ham_batch(q, p, dth)
+    same = (ns == sns) & good
+    assert same[good].mean() > 0.9, float(same[good].mean())
+    e3 = np.maximum(np.abs(q3 - sq).max(0), np.abs(p3 - sp).max(0)) / np.maximum(1.0, np.abs(sp).max(0))
+    assert np.all(e3[same] <= 100 * tol * scale[same]), float(np.max(e3[same] / scale[same]))
+
+
+@pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS)
+def test_device_code_on_host_matches_oracle(emulate, oracle_lib, name):
+    spec = E.get(name)
+    L, _ = emulate(spec)
+    check_against_oracle(L, spec, oracle_lib.OracleSystem(spec))
+
+
+@pytest.mark.parametrize("mode", ["H", "D", "R"])
+@pytest.mark.parametrize("name", ["opcodeZoo", "spring", "chain4"])
+def test_ad_strategies_and_stage_loops_on_host(emulate, oracle_lib, name, mode):
+    """HAMK_AD_MODE = H (full second-order jets), D (directional second sweep), R (generated reverse
+    sweep), each with the unrolled and the stage-loop stepping bodies."""
+    spec = E.get(name)
+    o = oracle_lib.OracleSystem(spec)
+    for loop in ("0", "1"):
+        L, src = emulate(spec, {"HAMK_AD_MODE": mode, "HAMK_RK4_LOOP": loop, "HAMK_RKF_LOOP": loop, "HAMK_WAVE": "0"})
+        assert ("MODE_H = true" in src) == (mode == "H") and ("MODE_R = true" in src) == (mode == "R")
+        assert ("RK4_STAGE_LOOP = true" in src) == (loop == "1")
+        check_against_oracle(L, spec, o, B=24)
+
+
+@pytest.mark.parametrize("name", ["chain8", "chain12"])
+def test_mid_size_systems_on_host(emulate, oracle_lib, name):
+    spec = E.get(name)
+    L, src = emulate(spec)
+    assert "MODE_R = true" in src
+    check_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=8, steps=2, tol=1e-10)
+
+
+@pytest.mark.parametrize("seed", [0, 3, 8, 10, 12, 15])
+def test_random_systems_on_host(emulate, oracle_lib, seed):
+    """The random expression-tree systems of the GPU suite (incl. seed 8, whose unrolled RKF45 kernel
+    was the nondeterministic one on the GPU): on the host the same device code is right -- the
+    defect was the GPU compiler's."""
+    from test_gpu_random_systems import random_spec
+    spec = random_spec(seed)
+    o = oracle_lib.OracleSystem(spec)
+    for loop in ("0", "1"):
+        L, _ = emulate(spec, {"HAMK_RK4_LOOP": loop, "HAMK_RKF_LOOP": loop})
+        check_against_oracle(L, spec, o, B=32, start=99, dt_ham=0.02)
