@@ -137,3 +137,32 @@ def test_random_systems_on_host(emulate, oracle_lib, seed):
     for loop in ("0", "1"):
         L, _ = emulate(spec, {"HAMK_RK4_LOOP": loop, "HAMK_RKF_LOOP": loop})
         check_against_oracle(L, spec, o, B=32, start=99, dt_ham=0.02)
+
+
+@pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS)
+def test_device_code_on_host_matches_golden_fixtures(emulate, name):
+    """The same device code against the independently derived 50-digit fixtures (tests/golden): no
+    oracle in the loop."""
+    from conftest import fvec, load_golden
+    spec = E.get(name)
+    L, _ = emulate(spec)
+    pts = load_golden(name)["points"]
+    B = len(pts)
+    q = np.ascontiguousarray(np.stack([fvec(p["q"]) for p in pts], axis=1))
+    qd = np.ascontiguousarray(np.stack([fvec(p["qd"]) for p in pts], axis=1))
+    p = np.ascontiguousarray(np.stack([fvec(pt["p"]) for pt in pts], axis=1))
+    tol = 1e-12 * np.maximum(1.0, np.array([float(pt["cond_hint"]) for pt in pts]) / 1e3)
+    got = np.zeros_like(q)
+    L.emu_to_phase(P(q), P(qd), P(got), LL(B))
+    assert np.all(np.abs(got - p).max(0) / np.maximum(1.0, np.abs(p).max(0)) <= tol)
+    dq, dp, st = np.zeros_like(q), np.zeros_like(q), np.zeros(B, np.int32)
+    L.emu_hameqs(P(q), P(p), P(dq), P(dp), LL(B), I(st))
+    wdq = np.stack([fvec(pt["dq"]) for pt in pts], axis=1)
+    wdp = np.stack([fvec(pt["dp"]) for pt in pts], axis=1)
+    assert not st.any()
+    assert np.all(np.abs(dq - wdq).max(0) / np.maximum(1.0, np.abs(wdq).max(0)) <= tol)
+    assert np.all(np.abs(dp - wdp).max(0) / np.maximum(1.0, np.abs(wdp).max(0)) <= tol)
+    ke, pe, h = np.zeros(B), np.zeros(B), np.zeros(B)
+    L.emu_observe(P(q), P(p), P(ke), P(pe), P(h), LL(B), I(st))
+    want_h = np.array([float(pt["hamiltonian"]) for pt in pts])
+    assert np.all(np.abs(h - want_h) / np.maximum(1.0, np.abs(want_h)) <= tol)
