@@ -166,3 +166,53 @@ def test_device_code_on_host_matches_golden_fixtures(emulate, name):
     L.emu_observe(P(q), P(p), P(ke), P(pe), P(h), LL(B), I(st))
     want_h = np.array([float(pt["hamiltonian"]) for pt in pts])
     assert np.all(np.abs(h - want_h) / np.maximum(1.0, np.abs(want_h)) <= tol)
+
+
+@pytest.fixture(scope="module")
+def elementary(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("emu_elem") / "elem.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-attributes",
+                           "-include", os.path.join(EMU, "hip_shim.hpp"), "-I" + os.path.join(ROOT, "hamilton_amd", "csrc"),
+                           "-o", so, os.path.join(EMU, "sincos_driver.cpp")])
+    return ctypes.CDLL(so)
+
+
+def test_own_sincos_accuracy(elementary):
+    """sincos_f64 (3-FMA Cody-Waite + power-basis kernels) against 80-bit long double: <= 2e-16 absolute
+    over uniform arguments, arguments next to multiples of pi/2 (where reduction cancels) and large
+    arguments up to the hand-over to the library path; the anchored incremental form adds nothing."""
+    rng = np.random.default_rng(7)
+    k = rng.integers(-1000000, 1000000, 200000).astype(np.float64)
+    x = np.concatenate([rng.uniform(-10, 10, 400000), rng.uniform(-1.5e6, 1.5e6, 400000),
+                        k * (np.pi / 2) + rng.uniform(-1e-6, 1e-6, k.size), np.array([0.0, -0.0, 1e-300, 1e-9, np.pi / 4, -np.pi / 4])])
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    elementary.emu_sincos(P(x), P(s), P(c), LL(x.size))
+    xl = x.astype(np.longdouble)
+    es, ec = np.abs(s - np.sin(xl)).max(), np.abs(c - np.cos(xl)).max()
+    assert float(es) < 2.0e-16 and float(ec) < 2.0e-16, (float(es), float(ec))
+    xa = rng.uniform(-50, 50, 400000)
+    d = rng.uniform(-0.2, 0.2, xa.size)               # beyond |d| = 1/8 the routine falls back to the full evaluation
+    elementary.emu_sincos_incr(P(xa), P(d), P(s[:xa.size]), P(c[:xa.size]), LL(xa.size))
+    xl = (xa + d).astype(np.longdouble)
+    es, ec = np.abs(s[:xa.size] - np.sin(xl)).max(), np.abs(c[:xa.size] - np.cos(xl)).max()
+    assert float(es) < 3.0e-16 and float(ec) < 3.0e-16, (float(es), float(ec))
+
+
+def test_reciprocal_and_controller_power(elementary):
+    """frcp (rcp + two Newton steps) and rpow_inv (the step-size controller's r^(-1/5), r^(-1/6)) to
+    a few ulp over the ranges the kernels feed them; rpow_inv clamps r to [2^-100, 2^100]."""
+    rng = np.random.default_rng(8)
+    x = np.concatenate([10.0 ** rng.uniform(-30, 30, 200000), -(10.0 ** rng.uniform(-5, 5, 1000))])
+    r = np.zeros_like(x)
+    elementary.emu_frcp(P(x), P(r), LL(x.size))
+    assert float(np.abs(r * x - 1.0).max()) < 5e-16
+    y = 10.0 ** rng.uniform(-28, 28, 200000)
+    r5, r6 = np.zeros_like(y), np.zeros_like(y)
+    elementary.emu_rpow(P(y), P(r5), P(r6), LL(y.size))
+    yl = y.astype(np.longdouble)
+    assert float(np.abs(r5 * yl ** (np.longdouble(1) / 5) - 1).max()) < 1e-15
+    assert float(np.abs(r6 * yl ** (np.longdouble(1) / 6) - 1).max()) < 1e-15
+    edge = np.array([1e-300, 2.0 ** -100, 2.0 ** 100, 1e300])
+    e5, e6 = np.zeros_like(edge), np.zeros_like(edge)
+    elementary.emu_rpow(P(edge), P(e5), P(e6), LL(edge.size))
+    assert e5[0] == e5[1] and e5[2] == e5[3] and abs(e5[1] / 2.0 ** 20 - 1) < 1e-15 and abs(e6[2] * 2.0 ** (100 / 6) - 1) < 1e-15
