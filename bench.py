@@ -103,11 +103,11 @@ def stepham_bench(a, s, spec, dt, state, dist, dev, rank, world):
     """Secondary: stepHam(dt) calls/s over the ensemble (GSL-semantics adaptive RKF45 per lane)."""
     ph = state
     for _ in range(a.warmup):
-        ph = api.stepHam(dt, s, ph)
+        ph = api.stepHam(dt, s, ph, inplace=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        ph = api.stepHam(dt, s, ph)
+        ph = api.stepHam(dt, s, ph, inplace=True)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     nsub = s.last_nsub.to(torch.float64)

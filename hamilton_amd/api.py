@@ -330,10 +330,11 @@ def hamEqs(s: System, ph: Phase):
 # ---------------------------------------------------------------------------------------
 # time stepping
 # ---------------------------------------------------------------------------------------
-def stepHam(r: float, s: System, ph: Phase) -> Phase:
-    """stepHam (Hamilton.hs:390-402): adaptive RKF45 (GSL semantics) from 0 to r."""
+def stepHam(r: float, s: System, ph: Phase, inplace: bool = False) -> Phase:
+    """stepHam (Hamilton.hs:390-402): adaptive RKF45 (GSL semantics) from 0 to r.  inplace=True
+    advances the given arrays without copying (ensemble loops; the reference's signature is pure)."""
     qa, pa = _Arr(ph.positions, s.n, "positions"), _Arr(ph.momenta, s.n, "momenta")
-    q, p = qa.clone(), pa.clone()
+    q, p = (qa.a, pa.a) if inplace else (qa.clone(), pa.clone())
     st, ns = qa.like(None, "i4"), qa.like(None, "i4")
     s._use_stream_of(qa)
     _abi.check(_abi.lib().hamk_step_ham_batch(s._h, qa.B, _ptr(q), _ptr(p), float(r), _ptr(st), _ptr(ns), qa.mem))

@@ -34,7 +34,7 @@ for cfg, name, B, nsteps in CONFIGS:
     st2 = api.Phase(ph.positions.clone(), ph.momenta.clone())
     hold = [st2]
     def step():
-        hold[0] = api.stepHam(spec.dt, s, hold[0])
+        hold[0] = api.stepHam(spec.dt, s, hold[0], inplace=True)
     sec2 = timed(step, 2, 6)
     nsub = s.last_nsub.double()
     info = {l.split()[0]: l.split()[1] for l in s.build_info.splitlines() if l}

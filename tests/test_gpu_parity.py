@@ -254,6 +254,13 @@ def test_device_pointers_equal_host_staging(api, systems):
     api.rk4Steps(0.01, 20, s, api.Phase(tq, tp), inplace=True)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(tq.cpu().numpy(), host.positions)
+    sq, sp = torch.from_numpy(q).cuda(), torch.from_numpy(p).cuda()
+    pure = api.stepHam(0.03, s, api.Phase(sq, sp))
+    np.testing.assert_array_equal(sq.cpu().numpy(), q)                      # the pure form leaves its argument alone
+    api.stepHam(0.03, s, api.Phase(sq, sp), inplace=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(sq.cpu().numpy(), pure.positions.cpu().numpy())
+    np.testing.assert_array_equal(sp.cpu().numpy(), pure.momenta.cpu().numpy())
 
 
 @pytest.mark.parametrize("B", [1, 7, 300, 20000])
