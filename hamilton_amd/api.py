@@ -94,6 +94,24 @@ class _Arr:
         return self.a.clone() if self.device else self.a.copy()
 
 
+def _pair(a, name_a: str, b, name_b: str, rows: int):
+    """Two arrays of one state (positions + velocities / momenta): same ensemble size, same place."""
+    xa, xb = _Arr(a, rows, name_a), _Arr(b, rows, name_b)
+    if xa.B != xb.B or xa.single != xb.single:
+        raise ValueError(f"{name_a} and {name_b} describe different ensembles ({xa.B} vs {xb.B} trajectories)")
+    if xa.device != xb.device or (xa.device and xa.a.device != xb.a.device):
+        raise ValueError(f"{name_a} and {name_b} must live in the same memory (both host arrays or both tensors of one GPU)")
+    return xa, xb
+
+
+def _in_place(x: "_Arr", original, name: str):
+    """inplace=True only makes sense if the array handed to the library IS the caller's array."""
+    same = (x.a.data_ptr() == original.data_ptr()) if (x.device and _is_torch(original)) else \
+        (isinstance(original, np.ndarray) and x.a.ctypes.data == original.ctypes.data)
+    if not same:
+        raise ValueError(f"inplace=True needs {name} as a contiguous float64 [n, B] array (a converted copy would be advanced instead)")
+
+
 def _ptr(x):
     if x is None:
         return None
@@ -242,7 +260,7 @@ def underlyingPos(s: System, q):
 
 def momenta(s: System, c: Config):
     """momenta (Hamilton.hs:262-269)."""
-    qa, va = _Arr(c.positions, s.n, "positions"), _Arr(c.velocities, s.n, "velocities")
+    qa, va = _pair(c.positions, "positions", c.velocities, "velocities", s.n)
     p = qa.like(s.n)
     s._use_stream_of(qa)
     _abi.check(_abi.lib().hamk_to_phase_batch(s._h, qa.B, qa.ptr, va.ptr, _ptr(p), qa.mem))
@@ -256,7 +274,7 @@ def toPhase(s: System, c: Config) -> Phase:
 
 def velocities(s: System, ph: Phase):
     """velocities (Hamilton.hs:316-324)."""
-    qa, pa = _Arr(ph.positions, s.n, "positions"), _Arr(ph.momenta, s.n, "momenta")
+    qa, pa = _pair(ph.positions, "positions", ph.momenta, "momenta", s.n)
     v, st = qa.like(s.n), qa.like(None, "i4")
     s._use_stream_of(qa)
     _abi.check(_abi.lib().hamk_from_phase_batch(s._h, qa.B, qa.ptr, pa.ptr, _ptr(v), _ptr(st), qa.mem))
@@ -270,8 +288,10 @@ def fromPhase(s: System, ph: Phase) -> Config:
 
 
 def _observe(s: System, q, p, which: str):
-    qa = _Arr(q, s.n, "positions")
-    pa = _Arr(p, s.n, "momenta") if p is not None else None
+    if p is not None:
+        qa, pa = _pair(q, "positions", p, "momenta", s.n)
+    else:
+        qa, pa = _Arr(q, s.n, "positions"), None
     out, st = qa.like(None), qa.like(None, "i4")
     ptrs = {"ke": None, "pe": None, "h": None}
     ptrs[which] = _ptr(out)
@@ -299,7 +319,7 @@ def pe(s: System, q):
 
 
 def _observe_config(s: System, c: Config, which: str):
-    qa, va = _Arr(c.positions, s.n, "positions"), _Arr(c.velocities, s.n, "velocities")
+    qa, va = _pair(c.positions, "positions", c.velocities, "velocities", s.n)
     out = qa.like(None)
     s._use_stream_of(qa)
     _abi.check(_abi.lib().hamk_observe_config_batch(
@@ -319,7 +339,7 @@ def lagrangian(s: System, c: Config):
 
 def hamEqs(s: System, ph: Phase):
     """hamEqs (Hamilton.hs:370-387): returns (dH/dp, -dH/dq)."""
-    qa, pa = _Arr(ph.positions, s.n, "positions"), _Arr(ph.momenta, s.n, "momenta")
+    qa, pa = _pair(ph.positions, "positions", ph.momenta, "momenta", s.n)
     dq, dp, st = qa.like(s.n), qa.like(s.n), qa.like(None, "i4")
     s._use_stream_of(qa)
     _abi.check(_abi.lib().hamk_hameqs_batch(s._h, qa.B, qa.ptr, pa.ptr, _ptr(dq), _ptr(dp), _ptr(st), qa.mem))
@@ -333,7 +353,9 @@ def hamEqs(s: System, ph: Phase):
 def stepHam(r: float, s: System, ph: Phase, inplace: bool = False) -> Phase:
     """stepHam (Hamilton.hs:390-402): adaptive RKF45 (GSL semantics) from 0 to r.  inplace=True
     advances the given arrays without copying (ensemble loops; the reference's signature is pure)."""
-    qa, pa = _Arr(ph.positions, s.n, "positions"), _Arr(ph.momenta, s.n, "momenta")
+    qa, pa = _pair(ph.positions, "positions", ph.momenta, "momenta", s.n)
+    if inplace:
+        _in_place(qa, ph.positions, "positions"); _in_place(pa, ph.momenta, "momenta")
     q, p = (qa.a, pa.a) if inplace else (qa.clone(), pa.clone())
     st, ns = qa.like(None, "i4"), qa.like(None, "i4")
     s._use_stream_of(qa)
@@ -348,7 +370,7 @@ def evolveHam(s: System, p0: Phase, ts, h0: float = 0.0, eps_abs: float = 0.0, e
     ts = np.ascontiguousarray(np.asarray(ts, dtype=np.float64))
     if ts.ndim != 1 or len(ts) < 2:
         raise ValueError("evolveHam needs at least two solution times (2 <= s)")
-    qa, pa = _Arr(p0.positions, s.n, "positions"), _Arr(p0.momenta, s.n, "momenta")
+    qa, pa = _pair(p0.positions, "positions", p0.momenta, "momenta", s.n)
     nt = len(ts)
     qo, po = qa.like(s.n, lead=(nt,)), qa.like(s.n, lead=(nt,))
     st, ns = qa.like(None, "i4"), qa.like(None, "i4")
@@ -390,7 +412,9 @@ def rk4Steps(dt: float, nsteps: int, s: System, ph: Phase, inplace: bool = False
     """Classic fixed-step RK4 over hamEqs -- named by BASELINE.json's north_star; the
     reference has no fixed-step integrator.  inplace=True advances the
     given device/host arrays without copying (bench path)."""
-    qa, pa = _Arr(ph.positions, s.n, "positions"), _Arr(ph.momenta, s.n, "momenta")
+    qa, pa = _pair(ph.positions, "positions", ph.momenta, "momenta", s.n)
+    if inplace:
+        _in_place(qa, ph.positions, "positions"); _in_place(pa, ph.momenta, "momenta")
     q, p = (qa.a, pa.a) if inplace else (qa.clone(), pa.clone())
     st = qa.like(None, "i4")
     s._use_stream_of(qa)

@@ -135,6 +135,12 @@ def test_argument_checks(hamk_lib):
     with pytest.raises(ValueError):
         api.evolveHam(s, api.Phase(np.zeros(1), np.zeros(1)), [0.0])       # needs 2 <= s
     assert api.evolveHam_(s, api.Phase(np.zeros(1), np.zeros(1)), []) == []
+    with pytest.raises(ValueError, match="different ensembles"):
+        api.hamEqs(s, api.Phase(np.zeros((1, 3)), np.zeros((1, 4))))
+    with pytest.raises(ValueError, match="inplace=True"):               # a float32 array would be converted: not in place
+        api.rk4Steps(0.01, 1, s, api.Phase(np.zeros((1, 3), dtype=np.float32), np.zeros((1, 3))), inplace=True)
+    with pytest.raises(ValueError, match="inplace=True"):
+        api.stepHam(0.01, s, api.Phase([0.1], [0.0]), inplace=True)
 
 
 @pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS + ["chain8"])
