@@ -82,6 +82,17 @@ def check_against_oracle(L, spec, o, B=48, start=11, tol=1e-11, steps=3, dt_ham=
     L.emu_observe(P(q), P(p), P(ke), P(pe), P(h), LL(B), I(st))
     oke, ope, oh = o.observe_batch(q, p)
     assert relerr(pe, ope) < tol and np.all((np.abs(h - oh) / np.maximum(1.0, np.abs(oh)))[good] <= tol * scale[good])
+    x = np.zeros((spec.m, B))
+    L.emu_coords(P(q), P(x), LL(B))
+    assert relerr(x, o.coords_batch(q)) < tol
+    v = np.zeros_like(q)
+    L.emu_from_phase(P(q), P(p), P(v), LL(B), I(st))
+    ov, _ = o.from_phase_batch(q, p)
+    assert np.all((np.abs(v - ov).max(0) / np.maximum(1.0, np.abs(ov).max(0)))[good] <= tol * scale[good])
+    kec, lag = np.zeros(B), np.zeros(B)
+    L.emu_observe_config(P(q), P(qd), P(kec), P(lag), LL(B))
+    okec, olag = o.observe_config_batch(q, qd)
+    assert relerr(kec, okec) < tol and relerr(lag, olag) < tol
     q2, p2 = q.copy(), p.copy()
     L.emu_rk4(P(q2), P(p2), LL(B), ctypes.c_double(spec.dt), steps, I(st))
     oq, op = o.rk4_steps_batch(q, p, spec.dt, steps)
@@ -95,6 +106,28 @@ def check_against_oracle(L, spec, o, B=48, start=11, tol=1e-11, steps=3, dt_ham=
     assert same[good].mean() > 0.9, float(same[good].mean())
     e3 = np.maximum(np.abs(q3 - sq).max(0), np.abs(p3 - sp).max(0)) / np.maximum(1.0, np.abs(sp).max(0))
     assert np.all(e3[same] <= 100 * tol * scale[same]), float(np.max(e3[same] / scale[same]))
+
+
+def test_evolveham_time_grid_on_host(emulate, oracle_lib):
+    """hmatrix-gsl's output loop (`for each ti: while (t < ti) step`, h carried across output times,
+    row 0 = the initial state; repeated and decreasing times do no stepping): the RKF45 body with a
+    time grid against the oracle's restatement, sub-step counts included."""
+    spec = E.get("doublePendulum")
+    o = oracle_lib.OracleSystem(spec)
+    L, _ = emulate(spec)
+    B = 40
+    q, qd = E.sample_config(spec, 3, B)
+    p = o.to_phase_batch(q, qd)
+    ts = np.array([0.0, 0.05, 0.05, 0.02, 0.2, 0.21])
+    qo, po = np.zeros((len(ts), spec.n, B)), np.zeros((len(ts), spec.n, B))
+    st, ns = np.zeros(B, np.int32), np.zeros(B, np.int32)
+    L.emu_evolve_ham(P(q), P(p), len(ts), P(ts), P(qo), P(po), LL(B), I(st), I(ns))
+    oq, op, ons = o.evolve_ham_batch(q, p, ts)
+    assert not st.any() and np.array_equal(qo[0], q) and np.array_equal(po[0], p)
+    assert np.array_equal(qo[2], qo[1]) and np.array_equal(qo[3], qo[1])
+    same = ns == ons
+    assert same.mean() > 0.9
+    assert relerr(qo[:, :, same], oq[:, :, same]) < 1e-10 and relerr(po[:, :, same], op[:, :, same]) < 1e-10
 
 
 @pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS)
