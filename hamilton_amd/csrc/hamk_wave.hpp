@@ -50,6 +50,16 @@ template <class S> struct Lds {
 // hamk::TrigCache, so the generated code and trig_pair<> work on it unchanged)
 struct TrigLds { double* s; double* c; double* ax; double* as; double* ac; };
 
+// Where the code relies on "DS operations of one wavefront execute in order" to reuse a buffer
+// without a second lds_sync (all lanes have issued their reads before any lane issues the next
+// write), the host emulation of tests/host_emulation -- one OS thread per lane -- needs a real
+// barrier; on the device this is nothing.
+#ifdef HAMK_HOST_EMULATION
+#define HAMK_LOCKSTEP() emu_wave_barrier()
+#else
+#define HAMK_LOCKSTEP() ((void)0)
+#endif
+
 // LDS written by some lanes of a wavefront and read by others of the same wavefront: DS
 // operations of one wave complete in order, so only the compiler has to be kept from moving them.
 HAMK_DEV void lds_sync() {
@@ -115,7 +125,11 @@ struct InJet2 {                                    // q_j along the common direc
 // A wavefront holds G = 64/NP trajectories; each MFMA serves one of them with all 64 lanes, the
 // accumulators of all G stay in registers: D[i][j] of block (ib, jb) is K[16 ib + i][16 jb + j],
 // lane l / register r holding i = 4 r + l/16, j = l%16 (scripts/probes/mfma_f64_layout.hip).
+#ifdef HAMK_HOST_EMULATION                                 // tests/host_emulation: g++ spelling of the same vector type
+typedef double mfma_d4 __attribute__((vector_size(32)));
+#else
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+#endif
 
 template <class S, int NP> struct SinkK {
   static constexpr int G = 64 / NP, NB = NP / 16, NBLK = NB * (NB + 1) / 2;
@@ -228,7 +242,11 @@ template <class S> struct Ctx {
   }
   int g4;            // 4 * (first lane of the group within the wavefront)
   HAMK_DEV int grp4() const { return g4; }
+#ifdef HAMK_HOST_EMULATION
+  HAMK_DEV Ctx launder() const { return *this; }
+#else
   HAMK_DEV Ctx launder() const { Ctx c = *this; asm volatile("" : "+v"(c.off), "+v"(c.li), "+v"(c.g4), "+v"(c.offw), "+v"(c.lw)); return c; }
+#endif
 };
 
 // Fill the LDS-resident sincos pairs cooperatively when every site's operand is an input.
@@ -303,6 +321,7 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
   {
 #pragma unroll
     for (int j = 0; j + 1 < N; j += 2) {
+      HAMK_LOCKSTEP();
       cA[li] = row[j];
       cB[li] = row[j + 1];
       cZ[li] = z;
@@ -326,6 +345,7 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
       if (li > j + 1) row[j + 1] = l1;
     }
     if constexpr ((N & 1) != 0) {                            // last pivot of an odd N: nothing below it
+      HAMK_LOCKSTEP();
       cA[li] = row[N - 1];
       lds_sync();
       const double dj = cA[N - 1];
@@ -357,6 +377,7 @@ HAMK_DEV double solve_back(const Ctx<S>& c, double dinv, double z) {
   const double* T = c.tile();
 #pragma unroll
   for (int k = N - 1; k >= N - R; --k) {                   // the top N mod 4 unknowns one at a time
+    HAMK_LOCKSTEP();
     cV[li] = v;
     lds_sync();
     const double vk = cV[k];
@@ -364,6 +385,7 @@ HAMK_DEV double solve_back(const Ctx<S>& c, double dinv, double z) {
   }
 #pragma unroll
   for (int kb = N - R - 4; kb >= 0; kb -= 4) {
+    HAMK_LOCKSTEP();
     cV[li] = v;
     lds_sync();
     const double p0 = cV[kb], p1 = cV[kb + 1], p2 = cV[kb + 2], v3 = cV[kb + 3];

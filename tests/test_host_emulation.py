@@ -249,3 +249,52 @@ def test_reciprocal_and_controller_power(elementary):
     e5, e6 = np.zeros_like(edge), np.zeros_like(edge)
     elementary.emu_rpow(P(edge), P(e5), P(e6), LL(edge.size))
     assert e5[0] == e5[1] and e5[2] == e5[3] and abs(e5[1] / 2.0 ** 20 - 1) < 1e-15 and abs(e6[2] * 2.0 ** (100 / 6) - 1) < 1e-15
+
+
+# ---------------------------------------------------------------------------------------------
+# the wave-cooperative kernels (n > 16; hamk_wave.hpp): one OS thread per lane, real barriers,
+# cross-lane primitives and the f64 MFMA emulated with the measured operand layout
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def emulate_wave(hamk_lib, tmp_path_factory):
+    from hamilton_amd import api
+    tmp = tmp_path_factory.mktemp("emu_wave")
+    cache = {}
+
+    def make(spec, force):
+        old = os.environ.get("HAMK_WAVE")
+        if force:
+            os.environ["HAMK_WAVE"] = "1"
+        try:
+            src = api.system_from_spec(spec).source
+        finally:
+            if force:
+                if old is None:
+                    os.environ.pop("HAMK_WAVE", None)
+                else:
+                    os.environ["HAMK_WAVE"] = old
+        assert "hamk_wave.hpp" in src
+        key = hashlib.sha1(src.encode()).hexdigest()[:16]
+        if key not in cache:
+            cpp, so = str(tmp / f"{key}.cpp"), str(tmp / f"{key}.so")
+            with open(cpp, "w") as fh:
+                fh.write(src + open(os.path.join(EMU, "wave_driver.inc")).read())
+            subprocess.check_call(["g++", "-O1", "-std=c++20", "-pthread", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-attributes",
+                                   "-Wno-psabi", "-include", os.path.join(EMU, "wave_shim.hpp"), "-I" + EMU,
+                                   "-I" + os.path.join(ROOT, "hamilton_amd", "csrc"), "-o", so, cpp])
+            cache[key] = ctypes.CDLL(so)
+        return cache[key]
+    return make
+
+
+@pytest.mark.parametrize("name,force,B", [("spring", True, 9), ("opcodeZoo", True, 6), ("threeBodyPolar", True, 5),
+                                          ("chain8", True, 5), ("chain17", False, 3), ("chain18", False, 2), ("chain32", False, 2)])
+def test_wave_kernels_on_host_match_oracle(emulate_wave, oracle_lib, name, force, B):
+    """Lane = AD direction, K = J^T M J through the (emulated) matrix-core instruction, two-pivot LDL^T
+    by LDS column broadcast with the forward substitution riding along, four-wide back substitution,
+    group-uniform RKF45 control -- against the oracle, incl. group sizes 16 and 32, padded lanes,
+    odd N (single last pivot), N mod 4 != 0 (scalar head of the back substitution), M mod 4 != 0
+    (zero-padded MFMA rows), unequal inertias, and ensembles that do not fill the last block."""
+    spec = E.get(name)
+    L = emulate_wave(spec, force)
+    check_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=B, steps=2, tol=1e-10)
