@@ -14,7 +14,7 @@
 //            four rows.  No J tile, no second pass over it.
 //   solve    LDL^T with rows distributed over lanes: per pivot, every lane drops its entry of the
 //            pivot column into an LDS buffer and reads what it needs back as broadcast loads; the
-//            forward substitution rides along; back substitution reads L^T from a padded LDS tile.
+//            forward substitution rides along; back substitution reads L^T from the packed triangle.
 //   sweep 2  Jet2<1> along the common runtime direction qd with own e_i: lane i accumulates
 //            dT/dq_i = -sum_k m_k (J qd)_k ((dJ/dq_i) qd)_k directly in the sink -- the m x n x n
 //            Hessian tensor of the reference (Hamilton.hs:222, 512 KiB per point at N = 32)
@@ -25,8 +25,9 @@
 //            instead of every lane recomputing all n of them.
 //
 // State stays SoA in HBM (q[j*B + t]); a group loads/stores one value per lane.  LDS per
-// trajectory: NP*(NP+1) (row staging, then K, then L) + 4*NP + 2*NTRIG doubles (9.75 KiB at N = 32): two 256-thread
-// blocks per CU, i.e. two wavefronts per SIMD.
+// trajectory: NP*(NP+1)/2 (row staging, then K, then L, as a packed lower triangle) + 4*NP + 2*NTRIG
+// doubles (5.6 KiB at N = 32, 45 KiB per 256-thread block).  Two wavefronts per SIMD by registers
+// (228 VGPRs); a third was measured and does not pay -- the LDS unit is the busy resource.
 #pragma once
 #include "hamk_device.hpp"
 
@@ -42,7 +43,12 @@ template <int N> struct Geo {
 template <class S> struct Lds {
   static constexpr int NP = Geo<S::N>::NP;
   static constexpr int NT = (S::NTRIG_F > 0) ? S::NTRIG_F : 1;
-  static constexpr int TILE = NP * (NP + 1);            // K (row-major, stride NP+1), then L
+  // K, then L, as a packed LOWER TRIANGLE: entry (i, j), j <= i, at i (i+1)/2 + j.  Half the footprint
+  // of a padded square tile (5.6 instead of 9.75 KiB per trajectory at NP = 32: three 256-thread
+  // blocks per CU instead of two); row k, read across the lanes in the back substitution, is
+  // contiguous.  The first 4*NP doubles double as the staging rows of sweep 1.
+  static constexpr int TILE = NP * (NP + 1) / 2;
+  HAMK_DEV static constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
   static constexpr int PER_TRAJ = TILE + 4 * NP + 2 * NT;   // + 2*NP scratch row (sincos exchange, pivot column + z) + two all-gather buffers + sincos pairs
 };
 
@@ -192,10 +198,13 @@ template <class S, int NP> struct SinkK {
     }
     lds_sync();                                            // the next rows overwrite the staging area
   }
-  // K of every trajectory of the wave into its tile (row-major, stride NP+1), both triangles
+  // K of every trajectory of the wave into its packed lower triangle.  Block (ib, jb), ib <= jb, holds
+  // K[16 ib + 4 r + kq][16 jb + l16]; an entry above the diagonal goes to its mirror position (K is
+  // symmetric, so in a diagonal block two lanes write the same number to the same place) -- no
+  // predicated stores, which would cost an exec-mask round trip each.
   HAMK_DEV void store(double* smem, int offw, int lw) const {
-    double* direct = smem + offw + (lw >> 4) * (NP + 1) + (lw & 15);
-    double* transp = smem + offw + (lw & 15) * (NP + 1) + (lw >> 4);
+    const int kq_ = lw >> 4, l16 = lw & 15;
+    double* base = smem + offw;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -204,9 +213,9 @@ template <class S, int NP> struct SinkK {
         for (int jb = ib; jb < NB; ++jb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const double kv = acc[g][blk_of(ib, jb)][r];
-            direct[g * PER + (16 * ib + 4 * r) * (NP + 1) + 16 * jb] = kv;
-            if (ib != jb) transp[g * PER + (16 * jb) * (NP + 1) + 16 * ib + 4 * r] = kv;
+            const int row = 16 * ib + 4 * r + kq_, col = 16 * jb + l16;
+            const int hi = (ib != jb || col > row) ? col : row, lo = (ib != jb || col > row) ? row : col;
+            base[g * PER + hi * (hi + 1) / 2 + lo] = acc[g][blk_of(ib, jb)][r];
           }
     }
   }
@@ -297,11 +306,11 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
     const Jet1<1> u = S::template coords_sink_u<Jet1<1>, TRIG1>(qj, tl, tu, sink);
     gU = u.d[0]; U = u.v;
     sink.finish();
-    sink.store(c.smem, c.offw, c.lw);                       // accumulators -> full symmetric K in the tiles
+    sink.store(c.smem, c.offw, c.lw);                       // accumulators -> K in the packed triangles
   }
   lds_sync();
 #pragma unroll
-  for (int b = 0; b < N; ++b) row[b] = c.tile()[li * (NP + 1) + b];   // each lane takes its row
+  for (int b = 0; b < N; ++b) row[b] = c.tile()[li * (li + 1) / 2 + b];   // each lane takes its row (entries b > li: never used)
   // LDL^T, right-looking, TWO pivots per LDS round trip: the serial chain (write column, read it
   // back, reciprocal, update) is what bounds this phase, not its flops.  With a = K[j][j],
   // b = K[j+1][j], c = K[j+1][j+1] (all before pivot j), l = b/a:
@@ -311,6 +320,10 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
   // were before the pair; the two reciprocals (1/a, 1/det) are independent.
   bool ok = true;
   dinv = 0.0;
+  // L[li][j] goes to the packed triangle the moment it is final (row[j] is dead from then on: fewer
+  // live registers); lanes at or above the pivot store to their own diagonal slot instead -- L has a
+  // unit diagonal, nobody reads that slot -- so the store needs no exec-mask round trip.
+  double* Lrow = c.tile() + li * (li + 1) / 2;
   double* cA = c.rowbuf();                                 // [NP] column j   (the exchange buffer is free here,
   double* cB = c.rowbuf() + NP;                            // [NP] column j+1   and so is the qd gather buffer)
   double* cZ = c.gb();                                     // [NP] z
@@ -341,8 +354,8 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
       const double al = fma(-l1, l, l0);
 #pragma unroll
       for (int k = j + 2; k < N; ++k) row[k] = fma(-al, cA[k], fma(-l1, cB[k], row[k]));   // (entries k > li are never read)
-      if (li > j) row[j] = l0;
-      if (li > j + 1) row[j + 1] = l1;
+      Lrow[(li > j) ? j : li] = l0;
+      Lrow[(li > j + 1) ? j + 1 : li] = l1;
     }
     if constexpr ((N & 1) != 0) {                            // last pivot of an odd N: nothing below it
       HAMK_LOCKSTEP();
@@ -354,12 +367,7 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
     }
   }
   if (!ok && li < N) st |= ST_SINGULAR;                    // no pivoting fallback in the wave kernels
-  // L over K in the tile (stride NP+1: conflict-free for these row writes and for the column
-  // reads of the back substitution)
-  lds_sync();
-#pragma unroll
-  for (int j = 0; j < N; ++j) c.tile()[li * (NP + 1) + j] = row[j];
-  lds_sync();
+  lds_sync();                                              // L is complete in the triangle
 }
 
 // Finish K v = rhs after `factor` (which left z = L^-1 rhs): D y = z, L^T v = y; returns v_li.
@@ -367,7 +375,8 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
 // resolves the 4 x 4 triangle at the head of the block itself (six FMAs on broadcast reads of L).
 template <class S>
 HAMK_DEV double solve_back(const Ctx<S>& c, double dinv, double z) {
-  constexpr int N = S::N, NP = Ctx<S>::NP, R = N & 3, W = NP + 1;
+  constexpr int N = S::N, R = N & 3;
+  auto tri = [](int i, int j) { return i * (i + 1) / 2 + j; };
   const int li = c.li;
 #ifdef HAMK_PROBE_SKIP_SOLVE
   return z * dinv;
@@ -381,7 +390,7 @@ HAMK_DEV double solve_back(const Ctx<S>& c, double dinv, double z) {
     cV[li] = v;
     lds_sync();
     const double vk = cV[k];
-    if (li < k) v = fma(-T[k * W + li], vk, v);
+    if (li < k) v = fma(-T[tri(k, li)], vk, v);
   }
 #pragma unroll
   for (int kb = N - R - 4; kb >= 0; kb -= 4) {
@@ -389,14 +398,14 @@ HAMK_DEV double solve_back(const Ctx<S>& c, double dinv, double z) {
     cV[li] = v;
     lds_sync();
     const double p0 = cV[kb], p1 = cV[kb + 1], p2 = cV[kb + 2], v3 = cV[kb + 3];
-    const double v2 = fma(-T[(kb + 3) * W + kb + 2], v3, p2);
-    const double v1 = fma(-T[(kb + 2) * W + kb + 1], v2, fma(-T[(kb + 3) * W + kb + 1], v3, p1));
-    const double v0 = fma(-T[(kb + 1) * W + kb], v1, fma(-T[(kb + 2) * W + kb], v2, fma(-T[(kb + 3) * W + kb], v3, p0)));
+    const double v2 = fma(-T[tri(kb + 3, kb + 2)], v3, p2);
+    const double v1 = fma(-T[tri(kb + 2, kb + 1)], v2, fma(-T[tri(kb + 3, kb + 1)], v3, p1));
+    const double v0 = fma(-T[tri(kb + 1, kb)], v1, fma(-T[tri(kb + 2, kb)], v2, fma(-T[tri(kb + 3, kb)], v3, p0)));
     if (li < kb) {
-      v = fma(-T[(kb + 3) * W + li], v3, v);
-      v = fma(-T[(kb + 2) * W + li], v2, v);
-      v = fma(-T[(kb + 1) * W + li], v1, v);
-      v = fma(-T[kb * W + li], v0, v);
+      v = fma(-T[tri(kb + 3, li)], v3, v);
+      v = fma(-T[tri(kb + 2, li)], v2, v);
+      v = fma(-T[tri(kb + 1, li)], v1, v);
+      v = fma(-T[tri(kb, li)], v0, v);
     } else {
       if (li == kb) v = v0;
       if (li == kb + 1) v = v1;
