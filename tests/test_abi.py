@@ -68,6 +68,16 @@ def test_malformed_tapes_are_rejected(hamk_lib):
     assert rc == _abi.HAMK_ERR_INVALID
 
 
+def test_sizes_beyond_the_kernels_are_refused(hamk_lib):
+    """n <= 32 (m <= 64 on the wave path): larger systems get HAMK_ERR_UNSUPPORTED and a message, not
+    a compile that never ends."""
+    from hamilton_amd import _abi, api
+    spec = E.chain(33)
+    with pytest.raises(api.HamkError) as e:
+        api.system_from_spec(spec)
+    assert e.value.code == _abi.HAMK_ERR_UNSUPPORTED and "supported sizes" in str(e.value)
+
+
 def test_calls_fail_loudly_without_a_gpu(hamk_lib):
     """There is no CPU fallback: on a box without a GPU a compute call returns an error code."""
     from hamilton_amd import api
