@@ -44,8 +44,7 @@ template <class S> struct Lds {
   static constexpr int NP = Geo<S::N>::NP;
   static constexpr int NT = (S::NTRIG_F > 0) ? S::NTRIG_F : 1;
   // K, then L, as a packed LOWER TRIANGLE: entry (i, j), j <= i, at i (i+1)/2 + j.  Half the footprint
-  // of a padded square tile (5.6 instead of 9.75 KiB per trajectory at NP = 32: three 256-thread
-  // blocks per CU instead of two); row k, read across the lanes in the back substitution, is
+  // of a padded square tile (5.6 instead of 9.75 KiB per trajectory at NP = 32); row k, read across the lanes in the back substitution, is
   // contiguous.  The first 4*NP doubles double as the staging rows of sweep 1.
   static constexpr int TILE = NP * (NP + 1) / 2;
   HAMK_DEV static constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
@@ -280,7 +279,7 @@ template <class S> HAMK_DEV void cooperative_trig(const Ctx<S>& c, double qi) {
 
 // Sweep 1 (with K accumulated in the sink) + LDL^T, with the forward substitution of one right-hand
 // side riding along.  On return: `row` holds L[li][j] (j < li), `dinv` = 1/d_li, z = (L^-1 rhs)_li;
-// gU = dU/dq_li; the tile holds L (row-major, stride NP+1).
+// gU = dU/dq_li; the packed triangle holds L.
 //
 // Rows are distributed over lanes and only the lower triangle is kept (lane i: K[i][k], k <= i).
 // The update of pivot j, K[i][k] -= l_ij K[k][j], needs column j as every lane k holds it in its
