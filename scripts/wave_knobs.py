@@ -1,3 +1,4 @@
+"""GPU: the wave-cooperative RK4 kernel at 1, 2 (default) and 3 wavefronts per SIMD (HAMK_RK4_WAVES)."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -1,3 +1,5 @@
+"""GPU: two launches of the wave-cooperative RK4 kernel (B = 65536, 4 steps) -- the command rocprofv3's
+kernel-trace / PMC passes are wrapped around (profiles/r01_wave_pmc.json, r01_wave_kernel_stats.csv)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
