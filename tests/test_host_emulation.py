@@ -130,6 +130,28 @@ def test_evolveham_time_grid_on_host(emulate, oracle_lib):
     assert relerr(qo[:, :, same], oq[:, :, same]) < 1e-10 and relerr(po[:, :, same], op[:, :, same]) < 1e-10
 
 
+def test_device_rkf45_step_is_fifth_order(emulate, oracle_lib):
+    """The device code's Fehlberg tableau by what defines it: one forced step of size h is the
+    5th-order solution, its error against a converged reference falls as h^6 (tests/test_rkf45_order.py
+    does the same for the oracle -- neither takes the other's word for the coefficients)."""
+    spec = E.get("doublePendulum")
+    o = oracle_lib.OracleSystem(spec)
+    L, _ = emulate(spec)
+    B = 16
+    q, qd = E.sample_config(spec, 21, B)
+    p = o.to_phase_batch(q, qd)
+    hs = [0.2 / 2 ** k for k in range(7)]
+    errs = []
+    for h in hs:
+        tq, tp = o.rk4_steps_batch(q, p, h / 4000, 4000)
+        q1, p1, st, ns = q.copy(), p.copy(), np.zeros(B, np.int32), np.zeros(B, np.int32)
+        L.emu_single_rkf45_step(P(q1), P(p1), LL(B), ctypes.c_double(h), I(st), I(ns))
+        assert np.all(ns == 1) and not st.any()
+        errs.append(max(np.abs(q1 - tq).max(), np.abs(p1 - tp).max()))
+    ratios = [errs[k] / errs[k + 1] for k in range(len(hs) - 1) if 2e-12 < errs[k + 1] and errs[k] < 1e-6]
+    assert ratios and all(40 < r < 100 for r in ratios), (errs, ratios)
+
+
 @pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS)
 def test_device_code_on_host_matches_oracle(emulate, oracle_lib, name):
     spec = E.get(name)
