@@ -173,7 +173,7 @@ def test_ad_strategies_and_stage_loops_on_host(emulate, oracle_lib, name, mode):
         check_against_oracle(L, spec, o, B=24)
 
 
-@pytest.mark.parametrize("name", ["chain8", "chain12"])
+@pytest.mark.parametrize("name", ["chain8", "chain12", "chain16"])
 def test_mid_size_systems_on_host(emulate, oracle_lib, name):
     spec = E.get(name)
     L, src = emulate(spec)
