@@ -355,7 +355,9 @@ HAMK_DEV void sincos_f64(double x, double& s, double& c) {
   c = __hiloint2double((int)((unsigned int)__double2hiint(c0) ^ (((q + 1u) << 30) & 0x80000000u)), __double2loint(c0));
   // huge, NaN, Inf: library path.  Two calls, not ::sincos(x, &s, &c): the pointer form leaves an
   // address-taken stack slot (scratch) in every kernel that inlines this.
+#ifndef HAMK_PROBE_NO_SLOWPATH                             // scripts/isa_stats.py: count the fast path alone
   if (!(fabs(x) < 1.6e6)) { s = ::sin(x); c = ::cos(x); }
+#endif
 }
 
 // 1/d for normal-range d: hardware estimate + two Newton steps (5 instructions instead
@@ -416,7 +418,9 @@ HAMK_DEV void sincos_incr(double x, double xa, double sa, double ca, double& s, 
   const double cm1 = z * pc;                              // cos(delta) - 1
   s = sa + fma(sa, cm1, ca * sd);
   c = ca + fma(ca, cm1, -(sa * sd));
+#ifndef HAMK_PROBE_NO_SLOWPATH
   if (!(fabs(d) < 0.125)) sincos_f64(x, s, c);            // far from the anchor (or NaN): full evaluation
+#endif
 }
 
 template <int MODE, class TC> HAMK_DEV void trig_pair(double x, TC& tc, int k) {
