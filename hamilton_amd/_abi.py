@@ -27,7 +27,7 @@ LIB_PATH = os.path.join(_HERE, "libhamk.so")
 HAMK_OK = 0
 HAMK_ERR_INVALID, HAMK_ERR_TAPE, HAMK_ERR_COMPILE, HAMK_ERR_HIP, HAMK_ERR_NODEVICE, HAMK_ERR_UNSUPPORTED = \
     -1, -2, -3, -4, -5, -6
-ST_SINGULAR, ST_NONFINITE, ST_UNDERFLOW, ST_MAXSTEPS = 1, 2, 4, 8
+ST_SINGULAR, ST_NONFINITE, ST_UNDERFLOW, ST_MAXSTEPS, ST_DRIFT = 1, 2, 4, 8, 16
 MEM_HOST, MEM_DEVICE = 0, 1
 
 _dp = ctypes.c_void_p          # double*  (host or device address)
@@ -55,6 +55,14 @@ SIGNATURES = {
     "hamk_observe_config_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _dp, _dp, _i32]),
     "hamk_hameqs_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _dp, _dp, _ip, _i32]),
     "hamk_rk4_steps": (ctypes.c_int, [_h, _i64, _dp, _dp, _f64, _i32, _ip, _i32]),
+    "hamk_rk4_steps_checked": (ctypes.c_int, [_h, _i64, _dp, _dp, _f64, _i32, _f64, _ip, _i32]),
+    "hamk_system_set_gsl_api": (ctypes.c_int, [_h, _i32]),
+    "hamk_system_get_gsl_api": (_i32, [_h]),
+    "hamk_system_code_object": (_i64, [_h, _i32, ctypes.c_void_p, _i64]),
+    "hamk_checkpoint_write": (ctypes.c_int, [ctypes.c_char_p, _i32, _i64, _dp, _dp, _i32, _i64, ctypes.c_uint64, _f64]),
+    "hamk_checkpoint_info": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_i32), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
+                                            ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(_f64)]),
+    "hamk_checkpoint_read": (ctypes.c_int, [ctypes.c_char_p, _i32, _i64, _dp, _dp, _i32]),
     "hamk_step_ham_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _f64, _ip, _ip, _i32]),
     "hamk_evolve_ham_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _i32, ctypes.POINTER(ctypes.c_double), _dp, _dp,
                                              _f64, _f64, _f64, _ip, _ip, _i32]),

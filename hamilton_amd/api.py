@@ -22,12 +22,13 @@ from __future__ import annotations
 
 import ctypes
 from typing import Callable, List, Optional, Sequence
+import contextlib
 
 import numpy as np
 
 from . import _abi
 from . import tracer as T
-from ._abi import HamkError, MEM_DEVICE, MEM_HOST, ST_SINGULAR
+from ._abi import HamkError, MEM_DEVICE, MEM_HOST, ST_DRIFT, ST_SINGULAR
 
 try:  # torch is plumbing (device memory, streams); the package works without it on host arrays
     import torch
@@ -209,12 +210,40 @@ class System:
     def synchronize(self):
         _abi.check(_abi.lib().hamk_synchronize(self._h))
 
-    def _use_stream_of(self, arr: _Arr):
+    @contextlib.contextmanager
+    def _on(self, arr: _Arr):
+        """Run the enclosed libhamk call where `arr` lives: a handle launches on the calling thread's
+        CURRENT device (hamk.h), so tensors of cuda:1 need cuda:1 current for the duration of the
+        call -- on torch's current stream of that device.  The handle keeps one module / staging
+        state per device, so alternating devices costs nothing after the first use of each."""
         if arr.device:
-            stream = torch.cuda.current_stream(arr.a.device).cuda_stream
-            _abi.check(_abi.lib().hamk_set_stream(self._h, ctypes.c_void_p(stream)))
+            with torch.cuda.device(arr.a.device):
+                stream = torch.cuda.current_stream(arr.a.device).cuda_stream
+                _abi.check(_abi.lib().hamk_set_stream(self._h, ctypes.c_void_p(stream)))
+                yield
         else:
             _abi.check(_abi.lib().hamk_set_stream(self._h, None))
+            yield
+
+    @property
+    def gsl_api(self) -> int:
+        """Which binding of hmatrix-gsl's gsl-ode.c stepHam / evolveHam follow: 2 = gsl_odeiv2
+        driver (its default build, this library's default), 1 = old gsl_odeiv (-DGSLODE1).  hamk.h."""
+        return int(_abi.lib().hamk_system_get_gsl_api(self._h))
+
+    @gsl_api.setter
+    def gsl_api(self, api: int):
+        _abi.check(_abi.lib().hamk_system_set_gsl_api(self._h, int(api)))
+
+    def code_object(self, which: int = 0) -> bytes:
+        """The gfx950 ELF the kernels are loaded from (which = 1: the build without MachineLICM)."""
+        L = _abi.lib()
+        n = int(L.hamk_system_code_object(self._h, which, None, 0))
+        if n == 0:
+            return b""
+        buf = ctypes.create_string_buffer(n)
+        L.hamk_system_code_object(self._h, which, buf, n)
+        return buf.raw
 
     def _after(self, status, single: bool, what: str):
         self.last_status = status
@@ -253,8 +282,8 @@ def underlyingPos(s: System, q):
     """underlyingPos (Hamilton.hs:174-178)."""
     qa = _Arr(q, s.n, "positions")
     x = qa.like(s.m)
-    s._use_stream_of(qa)
-    _abi.check(_abi.lib().hamk_coords_batch(s._h, qa.B, qa.ptr, _ptr(x), qa.mem))
+    with s._on(qa):
+        _abi.check(_abi.lib().hamk_coords_batch(s._h, qa.B, qa.ptr, _ptr(x), qa.mem))
     return _shape_out(x, qa.single)
 
 
@@ -262,8 +291,8 @@ def momenta(s: System, c: Config):
     """momenta (Hamilton.hs:262-269)."""
     qa, va = _pair(c.positions, "positions", c.velocities, "velocities", s.n)
     p = qa.like(s.n)
-    s._use_stream_of(qa)
-    _abi.check(_abi.lib().hamk_to_phase_batch(s._h, qa.B, qa.ptr, va.ptr, _ptr(p), qa.mem))
+    with s._on(qa):
+        _abi.check(_abi.lib().hamk_to_phase_batch(s._h, qa.B, qa.ptr, va.ptr, _ptr(p), qa.mem))
     return _shape_out(p, qa.single)
 
 
@@ -276,8 +305,8 @@ def velocities(s: System, ph: Phase):
     """velocities (Hamilton.hs:316-324)."""
     qa, pa = _pair(ph.positions, "positions", ph.momenta, "momenta", s.n)
     v, st = qa.like(s.n), qa.like(None, "i4")
-    s._use_stream_of(qa)
-    _abi.check(_abi.lib().hamk_from_phase_batch(s._h, qa.B, qa.ptr, pa.ptr, _ptr(v), _ptr(st), qa.mem))
+    with s._on(qa):
+        _abi.check(_abi.lib().hamk_from_phase_batch(s._h, qa.B, qa.ptr, pa.ptr, _ptr(v), _ptr(st), qa.mem))
     s._after(st, qa.single, "velocities")
     return _shape_out(v, qa.single)
 
@@ -295,9 +324,9 @@ def _observe(s: System, q, p, which: str):
     out, st = qa.like(None), qa.like(None, "i4")
     ptrs = {"ke": None, "pe": None, "h": None}
     ptrs[which] = _ptr(out)
-    s._use_stream_of(qa)
-    _abi.check(_abi.lib().hamk_observe_batch(s._h, qa.B, qa.ptr, pa.ptr if pa is not None else None,
-                                             ptrs["ke"], ptrs["pe"], ptrs["h"], _ptr(st), qa.mem))
+    with s._on(qa):
+        _abi.check(_abi.lib().hamk_observe_batch(s._h, qa.B, qa.ptr, pa.ptr if pa is not None else None,
+                                                 ptrs["ke"], ptrs["pe"], ptrs["h"], _ptr(st), qa.mem))
     if which != "pe":
         s._after(st, qa.single, which)
     return _shape_out(out, qa.single)
@@ -321,9 +350,9 @@ def pe(s: System, q):
 def _observe_config(s: System, c: Config, which: str):
     qa, va = _pair(c.positions, "positions", c.velocities, "velocities", s.n)
     out = qa.like(None)
-    s._use_stream_of(qa)
-    _abi.check(_abi.lib().hamk_observe_config_batch(
-        s._h, qa.B, qa.ptr, va.ptr, _ptr(out) if which == "ke" else None, _ptr(out) if which == "lag" else None, qa.mem))
+    with s._on(qa):
+        _abi.check(_abi.lib().hamk_observe_config_batch(
+            s._h, qa.B, qa.ptr, va.ptr, _ptr(out) if which == "ke" else None, _ptr(out) if which == "lag" else None, qa.mem))
     return _shape_out(out, qa.single)
 
 
@@ -341,8 +370,8 @@ def hamEqs(s: System, ph: Phase):
     """hamEqs (Hamilton.hs:370-387): returns (dH/dp, -dH/dq)."""
     qa, pa = _pair(ph.positions, "positions", ph.momenta, "momenta", s.n)
     dq, dp, st = qa.like(s.n), qa.like(s.n), qa.like(None, "i4")
-    s._use_stream_of(qa)
-    _abi.check(_abi.lib().hamk_hameqs_batch(s._h, qa.B, qa.ptr, pa.ptr, _ptr(dq), _ptr(dp), _ptr(st), qa.mem))
+    with s._on(qa):
+        _abi.check(_abi.lib().hamk_hameqs_batch(s._h, qa.B, qa.ptr, pa.ptr, _ptr(dq), _ptr(dp), _ptr(st), qa.mem))
     s._after(st, qa.single, "hamEqs")
     return _shape_out(dq, qa.single), _shape_out(dp, qa.single)
 
@@ -358,8 +387,8 @@ def stepHam(r: float, s: System, ph: Phase, inplace: bool = False) -> Phase:
         _in_place(qa, ph.positions, "positions"); _in_place(pa, ph.momenta, "momenta")
     q, p = (qa.a, pa.a) if inplace else (qa.clone(), pa.clone())
     st, ns = qa.like(None, "i4"), qa.like(None, "i4")
-    s._use_stream_of(qa)
-    _abi.check(_abi.lib().hamk_step_ham_batch(s._h, qa.B, _ptr(q), _ptr(p), float(r), _ptr(st), _ptr(ns), qa.mem))
+    with s._on(qa):
+        _abi.check(_abi.lib().hamk_step_ham_batch(s._h, qa.B, _ptr(q), _ptr(p), float(r), _ptr(st), _ptr(ns), qa.mem))
     s.last_nsub = ns
     s._after(st, qa.single, "stepHam")
     return Phase(_shape_out(q, qa.single), _shape_out(p, qa.single))
@@ -374,10 +403,10 @@ def evolveHam(s: System, p0: Phase, ts, h0: float = 0.0, eps_abs: float = 0.0, e
     nt = len(ts)
     qo, po = qa.like(s.n, lead=(nt,)), qa.like(s.n, lead=(nt,))
     st, ns = qa.like(None, "i4"), qa.like(None, "i4")
-    s._use_stream_of(qa)
-    _abi.check(_abi.lib().hamk_evolve_ham_batch(
-        s._h, qa.B, qa.ptr, pa.ptr, nt, ts.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _ptr(qo), _ptr(po),
-        float(h0), float(eps_abs), float(eps_rel), _ptr(st), _ptr(ns), qa.mem))
+    with s._on(qa):
+        _abi.check(_abi.lib().hamk_evolve_ham_batch(
+            s._h, qa.B, qa.ptr, pa.ptr, nt, ts.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _ptr(qo), _ptr(po),
+            float(h0), float(eps_abs), float(eps_rel), _ptr(st), _ptr(ns), qa.mem))
     s.last_nsub = ns
     s._after(st, qa.single, "evolveHam")
     return [Phase(_shape_out(qo[r], qa.single), _shape_out(po[r], qa.single)) for r in range(nt)]
@@ -408,16 +437,56 @@ def evolveHamC_(s: System, c0: Config, ts: Sequence[float]) -> List[Config]:
     return [fromPhase(s, ph) for ph in evolveHam_(s, toPhase(s, c0), ts)]
 
 
-def rk4Steps(dt: float, nsteps: int, s: System, ph: Phase, inplace: bool = False) -> Phase:
+def rk4Steps(dt: float, nsteps: int, s: System, ph: Phase, inplace: bool = False, drift_tol: float = 0.0) -> Phase:
     """Classic fixed-step RK4 over hamEqs -- named by BASELINE.json's north_star; the
     reference has no fixed-step integrator.  inplace=True advances the
-    given device/host arrays without copying (bench path)."""
+    given device/host arrays without copying (bench path).  drift_tol > 0: the launch
+    checks its own energy invariant and sets ST_DRIFT in `System.last_status` where
+    |H_exit - H_entry| > drift_tol * max(1, |H_entry|) (hamk_rk4_steps_checked)."""
     qa, pa = _pair(ph.positions, "positions", ph.momenta, "momenta", s.n)
     if inplace:
         _in_place(qa, ph.positions, "positions"); _in_place(pa, ph.momenta, "momenta")
     q, p = (qa.a, pa.a) if inplace else (qa.clone(), pa.clone())
     st = qa.like(None, "i4")
-    s._use_stream_of(qa)
-    _abi.check(_abi.lib().hamk_rk4_steps(s._h, qa.B, _ptr(q), _ptr(p), float(dt), int(nsteps), _ptr(st), qa.mem))
+    with s._on(qa):
+        _abi.check(_abi.lib().hamk_rk4_steps_checked(s._h, qa.B, _ptr(q), _ptr(p), float(dt), int(nsteps), float(drift_tol),
+                                                     _ptr(st), qa.mem))
     s.last_status = st
     return Phase(_shape_out(q, qa.single), _shape_out(p, qa.single))
+
+
+# ---------------------------------------------------------------------------------------
+# ensemble checkpoint (SURVEY.md section 8 f-4): device- or host-resident state <-> one flat file
+# ---------------------------------------------------------------------------------------
+def saveCheckpoint(path: str, ph: Phase, n: int, steps_done: int = 0, seed: int = 0, t: float = 0.0) -> None:
+    """hamk_checkpoint_write: q[n][B], p[n][B] (numpy or torch CUDA tensors) + bookkeeping."""
+    qa, pa = _pair(ph.positions, "positions", ph.momenta, "momenta", n)
+    if qa.device:
+        torch.cuda.current_stream(qa.a.device).synchronize()     # the copy out runs on the null stream
+    ctx = torch.cuda.device(qa.a.device) if qa.device else contextlib.nullcontext()
+    with ctx:
+        _abi.check(_abi.lib().hamk_checkpoint_write(str(path).encode(), n, qa.B, qa.ptr, pa.ptr, qa.mem,
+                                                    int(steps_done), int(seed), float(t)))
+
+
+def checkpointInfo(path: str) -> dict:
+    n, B, st, seed, t = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_uint64(), ctypes.c_double()
+    _abi.check(_abi.lib().hamk_checkpoint_info(str(path).encode(), ctypes.byref(n), ctypes.byref(B), ctypes.byref(st),
+                                               ctypes.byref(seed), ctypes.byref(t)))
+    return {"n": n.value, "B": B.value, "steps_done": st.value, "seed": seed.value, "t": t.value}
+
+
+def loadCheckpoint(path: str, device=None):
+    """Returns (Phase, info).  device=None: numpy arrays; a torch device: CUDA tensors on it."""
+    info = checkpointInfo(path)
+    n, B = info["n"], info["B"]
+    if device is None:
+        q, p = np.empty((n, B)), np.empty((n, B))
+        _abi.check(_abi.lib().hamk_checkpoint_read(str(path).encode(), n, B, q.ctypes.data, p.ctypes.data, MEM_HOST))
+    else:
+        dev = torch.device(device)
+        q = torch.empty((n, B), dtype=torch.float64, device=dev)
+        p = torch.empty((n, B), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _abi.check(_abi.lib().hamk_checkpoint_read(str(path).encode(), n, B, q.data_ptr(), p.data_ptr(), MEM_DEVICE))
+    return Phase(q, p), info

@@ -8,8 +8,10 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <initializer_list>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -49,20 +51,15 @@ enum KernelId { K_RK4, K_HAMEQS, K_COORDS, K_TO_PHASE, K_FROM_PHASE, K_OBSERVE, 
 static const char* kKernelNames[K__COUNT] = {"hamk_rk4_steps_k", "hamk_hameqs_k",  "hamk_coords_k",         "hamk_to_phase_k",
                                              "hamk_from_phase_k", "hamk_observe_k", "hamk_observe_config_k", "hamk_rkf45_k"};
 
-struct hamk_system {
-  SystemDesc desc;
-  std::string source;
-  std::vector<char> code;      // gfx950 code object (default options)
-  std::vector<char> code2;     // the same source built without MachineLICM; empty unless some kernel is taken from it
-  bool use2[K__COUNT] = {};    // kernel k comes from code2 (it spills no / fewer SGPRs there)
-  std::string build_log;
-  std::string build_info;      // per kernel: which build it comes from, bytes, spilled SGPRs
-  // lazily bound to a device
+// What a handle owns on ONE device.  A handle used from several devices (one process driving every
+// GPU of a node, or a torch program whose tensors live on cuda:1 while cuda:0 is current) keeps one
+// of these per device: modules stay loaded and staging buffers stay allocated when the calls
+// alternate between devices.
+struct DevState {
   int device = -1;
   hipModule_t module = nullptr;
   hipModule_t module2 = nullptr;
   hipFunction_t fn[K__COUNT] = {};
-  hipStream_t stream = nullptr;
   // grow-only device staging for HAMK_MEM_HOST calls (slot i serves the i-th staged array of a
   // call): the reference's own usage pattern is one small stepHam per frame (Examples.hs:429),
   // where a hipMalloc/hipFree pair per array per call would dominate
@@ -82,6 +79,34 @@ struct hamk_system {
   size_t d_ts_cap = 0;
   std::vector<double> h_ts;
   bool self_checked = false;
+  int code_generation = -1;     // hamk_system::generation the loaded modules were built from
+  void unload() {
+    if (module) { hipModuleUnload(module); module = nullptr; }
+    if (module2) { hipModuleUnload(module2); module2 = nullptr; }
+  }
+  void release() {
+    unload();
+    if (d_ts) { hipFree(d_ts); d_ts = nullptr; d_ts_cap = 0; }
+    for (void*& b : stage_buf) if (b) { hipFree(b); b = nullptr; }
+    stage_cap.assign(stage_cap.size(), 0);
+    if (pin) { hipHostFree(pin); pin = pin_dev = nullptr; }
+  }
+};
+
+struct hamk_system {
+  SystemDesc desc;
+  std::string source;
+  std::vector<char> code;      // gfx950 code object (default options)
+  std::vector<char> code2;     // the same source built without MachineLICM; empty unless some kernel is taken from it
+  bool use2[K__COUNT] = {};    // kernel k comes from code2 (it spills no / fewer SGPRs there)
+  std::string build_log;
+  std::string build_info;      // per kernel: which build it comes from, bytes, spilled SGPRs
+  int generation = 0;          // bumped whenever `code` is rebuilt (the self-check's recovery path)
+  // lazily bound to the calling thread's current device, one DevState per device ever used
+  std::vector<DevState*> devs;
+  DevState* cur = nullptr;
+  hipStream_t stream = nullptr;
+  int gsl_api = 2;             // which binding of hmatrix-gsl's gsl-ode.c stepHam/evolveHam follow (hamk.h)
   int self_check_rebuilds = 0;
 };
 
@@ -90,8 +115,84 @@ struct hamk_system {
 // ---------------------------------------------------------------------------
 // On-disk cache of compiled code objects, keyed by everything that determines them (generated
 // source, both device headers, the option list, the hiprtc version): the same System built twice
-// -- another process, another rank of the same job -- costs one compile.  HAMK_CACHE_DIR overrides
-// the location ($XDG_CACHE_HOME/hamk, else /tmp/hamk-cache-<uid>); HAMK_CACHE=0 disables it.
+// -- another process, another rank of the same job -- costs one compile.
+// Location: HAMK_CACHE_DIR, else $XDG_CACHE_HOME/hamk, else $HOME/.cache/hamk; HAMK_CACHE=0 disables
+// it.  What is loaded from it runs on the GPU inside this process, so the directory must be a real
+// directory (lstat: not a symlink) OWNED BY THE CALLER with no group/other permission bits -- a
+// pre-created or world-writable directory disables the cache instead of being trusted -- and every
+// entry carries a trailer (magic, payload size, SHA-256 of the full key material, SHA-256 of the
+// payload) that is verified before use: a 64-bit file-name collision, a truncated write or a stale
+// file yields a recompile, never someone else's kernels.
+namespace {
+struct Sha256 {
+  uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+  unsigned char buf[64];
+  size_t fill = 0;
+  uint64_t total = 0;
+  static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+  void block(const unsigned char* p) {
+    static const uint32_t K[64] = {
+        0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u,
+        0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu,
+        0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau, 0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u,
+        0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u,
+        0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u, 0x19a4c116u, 0x1e376c08u,
+        0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u,
+        0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+    for (int i = 16; i < 64; ++i) {
+      const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+      const uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; ++i) {
+      const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25), ch = (e & f) ^ (~e & g);
+      const uint32_t t1 = hh + S1 + ch + K[i] + w[i];
+      const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22), mj = (a & b) ^ (a & c) ^ (b & c);
+      const uint32_t t2 = S0 + mj;
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  void update(const void* data, size_t n) {
+    const unsigned char* p = (const unsigned char*)data;
+    total += n;
+    while (n) {
+      const size_t k = std::min(n, sizeof buf - fill);
+      std::memcpy(buf + fill, p, k);
+      fill += k; p += k; n -= k;
+      if (fill == 64) { block(buf); fill = 0; }
+    }
+  }
+  void finish(unsigned char out[32]) {
+    const uint64_t bits = total * 8;
+    const unsigned char one = 0x80, zero = 0;
+    update(&one, 1);
+    while (fill != 56) update(&zero, 1);
+    unsigned char len[8];
+    for (int i = 0; i < 8; ++i) len[i] = (unsigned char)(bits >> (56 - 8 * i));
+    update(len, 8);
+    for (int i = 0; i < 8; ++i) { out[4 * i] = (unsigned char)(h[i] >> 24); out[4 * i + 1] = (unsigned char)(h[i] >> 16); out[4 * i + 2] = (unsigned char)(h[i] >> 8); out[4 * i + 3] = (unsigned char)h[i]; }
+  }
+};
+
+constexpr char kCacheMagic[8] = {'H', 'A', 'M', 'K', 'C', 'O', '0', '2'};
+struct CacheTrailer {          // appended to the code object
+  char magic[8];
+  uint64_t payload_bytes;
+  unsigned char key_sha[32];   // source + headers + options + hiprtc version
+  unsigned char blob_sha[32];  // the code object itself
+};
+
+bool private_dir(const std::string& d) {      // a real directory of ours that nobody else can touch
+  struct stat st;
+  if (::lstat(d.c_str(), &st) != 0) return false;
+  return S_ISDIR(st.st_mode) && st.st_uid == ::getuid() && (st.st_mode & 077) == 0;
+}
+}  // namespace
+
 static uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
   const unsigned char* p = (const unsigned char*)data;
   for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
@@ -102,29 +203,77 @@ static std::string cache_dir() {
   if (const char* e = std::getenv("HAMK_CACHE")) if (e[0] == '0') return std::string();
   std::string d;
   if (const char* e = std::getenv("HAMK_CACHE_DIR")) d = e;
-  else if (const char* x = std::getenv("XDG_CACHE_HOME")) d = std::string(x) + "/hamk";
-  else d = "/tmp/hamk-cache-" + std::to_string((long)getuid());
-  ::mkdir(d.c_str(), 0700);
-  struct stat st;
-  if (::stat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return std::string();
+  else if (const char* x = std::getenv("XDG_CACHE_HOME")) { if (x[0]) { ::mkdir(x, 0700); d = std::string(x) + "/hamk"; } }
+  if (d.empty()) {
+    const char* home = std::getenv("HOME");
+    if (!home || !home[0]) return std::string();           // nowhere private to put it: no cache
+    const std::string c = std::string(home) + "/.cache";
+    ::mkdir(c.c_str(), 0700);
+    d = c + "/hamk";
+  }
+  ::mkdir(d.c_str(), 0700);                                // EEXIST is fine: what exists is checked next
+  if (!private_dir(d)) return std::string();
   return d;
 }
 
-static std::string cache_path(const hamk_system* s, const std::vector<const char*>& opts) {
+struct CacheKey { std::string path; unsigned char sha[32]; };
+
+static CacheKey cache_key(const hamk_system* s, const std::vector<const char*>& opts) {
+  CacheKey k;
+  std::memset(k.sha, 0, sizeof k.sha);
   const std::string dir = cache_dir();
-  if (dir.empty()) return dir;
-  uint64_t h = 1469598103934665603ull;
-  h = fnv1a(s->source.data(), s->source.size(), h);
-  h = fnv1a(kDeviceHeader, sizeof kDeviceHeader, h);
-  h = fnv1a(kWaveHeader, sizeof kWaveHeader, h);
-  for (const char* o : opts) h = fnv1a(o, std::strlen(o) + 1, h);
+  if (dir.empty()) return k;
   int major = 0, minor = 0;
   hiprtcVersion(&major, &minor);
-  h = fnv1a(&major, sizeof major, h);
-  h = fnv1a(&minor, sizeof minor, h);
+  uint64_t h = 1469598103934665603ull;
+  Sha256 sha;
+  auto feed = [&](const void* p, size_t n) { h = fnv1a(p, n, h); const uint64_t len = n; sha.update(&len, sizeof len); sha.update(p, n); };
+  feed(s->source.data(), s->source.size());
+  feed(kDeviceHeader, sizeof kDeviceHeader);
+  feed(kWaveHeader, sizeof kWaveHeader);
+  for (const char* o : opts) feed(o, std::strlen(o) + 1);
+  feed(&major, sizeof major);
+  feed(&minor, sizeof minor);
+  sha.finish(k.sha);
   char name[64];
   std::snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
-  return dir + name;
+  k.path = dir + name;
+  return k;
+}
+
+// a cache entry is used only if its trailer matches the key and the payload it describes
+static bool cache_load(const CacheKey& k, std::vector<char>& code) {
+  std::ifstream in(k.path, std::ios::binary);
+  if (!in) return false;
+  std::vector<char> blob((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  if (blob.size() < sizeof(CacheTrailer) + 64) return false;
+  CacheTrailer t;
+  std::memcpy(&t, blob.data() + blob.size() - sizeof t, sizeof t);
+  if (std::memcmp(t.magic, kCacheMagic, sizeof t.magic) != 0) return false;
+  if (t.payload_bytes != blob.size() - sizeof t) return false;
+  if (std::memcmp(t.key_sha, k.sha, 32) != 0) return false;
+  unsigned char got[32];
+  Sha256 sha; sha.update(blob.data(), (size_t)t.payload_bytes); sha.finish(got);
+  if (std::memcmp(got, t.blob_sha, 32) != 0) return false;
+  if (std::memcmp(blob.data(), "\177ELF", 4) != 0) return false;
+  blob.resize((size_t)t.payload_bytes);
+  code.swap(blob);
+  return true;
+}
+
+static void cache_store(const CacheKey& k, const std::vector<char>& code) {   // publish atomically: write aside, rename
+  CacheTrailer t;
+  std::memcpy(t.magic, kCacheMagic, sizeof t.magic);
+  t.payload_bytes = code.size();
+  std::memcpy(t.key_sha, k.sha, 32);
+  Sha256 sha; sha.update(code.data(), code.size()); sha.finish(t.blob_sha);
+  const std::string tmp = k.path + ".tmp." + std::to_string((long)getpid());
+  std::ofstream out(tmp, std::ios::binary);
+  if (!out) return;
+  out.write(code.data(), (std::streamsize)code.size());
+  out.write((const char*)&t, sizeof t);
+  out.close();
+  if (!out || std::rename(tmp.c_str(), k.path.c_str()) != 0) std::remove(tmp.c_str());
 }
 
 static int compile_module(hamk_system* s, bool no_machine_licm, std::vector<char>& code) {
@@ -158,18 +307,11 @@ static int compile_module(hamk_system* s, bool no_machine_licm, std::vector<char
     }
     for (auto& t : extra_tok) opts.push_back(t.c_str());
   }
-  const std::string cpath = cache_path(s, opts);
-  if (!cpath.empty()) {
-    std::ifstream in(cpath, std::ios::binary);
-    if (in) {
-      std::vector<char> blob((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
-      if (blob.size() > 64 && std::memcmp(blob.data(), "\177ELF", 4) == 0) {
-        code.swap(blob);
-        s->build_log = "cache hit: " + cpath;
-        hiprtcDestroyProgram(&prog);
-        return HAMK_OK;
-      }
-    }
+  const CacheKey ckey = cache_key(s, opts);
+  if (!ckey.path.empty() && cache_load(ckey, code)) {
+    s->build_log = "cache hit: " + ckey.path;
+    hiprtcDestroyProgram(&prog);
+    return HAMK_OK;
   }
   r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   size_t logsz = 0;
@@ -188,15 +330,7 @@ static int compile_module(hamk_system* s, bool no_machine_licm, std::vector<char
   code.resize(sz);
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
-  if (!cpath.empty()) {                                  // publish atomically: write aside, rename
-    const std::string tmp = cpath + ".tmp." + std::to_string((long)getpid());
-    std::ofstream out(tmp, std::ios::binary);
-    if (out) {
-      out.write(code.data(), (std::streamsize)code.size());
-      out.close();
-      if (!out || std::rename(tmp.c_str(), cpath.c_str()) != 0) std::remove(tmp.c_str());
-    }
-  }
+  if (!ckey.path.empty()) cache_store(ckey, code);
   return HAMK_OK;
 }
 
@@ -391,8 +525,8 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
     }
     if (rc == HAMK_OK) {
       hipMemcpy(d_q, q.data(), cnt * 8, hipMemcpyHostToDevice); hipMemcpy(d_p, p.data(), cnt * 8, hipMemcpyHostToDevice);
-      double ddt = dt; int ns = 1; int32_t* st = d_st;
-      void* args[] = {&d_q, &d_p, &b, &ddt, &ns, &st};
+      double ddt = dt, no_drift = 0.0; int ns = 1; int32_t* st = d_st;
+      void* args[] = {&d_q, &d_p, &b, &ddt, &ns, &no_drift, &st};
       rc = launch(s, K_RK4, B, args);
       if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RK4 kernel failed");
       hipMemcpy(got.data(), d_q, cnt * 8, hipMemcpyDeviceToHost); hipMemcpy(got.data() + cnt, d_p, cnt * 8, hipMemcpyDeviceToHost);
@@ -425,9 +559,9 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
       }
       hipMemcpy(d_q, q.data(), cnt * 8, hipMemcpyHostToDevice); hipMemcpy(d_p, p.data(), cnt * 8, hipMemcpyHostToDevice);
       double h0 = dt, ea = 1e30, er = 1e30, t0 = 0.0, t1 = dt;
-      int nt = 2, row0 = 1, inplace = 1, max_sub = 8;
+      int nt = 2, row0 = 1, inplace = 1, max_sub = 8, api = s->gsl_api;
       const double *cq = d_q, *cp = d_p, *cts = nullptr; int32_t* st = d_st; int32_t* ns = nullptr;
-      void* args[] = {&cq, &cp, &d_q, &d_p, &b, &nt, &cts, &t0, &t1, &h0, &ea, &er, &row0, &inplace, &max_sub, &st, &ns};
+      void* args[] = {&cq, &cp, &d_q, &d_p, &b, &nt, &cts, &t0, &t1, &h0, &ea, &er, &row0, &inplace, &max_sub, &api, &st, &ns};
       rc = launch(s, K_RKF45, B, args);
       if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RKF45 kernel failed");
       hipMemcpy(got.data(), d_q, cnt * 8, hipMemcpyDeviceToHost); hipMemcpy(got.data() + cnt, d_p, cnt * 8, hipMemcpyDeviceToHost);
@@ -463,8 +597,8 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
       std::vector<double> ref3b(2 * c3);
       for (int r = 0; r < 2 && rc == HAMK_OK; ++r) {         // the fixed-step kernel, twice as well
         upload();
-        double ddt = T / 64; int ns = 64;
-        void* a4[] = {&e_q, &e_p, &b3, &ddt, &ns, &e_st};
+        double ddt = T / 64, no_drift = 0.0; int ns = 64;
+        void* a4[] = {&e_q, &e_p, &b3, &ddt, &ns, &no_drift, &e_st};
         rc = launch(s, K_RK4, B3, a4);
         if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RK4 kernel failed");
         download(r == 0 ? ref3 : ref3b);
@@ -477,9 +611,9 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
       for (int r = 0; r < 2 && rc == HAMK_OK; ++r) {
         upload();
         double h0 = T / 100, ea = kRefEpsilon, er = kRefEpsilon, t0 = 0.0, t1 = T;
-        int nt = 2, row0 = 1, inplace = 1, max_sub = 4096;
+        int nt = 2, row0 = 1, inplace = 1, max_sub = 4096, api = s->gsl_api;
         const double *cq = e_q, *cp = e_p, *cts = nullptr;
-        void* a5[] = {&cq, &cp, &e_q, &e_p, &b3, &nt, &cts, &t0, &t1, &h0, &ea, &er, &row0, &inplace, &max_sub, &e_st, &e_ns};
+        void* a5[] = {&cq, &cp, &e_q, &e_p, &b3, &nt, &cts, &t0, &t1, &h0, &ea, &er, &row0, &inplace, &max_sub, &api, &e_st, &e_ns};
         rc = launch(s, K_RKF45, B3, a5);
         if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RKF45 kernel failed");
         download(run[r]);
@@ -520,12 +654,12 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
 
 static int self_check(hamk_system* s) {
   if (const char* e = std::getenv("HAMK_SELFCHECK")) if (e[0] == '0') return HAMK_OK;
-  if (s->self_checked) return HAMK_OK;
+  if (s->cur->self_checked) return HAMK_OK;
   for (int attempt = 0; attempt < 2; ++attempt) {
     bool rk4_ok = true, rkf_ok = true;
     int rc = self_check_once(s, &rk4_ok, &rkf_ok);
     if (rc != HAMK_OK) return rc;
-    if (rk4_ok && rkf_ok) { s->self_checked = true; return HAMK_OK; }
+    if (rk4_ok && rkf_ok) { s->cur->self_checked = true; return HAMK_OK; }
     const bool can_retry = attempt == 0 && !s->desc.wave && ((!rk4_ok && !s->desc.rk4_stage_loop) || (!rkf_ok && !s->desc.rkf_stage_loop));
     if (!can_retry)
       return fail(HAMK_ERR_COMPILE, std::string("self-check failed: the fused ") + (!rk4_ok ? "RK4" : "RKF45") +
@@ -536,6 +670,8 @@ static int self_check(hamk_system* s) {
     s->source = generate_source(s->desc);
     rc = build_code(s);
     if (rc != HAMK_OK) return rc;
+    s->generation++;                                       // other devices reload (and re-check) lazily
+    for (DevState* d : s->devs) if (d != s->cur) d->self_checked = false;
     rc = load_modules(s);
     if (rc != HAMK_OK) return rc;
     s->self_check_rebuilds++;
@@ -544,38 +680,40 @@ static int self_check(hamk_system* s) {
 }
 
 static int load_modules(hamk_system* s) {
-  if (s->module) { hipModuleUnload(s->module); s->module = nullptr; }
-  if (s->module2) { hipModuleUnload(s->module2); s->module2 = nullptr; }
-  HIP_TRY(hipModuleLoadData(&s->module, s->code.data()));
-  if (!s->code2.empty()) HIP_TRY(hipModuleLoadData(&s->module2, s->code2.data()));
+  DevState* d = s->cur;
+  d->unload();
+  HIP_TRY(hipModuleLoadData(&d->module, s->code.data()));
+  if (!s->code2.empty()) HIP_TRY(hipModuleLoadData(&d->module2, s->code2.data()));
   for (int k = 0; k < K__COUNT; ++k)
-    HIP_TRY(hipModuleGetFunction(&s->fn[k], (s->use2[k] && s->module2) ? s->module2 : s->module, kKernelNames[k]));
+    HIP_TRY(hipModuleGetFunction(&d->fn[k], (s->use2[k] && d->module2) ? d->module2 : d->module, kKernelNames[k]));
+  d->code_generation = s->generation;
   return HAMK_OK;
 }
 
+// Select (creating it on first use) the state of the calling thread's current device.
 static int bind_device(hamk_system* s) {
   int dev = -1;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return fail(HAMK_ERR_NODEVICE, std::string("hipGetDevice: ") + hipGetErrorString(e));
-  if (s->module && dev == s->device) return HAMK_OK;
-  if (s->module) {
-    hipModuleUnload(s->module);
-    s->module = nullptr;
-    if (s->module2) { hipModuleUnload(s->module2); s->module2 = nullptr; }
-    if (s->d_ts) { hipFree(s->d_ts); s->d_ts = nullptr; s->d_ts_cap = 0; }
-    for (void*& b : s->stage_buf) if (b) { hipFree(b); b = nullptr; }
-    s->stage_cap.assign(s->stage_cap.size(), 0);
-    if (s->pin) { hipHostFree(s->pin); s->pin = s->pin_dev = nullptr; }
+  if (!s->cur || s->cur->device != dev) {
+    s->cur = nullptr;
+    for (DevState* d : s->devs) if (d->device == dev) s->cur = d;
+    if (!s->cur) {
+      hipDeviceProp_t prop;
+      HIP_TRY(hipGetDeviceProperties(&prop, dev));
+      if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(HAMK_ERR_NODEVICE, std::string("device ") + prop.gcnArchName + " is not gfx950 (MI355X); libhamk has no other code path");
+      DevState* d = new DevState();
+      d->device = dev;
+      s->devs.push_back(d);
+      s->cur = d;
+    }
   }
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, dev));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(HAMK_ERR_NODEVICE, std::string("device ") + prop.gcnArchName + " is not gfx950 (MI355X); libhamk has no other code path");
+  if (s->cur->module && s->cur->code_generation == s->generation) return HAMK_OK;
   {
     const int rc_load = load_modules(s);
     if (rc_load != HAMK_OK) return rc_load;
   }
-  s->device = dev;
   return self_check(s);
 }
 
@@ -586,7 +724,7 @@ static int launch(hamk_system* s, KernelId k, int64_t B, void** args) {
   if (s->desc.wave) per_block = 4 * (64 / (s->desc.n <= 16 ? 16 : 32));
   const int64_t grid = (B + per_block - 1) / per_block;
   if (grid > 0x7fffffffLL) return fail(HAMK_ERR_INVALID, "ensemble too large for one launch");
-  HIP_TRY(hipModuleLaunchKernel(s->fn[k], (unsigned)grid, 1, 1, block, 1, 1, 0, s->stream, args, nullptr));
+  HIP_TRY(hipModuleLaunchKernel(s->cur->fn[k], (unsigned)grid, 1, 1, block, 1, 1, 0, s->stream, args, nullptr));
   return HAMK_OK;
 }
 
@@ -637,15 +775,15 @@ class Stager {
       return HAMK_OK;
     }
     const size_t slot = nstaged_++;
-    if (slot >= s_->stage_buf.size()) { s_->stage_buf.push_back(nullptr); s_->stage_cap.push_back(0); }
-    if (s_->stage_cap[slot] < bytes) {
+    if (slot >= s_->cur->stage_buf.size()) { s_->cur->stage_buf.push_back(nullptr); s_->cur->stage_cap.push_back(0); }
+    if (s_->cur->stage_cap[slot] < bytes) {
       HIP_TRY(hipStreamSynchronize(s_->stream));          // nobody may still be using the old block
-      if (s_->stage_buf[slot]) hipFree(s_->stage_buf[slot]);
-      s_->stage_buf[slot] = nullptr; s_->stage_cap[slot] = 0;
-      HIP_TRY(hipMalloc(&s_->stage_buf[slot], bytes));
-      s_->stage_cap[slot] = bytes;
+      if (s_->cur->stage_buf[slot]) hipFree(s_->cur->stage_buf[slot]);
+      s_->cur->stage_buf[slot] = nullptr; s_->cur->stage_cap[slot] = 0;
+      HIP_TRY(hipMalloc(&s_->cur->stage_buf[slot], bytes));
+      s_->cur->stage_cap[slot] = bytes;
     }
-    b.dev = s_->stage_buf[slot];
+    b.dev = s_->cur->stage_buf[slot];
     bufs_.push_back(b);
     if (copy_in) HIP_TRY(hipMemcpyAsync(b.dev, p, bytes, hipMemcpyHostToDevice, s_->stream));
     *dev = b.dev;
@@ -654,8 +792,8 @@ class Stager {
   // bump allocation in the handle's pinned arena; every host-pointer call ends with a stream
   // synchronisation (finish), so the arena is free again when the next call starts
   bool pin_alloc(size_t bytes, void** host, void** dev) {
-    if (s_->pin_failed) return false;
-    if (!s_->pin) {
+    if (s_->cur->pin_failed) return false;
+    if (!s_->cur->pin) {
       static const bool off = [] { const char* e = std::getenv("HAMK_PINNED"); return e && e[0] == '0'; }();
       void* h = nullptr; void* d = nullptr;
       static const bool noncoh = [] { const char* e = std::getenv("HAMK_PINNED"); return e && e[0] == 'n'; }();   // test hook: the broken variant
@@ -663,15 +801,15 @@ class Stager {
           hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
         if (h) hipHostFree(h);
         (void)hipGetLastError();
-        s_->pin_failed = true;
+        s_->cur->pin_failed = true;
         return false;
       }
-      s_->pin = (char*)h; s_->pin_dev = (char*)d;
+      s_->cur->pin = (char*)h; s_->cur->pin_dev = (char*)d;
     }
     const size_t at = (pin_used_ + 255) & ~(size_t)255;
     if (at + bytes > kPinArena) return false;
     pin_used_ = at + bytes;
-    *host = s_->pin + at; *dev = s_->pin_dev + at;
+    *host = s_->cur->pin + at; *dev = s_->cur->pin_dev + at;
     return true;
   }
   hamk_system* s_;
@@ -697,7 +835,7 @@ static int check_call(hamk_system* s, int64_t B, int32_t mem) {
 extern "C" {
 
 const char* hamk_last_error(void) { return g_last_error.c_str(); }
-const char* hamk_version(void) { return "hamk 0.1 (gfx950; hiprtc-specialised jets; RK4 + GSL-semantics RKF45)"; }
+const char* hamk_version(void) { return "hamk 0.2 (gfx950; hiprtc-specialised jets; RK4 + GSL-semantics RKF45, gsl_odeiv2 / gsl_odeiv)"; }
 
 int hamk_device_count(void) {
   int n = 0;
@@ -761,6 +899,7 @@ int hamk_gather_batch(int32_t nparts, int32_t n, const int64_t* B_parts, const d
   if (!out) return fail(HAMK_ERR_INVALID, "hamk_gather_batch: null out");
   int here = 0;
   HIP_TRY(hipGetDevice(&here));
+  std::string peer_note;                                   // why a direct xGMI path could not be set up, if so
   int64_t at = 0;
   for (int g = 0; g < nparts; ++g) {
     const int64_t Bg = B_parts[g];
@@ -771,14 +910,20 @@ int hamk_gather_batch(int32_t nparts, int32_t n, const int64_t* B_parts, const d
         int can = 0;
         if (hipDeviceCanAccessPeer(&can, here, attr.device) == hipSuccess && can) {
           hipError_t e = hipDeviceEnablePeerAccess(attr.device, 0);
-          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+            peer_note = std::string(" [hipDeviceEnablePeerAccess(") + std::to_string(attr.device) + "): " + hipGetErrorString(e) + "]";
+        } else {
+          peer_note = " [device " + std::to_string(attr.device) + " is not a peer of device " + std::to_string(here) + "]";
         }
       }
-      (void)hipGetLastError();
+      (void)hipGetLastError();                             // the copy below still works without peer access (staged by the runtime)
     }
     // row j of the part goes to columns [at, at + Bg) of row j of the output
-    HIP_TRY(hipMemcpy2DAsync(out + at, (size_t)total * sizeof(double), parts[g], (size_t)Bg * sizeof(double),
-                             (size_t)Bg * sizeof(double), (size_t)n, hipMemcpyDefault, nullptr));
+    {
+      hipError_t e = hipMemcpy2DAsync(out + at, (size_t)total * sizeof(double), parts[g], (size_t)Bg * sizeof(double),
+                                      (size_t)Bg * sizeof(double), (size_t)n, hipMemcpyDefault, nullptr);
+      if (e != hipSuccess) return fail(HAMK_ERR_HIP, std::string("hamk_gather_batch: copy of part ") + std::to_string(g) + ": " + hipGetErrorString(e) + peer_note);
+    }
     at += Bg;
   }
   HIP_TRY(hipStreamSynchronize(nullptr));
@@ -824,6 +969,7 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   s->desc.rk4_stage_loop = (n >= 7);
   if (const char* e = std::getenv("HAMK_RK4_LOOP")) s->desc.rk4_stage_loop = (e[0] == '1');
   if (const char* e = std::getenv("HAMK_RK4_WAVES")) s->desc.rk4_min_waves = std::atoi(e);
+  if (const char* e = std::getenv("HAMK_GSL_API")) s->gsl_api = (e[0] == '1') ? 1 : 2;
   s->desc.rkf_stage_loop = (n >= 4);
   if (const char* e = std::getenv("HAMK_RKF_LOOP")) s->desc.rkf_stage_loop = (e[0] == '1');
   const bool forced_rk4 = std::getenv("HAMK_RK4_LOOP") != nullptr, forced_rkf = std::getenv("HAMK_RKF_LOOP") != nullptr;
@@ -847,11 +993,8 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
 
 void hamk_system_destroy(hamk_system* s) {
   if (!s) return;
-  if (s->module) hipModuleUnload(s->module);
-  if (s->module2) hipModuleUnload(s->module2);
-  if (s->d_ts) hipFree(s->d_ts);
-  for (void* b : s->stage_buf) if (b) hipFree(b);
-  if (s->pin) hipHostFree(s->pin);
+  for (DevState* d : s->devs) { d->release(); delete d; }
+  (void)hipGetLastError();
   delete s;
 }
 
@@ -872,6 +1015,22 @@ int hamk_synchronize(hamk_system* s) {
   if (!s) return fail(HAMK_ERR_INVALID, "null system handle");
   HIP_TRY(hipStreamSynchronize(s->stream));
   return HAMK_OK;
+}
+
+int hamk_system_set_gsl_api(hamk_system* s, int32_t api) {
+  if (!s) return fail(HAMK_ERR_INVALID, "null system handle");
+  if (api != 1 && api != 2) return fail(HAMK_ERR_INVALID, "gsl api must be 1 (gsl_odeiv) or 2 (gsl_odeiv2)");
+  s->gsl_api = api;
+  return HAMK_OK;
+}
+
+int32_t hamk_system_get_gsl_api(const hamk_system* s) { return s ? s->gsl_api : 0; }
+
+int64_t hamk_system_code_object(const hamk_system* s, int32_t which, void* buf, int64_t cap) {
+  if (!s || (which != 0 && which != 1)) return 0;
+  const std::vector<char>& c = which ? s->code2 : s->code;
+  if (buf && cap >= (int64_t)c.size() && !c.empty()) std::memcpy(buf, c.data(), c.size());
+  return (int64_t)c.size();
 }
 
 const char* hamk_system_source(const hamk_system* s) { return s ? s->source.c_str() : nullptr; }
@@ -997,11 +1156,12 @@ int hamk_hameqs_batch(hamk_system* s, int64_t B, const double* q, const double* 
   return st.finish();
 }
 
-int hamk_rk4_steps(hamk_system* s, int64_t B, double* q, double* p, double dt, int32_t nsteps, int32_t* status,
-                   int32_t mem) {
+int hamk_rk4_steps_checked(hamk_system* s, int64_t B, double* q, double* p, double dt, int32_t nsteps, double drift_tol,
+                           int32_t* status, int32_t mem) {
   TRY(check_call(s, B, mem));
   if (!q || !p) return fail(HAMK_ERR_INVALID, "null q / p");
   if (nsteps < 0) return fail(HAMK_ERR_INVALID, "negative nsteps");
+  if (drift_tol != drift_tol) return fail(HAMK_ERR_INVALID, "drift_tol is NaN");
   if (B == 0) return HAMK_OK;
   TRY(bind_device(s));
   Stager st(s, mem);
@@ -1012,22 +1172,27 @@ int hamk_rk4_steps(hamk_system* s, int64_t B, double* q, double* p, double dt, i
   TRY(st.out(status, (size_t)B, &dst));
   long long b = B;
   int ns = nsteps;
-  void* args[] = {&xq, &xp, &b, &dt, &ns, &dst};
+  void* args[] = {&xq, &xp, &b, &dt, &ns, &drift_tol, &dst};
   TRY(launch(s, K_RK4, B, args));
   return st.finish();
 }
 
+int hamk_rk4_steps(hamk_system* s, int64_t B, double* q, double* p, double dt, int32_t nsteps, int32_t* status,
+                   int32_t mem) {
+  return hamk_rk4_steps_checked(s, B, q, p, dt, nsteps, 0.0, status, mem);
+}
+
 static int upload_times(hamk_system* s, int32_t nt, const double* ts) {
-  if ((size_t)nt > s->d_ts_cap) {
-    if (s->d_ts) hipFree(s->d_ts);
-    s->d_ts = nullptr; s->d_ts_cap = 0;
-    HIP_TRY(hipMalloc((void**)&s->d_ts, sizeof(double) * nt));
-    s->d_ts_cap = nt;
+  if ((size_t)nt > s->cur->d_ts_cap) {
+    if (s->cur->d_ts) hipFree(s->cur->d_ts);
+    s->cur->d_ts = nullptr; s->cur->d_ts_cap = 0;
+    HIP_TRY(hipMalloc((void**)&s->cur->d_ts, sizeof(double) * nt));
+    s->cur->d_ts_cap = nt;
   }
   // the previous launch may still be reading d_ts / h_ts: order behind it on the stream
   HIP_TRY(hipStreamSynchronize(s->stream));
-  s->h_ts.assign(ts, ts + nt);
-  HIP_TRY(hipMemcpyAsync(s->d_ts, s->h_ts.data(), sizeof(double) * nt, hipMemcpyHostToDevice, s->stream));
+  s->cur->h_ts.assign(ts, ts + nt);
+  HIP_TRY(hipMemcpyAsync(s->cur->d_ts, s->cur->h_ts.data(), sizeof(double) * nt, hipMemcpyHostToDevice, s->stream));
   return HAMK_OK;
 }
 
@@ -1054,6 +1219,16 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
   if (!(h0 > 0.0)) h0 = (ts[1] - ts[0]) / 100.0;          // Hamilton.hs:447
   if (!(eps_abs > 0.0)) eps_abs = kRefEps;
   if (!(eps_rel > 0.0)) eps_rel = kRefEps;
+  if (s->gsl_api == 2) {
+    // gsl_odeiv2_driver_apply: the direction is the sign of the initial step (h > 0 ? +1 : -1) and a
+    // target time on the wrong side of t is GSL_EINVAL ("integration limits and/or step direction not
+    // consistent"); t equals the previous grid time exactly whenever a trajectory gets this far
+    const double sgn = h0 > 0.0 ? 1.0 : -1.0;
+    for (int32_t r = 1; r < nt; ++r)
+      if (sgn * (ts[r] - ts[r - 1]) < 0.0)
+        return fail(HAMK_ERR_INVALID, "evolveHam (gsl_odeiv2 semantics): integration limits and/or step direction not consistent "
+                                      "(the time grid must be monotone in the direction of ts[1] - ts[0])");
+  }
   Stager st(s, mem);
   // time grid: two times travel as kernel arguments; a longer grid as a pinned side input of a
   // small host-pointer call, else through the handle's device scratch
@@ -1061,7 +1236,7 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
   const double* dts = nullptr;
   if (nt > 2) {
     dts = (size_t)nt * sizeof(double) <= kPinMaxBuf ? st.side_input(ts, (size_t)nt) : nullptr;
-    if (!dts) { TRY(upload_times(s, nt, ts)); dts = s->d_ts; }
+    if (!dts) { TRY(upload_times(s, nt, ts)); dts = s->cur->d_ts; }
   }
   const size_t cnt = (size_t)s->desc.n * B;
   const double *xq, *xp; double *xqo, *xpo; int32_t *dst, *dns;
@@ -1072,8 +1247,8 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
   TRY(st.out(status, (size_t)B, &dst));
   TRY(st.out(nsub, (size_t)B, &dns));
   long long b = B;
-  int nt_ = nt, row0 = 0, inplace = 0, max_sub = max_substeps();
-  void* args[] = {&xq, &xp, &xqo, &xpo, &b, &nt_, &dts, &ts0, &ts1, &h0, &eps_abs, &eps_rel, &row0, &inplace, &max_sub, &dst, &dns};
+  int nt_ = nt, row0 = 0, inplace = 0, max_sub = max_substeps(), api = s->gsl_api;
+  void* args[] = {&xq, &xp, &xqo, &xpo, &b, &nt_, &dts, &ts0, &ts1, &h0, &eps_abs, &eps_rel, &row0, &inplace, &max_sub, &api, &dst, &dns};
   TRY(launch(s, K_RKF45, B, args));
   return st.finish();
 }
@@ -1094,12 +1269,119 @@ int hamk_step_ham_batch(hamk_system* s, int64_t B, double* q, double* p, double 
   TRY(st.out(status, (size_t)B, &dst));
   TRY(st.out(nsub, (size_t)B, &dns));
   long long b = B;
-  int nt_ = 2, row0 = 1, inplace = 1, max_sub = max_substeps();
+  int nt_ = 2, row0 = 1, inplace = 1, max_sub = max_substeps(), api = s->gsl_api;
   const double* dts = nullptr;
   const double *cq = xq, *cp = xp;
-  void* args[] = {&cq, &cp, &xq, &xp, &b, &nt_, &dts, &ts0, &ts1, &h0, &eps_abs, &eps_rel, &row0, &inplace, &max_sub, &dst, &dns};
+  void* args[] = {&cq, &cp, &xq, &xp, &b, &nt_, &dts, &ts0, &ts1, &h0, &eps_abs, &eps_rel, &row0, &inplace, &max_sub, &api, &dst, &dns};
   TRY(launch(s, K_RKF45, B, args));
   return st.finish();
+}
+
+
+// ---- ensemble checkpoint: flat binary dump / restore of the SoA state ----------
+namespace {
+struct CkHeader {              // 64 bytes, little endian
+  char magic[8];               // "HAMKCKP1"
+  int32_t n, version;
+  int64_t B, steps_done;
+  uint64_t seed;
+  double t;
+  unsigned char reserved[16];
+};
+static_assert(sizeof(CkHeader) == 64, "checkpoint header layout");
+constexpr char kCkMagic[8] = {'H', 'A', 'M', 'K', 'C', 'K', 'P', '1'};
+constexpr size_t kCkChunk = 8u << 20;   // staging chunk for device-resident state
+}  // namespace
+
+int hamk_checkpoint_write(const char* path, int32_t n, int64_t B, const double* q, const double* p, int32_t mem,
+                          int64_t steps_done, uint64_t seed, double t) {
+  if (!path || n <= 0 || B < 0 || (B > 0 && (!q || !p))) return fail(HAMK_ERR_INVALID, "hamk_checkpoint_write: bad path / n / B / null state");
+  if (mem != HAMK_MEM_HOST && mem != HAMK_MEM_DEVICE) return fail(HAMK_ERR_INVALID, "mem must be HAMK_MEM_HOST or HAMK_MEM_DEVICE");
+  CkHeader h;
+  std::memset(&h, 0, sizeof h);
+  std::memcpy(h.magic, kCkMagic, 8);
+  h.n = n; h.version = 1; h.B = B; h.steps_done = steps_done; h.seed = seed; h.t = t;
+  const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
+  std::FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f) return fail(HAMK_ERR_INVALID, std::string("hamk_checkpoint_write: cannot create ") + tmp);
+  Sha256 sha;
+  bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
+  sha.update(&h, sizeof h);
+  std::vector<char> stage;
+  const size_t bytes = (size_t)n * (size_t)B * sizeof(double);
+  for (const double* arr : {q, p}) {
+    for (size_t off = 0; off < bytes && ok; off += kCkChunk) {
+      const size_t k = std::min(kCkChunk, bytes - off);
+      const char* src = (const char*)arr + off;
+      if (mem == HAMK_MEM_DEVICE) {
+        stage.resize(k);
+        hipError_t e = hipMemcpy(stage.data(), src, k, hipMemcpyDeviceToHost);    // synchronises with the null stream
+        if (e != hipSuccess) { std::fclose(f); std::remove(tmp.c_str()); return fail(HAMK_ERR_HIP, std::string("hamk_checkpoint_write: ") + hipGetErrorString(e)); }
+        src = stage.data();
+      }
+      ok = std::fwrite(src, 1, k, f) == k;
+      sha.update(src, k);
+    }
+  }
+  unsigned char dg[32];
+  sha.finish(dg);
+  ok = ok && std::fwrite(dg, 1, 32, f) == 32;
+  ok = (std::fclose(f) == 0) && ok;
+  if (!ok || std::rename(tmp.c_str(), path) != 0) { std::remove(tmp.c_str()); return fail(HAMK_ERR_INVALID, std::string("hamk_checkpoint_write: write to ") + path + " failed"); }
+  return HAMK_OK;
+}
+
+static int read_ck_header(std::FILE* f, const char* path, CkHeader* h) {
+  if (std::fread(h, sizeof *h, 1, f) != 1 || std::memcmp(h->magic, kCkMagic, 8) != 0 || h->version != 1 || h->n <= 0 || h->B < 0)
+    return fail(HAMK_ERR_INVALID, std::string(path) + " is not a hamk checkpoint");
+  return HAMK_OK;
+}
+
+int hamk_checkpoint_info(const char* path, int32_t* n, int64_t* B, int64_t* steps_done, uint64_t* seed, double* t) {
+  if (!path) return fail(HAMK_ERR_INVALID, "hamk_checkpoint_info: null path");
+  std::FILE* f = std::fopen(path, "rb");
+  if (!f) return fail(HAMK_ERR_INVALID, std::string("hamk_checkpoint_info: cannot open ") + path);
+  CkHeader h;
+  const int rc = read_ck_header(f, path, &h);
+  std::fclose(f);
+  if (rc != HAMK_OK) return rc;
+  if (n) *n = h.n;
+  if (B) *B = h.B;
+  if (steps_done) *steps_done = h.steps_done;
+  if (seed) *seed = h.seed;
+  if (t) *t = h.t;
+  return HAMK_OK;
+}
+
+int hamk_checkpoint_read(const char* path, int32_t n, int64_t B, double* q, double* p, int32_t mem) {
+  if (!path || (B > 0 && (!q || !p))) return fail(HAMK_ERR_INVALID, "hamk_checkpoint_read: null path / state");
+  if (mem != HAMK_MEM_HOST && mem != HAMK_MEM_DEVICE) return fail(HAMK_ERR_INVALID, "mem must be HAMK_MEM_HOST or HAMK_MEM_DEVICE");
+  std::FILE* f = std::fopen(path, "rb");
+  if (!f) return fail(HAMK_ERR_INVALID, std::string("hamk_checkpoint_read: cannot open ") + path);
+  CkHeader h;
+  int rc = read_ck_header(f, path, &h);
+  if (rc == HAMK_OK && (h.n != n || h.B != B)) rc = fail(HAMK_ERR_INVALID, "hamk_checkpoint_read: the file holds a different ensemble (n, B)");
+  if (rc != HAMK_OK) { std::fclose(f); return rc; }
+  Sha256 sha;
+  sha.update(&h, sizeof h);
+  const size_t bytes = (size_t)n * (size_t)B * sizeof(double);
+  // the digest is checked BEFORE anything reaches the caller's arrays (host or device)
+  std::vector<char> all(2 * bytes);
+  bool ok = bytes == 0 || std::fread(all.data(), 1, 2 * bytes, f) == 2 * bytes;
+  unsigned char want[32], got[32];
+  ok = ok && std::fread(want, 1, 32, f) == 32;
+  std::fclose(f);
+  if (ok) { sha.update(all.data(), 2 * bytes); sha.finish(got); ok = std::memcmp(want, got, 32) == 0; }
+  if (!ok) return fail(HAMK_ERR_INVALID, std::string(path) + ": truncated or corrupted checkpoint (digest mismatch)");
+  if (bytes == 0) return HAMK_OK;
+  if (mem == HAMK_MEM_HOST) {
+    std::memcpy(q, all.data(), bytes);
+    std::memcpy(p, all.data() + bytes, bytes);
+  } else {
+    HIP_TRY(hipMemcpy(q, all.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p, all.data() + bytes, bytes, hipMemcpyHostToDevice));
+  }
+  return HAMK_OK;
 }
 
 }  // extern "C"

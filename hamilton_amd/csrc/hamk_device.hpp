@@ -50,7 +50,7 @@ namespace hamk {
 
 typedef long long i64;
 
-enum : int { ST_SINGULAR = 1, ST_NONFINITE = 2, ST_UNDERFLOW = 4, ST_MAXSTEPS = 8 };
+enum : int { ST_SINGULAR = 1, ST_NONFINITE = 2, ST_UNDERFLOW = 4, ST_MAXSTEPS = 8, ST_DRIFT = 16 };
 
 // hiprtc has no <type_traits>
 template <class T> struct bare { typedef T type; };
@@ -855,9 +855,27 @@ HAMK_DEV bool is_nonfinite_bits(double x) {
 // Kernels.  One trajectory per lane; grid covers B.
 // ===========================================================================
 
+// hamiltonian (Hamilton.hs:353-361) of y = [q; p]
+template <class S> HAMK_DEV double energy(const double (&y)[2 * S::N], int& st) {
+  constexpr int N = S::N;
+  double q[N], p[N], v[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) { q[j] = y[j]; p[j] = y[N + j]; }
+  velocities<S>(q, p, v, st);
+  double t = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) t = fma(v[j], p[j], t);
+  return fma(0.5, t, potential_value<S>(q));
+}
+
 // Classic RK4, nsteps steps of dt, state resident in VGPRs for the whole launch.
+// drift_tol > 0: the launch also checks its own invariant -- H at entry and exit (two extra
+// evaluations per LAUNCH, nothing per step) -- and sets ST_DRIFT where |H1 - H0| exceeds
+// drift_tol * max(1, |H0|): a fixed step through a near-singularity (a close encounter of the
+// gravitational systems) is silently wrong otherwise.  The reference's analogous failure is an
+// exception out of `inv` (Hamilton.hs:321,381); a fixed-step integrator has no such signal.
 template <class S>
-HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, double dt, int nsteps,
+HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, double dt, int nsteps, double drift_tol,
                        int* __restrict__ status) {
   constexpr int N = S::N, D = 2 * N;
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -868,6 +886,8 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
   int st = 0;
   TrigCache<S::NTRIG_F> tc;
   const double h2 = 0.5 * dt, h6 = dt * (1.0 / 6.0), h3 = dt * (1.0 / 3.0);
+  double H0 = 0.0;
+  if (drift_tol > 0.0) H0 = energy<S>(y, st);
   if constexpr (S::RK4_STAGE_LOOP) {
     // one copy of the right-hand side, executed 4 x nsteps times: keeps the live set to a
     // single hamEqs (n >= 3 would otherwise pay for four interleaved copies in VGPRs).
@@ -909,6 +929,12 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
 #pragma unroll
       for (int j = 0; j < D; ++j) y[j] = fma(h6, k[j], acc[j]);
     }
+  }
+  if (drift_tol > 0.0) {
+    int st1 = 0;
+    const double H1 = energy<S>(y, st1);
+    const double lim = drift_tol * fmax(1.0, fabs(H0));
+    if (!(fabs(H1 - H0) <= lim) || is_nonfinite_bits(H1)) st |= ST_DRIFT;
   }
   bool bad = false;
 #pragma unroll
@@ -1032,12 +1058,24 @@ HAMK_DEV void observe_config_body(const double* __restrict__ q, const double* __
 }
 
 // ---------------------------------------------------------------------------
-// evolveHam / stepHam: GSL gsl_odeiv semantics per lane (rkf45.c stepper,
-// cstd.c standard controller a_y = a_dydt = 1, evolve.c evolve_apply, and
-// hmatrix-gsl's gsl-ode.c output loop), restated from the published algorithm.
+// evolveHam / stepHam: GSL semantics per lane (rkf45.c stepper, cstd.c standard
+// controller a_y = a_dydt = 1, evolve.c evolve_apply, and hmatrix-gsl's
+// gsl-ode.c output loop), restated from the published algorithm.
+// gsl_api selects which of gsl-ode.c's two bindings is followed:
+//   2 (its default build): gsl_odeiv2 -- `for each ti: gsl_odeiv2_driver_apply`.  The direction
+//     is the sign of the initial step; the loop is `while (sign (ti - t) > 0)`; evolve_apply
+//     does NOT write the controller's step size back on a final (clipped-to-ti) step, so the
+//     h carried to the next output time is the last unclipped one; a step whose error is too
+//     large while h cannot shrink any further is GSL_FAILURE: the lane stops there
+//     (ST_UNDERFLOW), its remaining rows hold the last state reached (the reference leaves
+//     them uninitialised after printing "error in ode").
+//   1 (gsl-ode.c built with -DGSLODE1): old gsl_odeiv -- `for each ti: while (t < ti)
+//     gsl_odeiv_evolve_apply`: h is written back after every accepted step, the clipped
+//     final one included; a step that cannot shrink is accepted with its step size kept.
 // Lanes take different numbers of sub-steps; the loop runs until the wave's
 // slowest lane reaches the output time.  dydt_out of an accepted step is
-// reused as dydt_in of the next (GSL re-evaluates it; same value).
+// reused as dydt_in of the next (odeiv2 does the same; odeiv re-evaluates it:
+// same value).
 // qout/pout: [nt][N][B], row 0 = initial state.  nt == 2 and qout == q0 gives
 // stepHam in place (rows are written only for r >= row0).
 // ---------------------------------------------------------------------------
@@ -1063,11 +1101,14 @@ template <int ORD> HAMK_DEV double rpow_inv(double r) {
 
 template <class S>
 HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt, const double* __restrict__ ts, double ts0, double ts1, double h0,
-                         double eps_abs, double eps_rel, int row0, int inplace, int max_sub,
+                         double eps_abs, double eps_rel, int row0, int inplace, int max_sub, int gsl_api,
                          int* __restrict__ status, int* __restrict__ nsub) {
   constexpr int N = S::N, D = 2 * N;
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
+  const bool api2 = gsl_api != 1;
+  const double sgn = (!api2 || h0 > 0.0) ? 1.0 : -1.0;    // odeiv2 driver.c: direction = sign of the initial step
+  bool failed = false;                                    // odeiv2: evolve_apply returned GSL_FAILURE
   double y[D], f0[D];
 #pragma unroll
   for (int j = 0; j < N; ++j) { y[j] = q0[(i64)j * B + i]; y[N + j] = p0[(i64)j * B + i]; }
@@ -1085,7 +1126,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
   rhs<S, StageTrig<S>::anchor>(y, f0, st, tc);        // dydt_in at the initial state
   for (int r = 1; r < nt; ++r) {
     const double ti = ts ? ts[r] : ts1;
-    while (t < ti && attempts < max_sub) {
+    while (sgn * (ti - t) > 0.0 && attempts < max_sub && !failed) {
       ++attempts;
       const double dt = ti - t;
       double hh = h;
@@ -1217,6 +1258,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
         if (rr < 0.2) rr = 0.2;
         const double hdec = rr * h_old;
         if (fabs(hdec) < fabs(h_old) && (tnew + hdec) != tnew) { reject = true; hh = hdec; }
+        else if (api2) { failed = true; hh = hdec; st |= ST_UNDERFLOW; }     // GSL_FAILURE; y and t stay advanced
       } else if (rmax < 0.5) {
         double rr = 0.9 * rpow_inv<6>(rmax);
         if (rr > 5.0) rr = 5.0;
@@ -1224,15 +1266,16 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
         hh = rr * h_old;
       }
       // --- evolve.c: accept or undo -------------------------------------------
-      h = hh;
+      // the suggested step: always written back by gsl_odeiv; by gsl_odeiv2 not on a final step
+      if (reject || failed || !api2 || !final_step) h = hh;
       if (!reject) {
-        if (!(tnew > t)) st |= ST_UNDERFLOW;
+        if (!(sgn * (tnew - t) > 0.0)) st |= ST_UNDERFLOW;
         t = tnew;
 #pragma unroll
         for (int j = 0; j < D; ++j) { y[j] = yn[j]; f0[j] = fn[j]; }
       }
     }
-    if (t < ti) st |= ST_MAXSTEPS;
+    if (sgn * (ti - t) > 0.0 && !failed) st |= ST_MAXSTEPS;
     if (r >= row0) {
       double* qo = inplace ? qout : qout + (i64)r * N * B;
       double* po = inplace ? pout : pout + (i64)r * N * B;
@@ -1261,9 +1304,9 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
 #define HAMK_RK4_BOUNDS __launch_bounds__(256)
 #endif
 #define HAMK_INSTANTIATE(S)                                                                                      \
-  extern "C" __global__ void HAMK_RK4_BOUNDS hamk_rk4_steps_k(double* q, double* p, long long B,                 \
-                                                                      double dt, int nsteps, int* status) {      \
-    hamk::rk4_body<S>(q, p, B, dt, nsteps, status);                                                              \
+  extern "C" __global__ void HAMK_RK4_BOUNDS hamk_rk4_steps_k(double* q, double* p, long long B, double dt,      \
+                                                              int nsteps, double drift_tol, int* status) {       \
+    hamk::rk4_body<S>(q, p, B, dt, nsteps, drift_tol, status);                                                   \
   }                                                                                                              \
   extern "C" __global__ void __launch_bounds__(256) hamk_hameqs_k(const double* q, const double* p, double* dq,  \
                                                                    double* dp, long long B, int* status) {       \
@@ -1293,7 +1336,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
   extern "C" __global__ void __launch_bounds__(256) hamk_rkf45_k(                                                \
       const double* q0, const double* p0, double* qout, double* pout, long long B, int nt, const double* ts,     \
       double ts0, double ts1, double h0, double eps_abs, double eps_rel, int row0, int inplace, int max_sub,     \
-      int* status, int* nsub) {                                                                                  \
+      int gsl_api, int* status, int* nsub) {                                                                     \
     hamk::rkf45_body<S>(q0, p0, qout, pout, B, nt, ts, ts0, ts1, h0, eps_abs, eps_rel, row0, inplace, max_sub,   \
-                        status, nsub);                                                                           \
+                        gsl_api, status, nsub);                                                                  \
   }

@@ -468,13 +468,26 @@ template <class S> struct Where {
 
 #define HAMK_WAVE_SMEM(S) __shared__ double smem[hamk::wave::Geo<S::N>::WAVES * hamk::wave::Geo<S::N>::G * hamk::wave::Lds<S>::PER_TRAJ]
 
+template <class S> HAMK_DEV double velocity(const Ctx<S>& c0, double qi, double pi, double& U, int& st);
+
+// hamiltonian of the group's trajectory (every lane returns it)
+template <class S> HAMK_DEV double energy(const Ctx<S>& c, double qi, double pi, int& st) {
+  constexpr int N = S::N, NP = Geo<N>::NP;
+  double U;
+  const double vi = velocity<S>(c, qi, pi, U, st);
+  return fma(0.5, group_sum<NP>((c.li < N) ? vi * pi : 0.0), U);
+}
+
+// drift_tol: see hamk::rk4_body (ST_DRIFT when the launch loses its invariant)
 template <class S>
-HAMK_DEV void rk4_body(double* smem, double* q, double* p, i64 B, double dt, int nsteps, int* status) {
+HAMK_DEV void rk4_body(double* smem, double* q, double* p, i64 B, double dt, int nsteps, double drift_tol, int* status) {
   constexpr int N = S::N;
   Where<S> w(smem, B);
   const int j = (w.c.li < N) ? w.c.li : 0;
   double yq = q[(i64)j * B + w.t], yp = p[(i64)j * B + w.t];
   int st = 0;
+  double H0 = 0.0;
+  if (drift_tol > 0.0) H0 = energy<S>(w.c, yq, yp, st);
   const double h2 = 0.5 * dt, h6 = dt * (1.0 / 6.0), h3 = dt * (1.0 / 3.0);
   double kq = 0.0, kp = 0.0, aq = yq, ap = yp;
 #pragma unroll 1
@@ -486,6 +499,12 @@ HAMK_DEV void rk4_body(double* smem, double* q, double* p, i64 B, double dt, int
     ham_eqs<S>(w.c, tq, tp, kq, kp, st);
     aq = fma(b, kq, aq); ap = fma(b, kp, ap);
     if (sg == 3) { yq = aq; yp = ap; }
+  }
+  if (drift_tol > 0.0) {
+    int st1 = 0;
+    const double H1 = energy<S>(w.c, yq, yp, st1);
+    const double lim = drift_tol * fmax(1.0, fabs(H0));
+    if (!(fabs(H1 - H0) <= lim) || is_nonfinite_bits(H1)) st |= ST_DRIFT;
   }
   const bool bad = is_nonfinite_bits(yq) || is_nonfinite_bits(yp);
   if (bad && w.c.li < N) st |= ST_NONFINITE;
@@ -643,8 +662,11 @@ template <class S> HAMK_DEV void coords_body(double* smem, const double* q, doub
 template <class S>
 HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt,
                          const double* ts, double ts0, double ts1, double h0, double eps_abs, double eps_rel,
-                         int row0, int inplace, int max_sub, int* status, int* nsub) {
+                         int row0, int inplace, int max_sub, int gsl_api, int* status, int* nsub) {
   constexpr int N = S::N, NP = Geo<N>::NP;
+  const bool api2 = gsl_api != 1;
+  const double sgn = (!api2 || h0 > 0.0) ? 1.0 : -1.0;    // odeiv2 driver.c: direction = sign of the initial step
+  bool failed = false;                                    // odeiv2: GSL_FAILURE (uniform within a group)
   Where<S> w(smem, B);
   const int j = (w.c.li < N) ? w.c.li : 0;
   const bool mine = w.c.li < N;
@@ -657,7 +679,7 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
   for (int r = 1; r < nt; ++r) {
     const double ti = ts ? ts[r] : ts1;
     for (;;) {
-      const bool active = (t < ti) && (attempts < max_sub);
+      const bool active = (sgn * (ti - t) > 0.0) && (attempts < max_sub) && !failed;
       if (!__any(active)) break;                           // wave-uniform exit
       const double dt = ti - t;
       double hh = h;
@@ -715,12 +737,13 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
       const double rmax = group_max<NP>(rl);
       const double tnew = final_step ? ti : t + hh;
       const double h_old = hh;
-      bool reject = false;
+      bool reject = false, fail_now = false;
       if (rmax > 1.1) {
         double rr = 0.9 * rpow_inv<5>(rmax);
         if (rr < 0.2) rr = 0.2;
         const double hdec = rr * h_old;
         if (fabs(hdec) < fabs(h_old) && (tnew + hdec) != tnew) { reject = true; hh = hdec; }
+        else if (api2) { fail_now = true; hh = hdec; }       // GSL_FAILURE; y and t stay advanced
       } else if (rmax < 0.5) {
         double rr = 0.9 * rpow_inv<6>(rmax);
         if (rr > 5.0) rr = 5.0;
@@ -729,14 +752,16 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
       }
       if (active) {                                        // evolve.c: accept or undo
         ++attempts;
-        h = hh;
+        if (fail_now) { failed = true; st |= ST_UNDERFLOW; }
+        // the suggested step: always written back by gsl_odeiv; by gsl_odeiv2 not on a final step
+        if (reject || fail_now || !api2 || !final_step) h = hh;
         if (!reject) {
-          if (!(tnew > t)) st |= ST_UNDERFLOW;
+          if (!(sgn * (tnew - t) > 0.0)) st |= ST_UNDERFLOW;
           t = tnew; yq = ynq; yp = ynp; fq = fnq; fp = fnp;
         }
       }
     }
-    if (t < ti) st |= ST_MAXSTEPS;
+    if (sgn * (ti - t) > 0.0 && !failed) st |= ST_MAXSTEPS;
     if (r >= row0 && w.live) {
       double* qo = inplace ? qout : qout + (i64)r * N * B;
       double* po = inplace ? pout : pout + (i64)r * N * B;
@@ -763,9 +788,9 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
 #endif
 #define HAMK_INSTANTIATE_WAVE(S)                                                                                 \
   extern "C" __global__ void __launch_bounds__(256, HAMK_RK4_MIN_WAVES) hamk_rk4_steps_k(double* q, double* p, long long B, \
-                                                                         double dt, int nsteps, int* status) {   \
+                                                          double dt, int nsteps, double drift_tol, int* status) { \
     HAMK_WAVE_SMEM(S);                                                                                           \
-    hamk::wave::rk4_body<S>(smem, q, p, B, dt, nsteps, status);                                                  \
+    hamk::wave::rk4_body<S>(smem, q, p, B, dt, nsteps, drift_tol, status);                                       \
   }                                                                                                              \
   extern "C" __global__ void __launch_bounds__(256) hamk_hameqs_k(const double* q, const double* p, double* dq,  \
                                                                    double* dp, long long B, int* status) {       \
@@ -801,8 +826,8 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
   extern "C" __global__ void __launch_bounds__(256) hamk_rkf45_k(                                                \
       const double* q0, const double* p0, double* qout, double* pout, long long B, int nt, const double* ts,     \
       double ts0, double ts1, double h0, double eps_abs, double eps_rel, int row0, int inplace, int max_sub,     \
-      int* status, int* nsub) {                                                                                  \
+      int gsl_api, int* status, int* nsub) {                                                                     \
     HAMK_WAVE_SMEM(S);                                                                                           \
     hamk::wave::rkf45_body<S>(smem, q0, p0, qout, pout, B, nt, ts, ts0, ts1, h0, eps_abs, eps_rel, row0,         \
-                              inplace, max_sub, status, nsub);                                                   \
+                              inplace, max_sub, gsl_api, status, nsub);                                          \
   }

@@ -80,7 +80,7 @@ class Tape:
         """Plain-float interpretation (host-side sanity check of a recording)."""
         v: List[float] = []
         for op, a, b, c in self.ops:
-            v.append(_EVAL[op](v, xs, a, b, c))
+            v.append(_eval_ieee(op, v, xs, a, b, c))
         return [v[o] for o in self.outs]
 
     def __len__(self):
@@ -137,6 +137,46 @@ _EVAL = {
 }
 
 
+def _eval_ieee(op: int, v, xs, a, b, c) -> float:
+    """One op on fp64 values with IEEE semantics: where Python's math raises (1/0, log 0, sqrt -1,
+    exp 1000) Haskell's Double yields Inf / NaN -- and so must a folded constant."""
+    try:
+        return _EVAL[op](v, xs, a, b, c)
+    except (ZeroDivisionError, ValueError, OverflowError):
+        import numpy as np
+        f8 = np.float64
+        va = f8(v[a]) if op != OP_CONST and op != OP_INPUT else f8(0)
+        with np.errstate(all="ignore"):
+            if op == OP_DIV:
+                r = va / f8(v[b])
+            elif op == OP_RECIP:
+                r = f8(1.0) / va
+            elif op == OP_POWC:
+                r = np.power(va, f8(c))
+            elif op == OP_POW:
+                r = np.power(va, f8(v[b]))
+            elif op == OP_POWI:
+                r = f8(1.0) / f8(_powi_ieee(float(va), -b)) if b < 0 else f8(_powi_ieee(float(va), b))
+            else:
+                r = getattr(np, {OP_SIN: "sin", OP_COS: "cos", OP_TAN: "tan", OP_ASIN: "arcsin", OP_ACOS: "arccos",
+                                 OP_ATAN: "arctan", OP_SINH: "sinh", OP_COSH: "cosh", OP_TANH: "tanh", OP_EXP: "exp",
+                                 OP_LOG: "log", OP_SQRT: "sqrt", OP_ASINH: "arcsinh", OP_ACOSH: "arccosh",
+                                 OP_ATANH: "arctanh"}[op])(va)
+        return float(r)
+
+
+def _powi_ieee(x: float, k: int) -> float:
+    import numpy as np
+    with np.errstate(all="ignore"):
+        r, base = np.float64(1.0), np.float64(x)
+        while k:
+            if k & 1:
+                r = r * base
+            base = base * base
+            k >>= 1
+    return float(r)
+
+
 class Var:
     """A traced fp64 value (the `a` of `forall a. RealFloat a`)."""
     __slots__ = ("tape", "idx")
@@ -170,7 +210,7 @@ class Var:
         ca, cb = a._cv(), b._cv()
         t = self.tape
         if ca is not None and cb is not None:      # constant folding
-            return t.const(_EVAL[op]([ca, cb], None, 0, 1, 0.0))
+            return t.const(_eval_ieee(op, [ca, cb], None, 0, 1, 0.0))
         # exact identities only (x+0, 0+x, x-0, x*1, 1*x, x/1): never change a result bit
         if op == OP_ADD:
             if ca == 0.0:
@@ -234,7 +274,7 @@ class Var:
         ce, cs = ev._cv(), self._cv()
         if ce is not None:
             if cs is not None:
-                return t.const(math.pow(cs, ce))
+                return t.const(_eval_ieee(OP_POWC, [cs], None, 0, 0, ce))
             if ce == math.floor(ce) and abs(ce) <= 64:
                 return powi(self, int(ce))     # x ** 2 must stay valid for x < 0 (Examples.hs:154)
             return Var(t, t.emit(OP_POWC, self.idx, 0, ce))
@@ -251,8 +291,16 @@ class Var:
         raise TypeError("comparison on a traced value: functions that branch on their "
                         "argument (Ord/RealFrac methods) cannot be recorded")
     __lt__ = __le__ = __gt__ = __ge__ = _no_ord
+    # == and != too: identity semantics would silently record one branch of `if x == 0:` (the
+    # Haskell shim's Traced instance has no usable Eq either); Vars stay hashable by identity
+    __eq__ = __ne__ = _no_ord
+    __hash__ = object.__hash__
     __bool__ = _no_ord
     __float__ = _no_ord
+
+    def __abs__(self):
+        raise TypeError("abs/signum of a traced value: |x| is not differentiable at 0 and the tape has no opcode for it "
+                        "(the reference's systems do not use it); write sqrt(x * x) if a smooth-enough |x| is meant")
 
     def __repr__(self):
         return f"Var(v{self.idx})"
@@ -263,9 +311,9 @@ def _unary(op: int, pyf: Callable[[float], float]):
         if isinstance(x, Var):
             c = x._cv()
             if c is not None:
-                return x.tape.const(pyf(c))
+                return x.tape.const(_eval_ieee(op, [c], None, 0, 0, 0.0))
             return Var(x.tape, x.tape.emit(op, x.idx))
-        return pyf(float(x))
+        return _eval_ieee(op, [float(x)], None, 0, 0, 0.0)
     f.__name__ = OP_NAMES[op]
     return f
 
@@ -295,7 +343,7 @@ def powi(x, k: int):
         return _powi(float(x), k)
     c = x._cv()
     if c is not None:
-        return x.tape.const(_powi(c, k))
+        return x.tape.const(_eval_ieee(OP_POWI, [c], None, 0, k, 0.0))
     if k == 0:
         return x.tape.const(1.0)
     if k == 1:

@@ -18,7 +18,9 @@
  *   hamEqs :370-387                                     hamk_hameqs_batch
  *   stepHam :390-402                                    hamk_step_ham_batch   (adaptive RKF45, GSL semantics)
  *   evolveHam :433-462, evolveHam' :409-429             hamk_evolve_ham_batch (adaptive RKF45, GSL semantics)
+ *   odeSolveV's GSL binding (:445, hmatrix-gsl)         hamk_system_set_gsl_api (gsl_odeiv2 driver | old gsl_odeiv)
  *   (no counterpart; named by BASELINE.json north_star) hamk_rk4_steps        (classic fixed-step RK4)
+ *   (no counterpart)            hamk_rk4_steps_checked, hamk_checkpoint_*
  *
  * The reference evaluates ONE trajectory per call on the CPU through `ad`
  * (AD), hmatrix (LAPACK/BLAS) and hmatrix-gsl (GSL odeiv).  This library
@@ -80,8 +82,10 @@ extern "C" {
 /* ---- per-trajectory status bits --------------------------------------- */
 #define HAMK_ST_SINGULAR   1  /* mass matrix K = J^T M J not invertible (reference: hmatrix `inv` throws) */
 #define HAMK_ST_NONFINITE  2  /* state became NaN/Inf                          */
-#define HAMK_ST_UNDERFLOW  4  /* adaptive step could not advance time (h -> 0) */
+#define HAMK_ST_UNDERFLOW  4  /* adaptive step could not advance time (h -> 0); with gsl_odeiv2 semantics:
+                                 GSL_FAILURE out of evolve_apply -- the trajectory stops where it is         */
 #define HAMK_ST_MAXSTEPS   8  /* adaptive stepper hit its sub-step budget      */
+#define HAMK_ST_DRIFT     16  /* hamk_rk4_steps_checked: the launch lost its energy invariant */
 
 /* ---- where caller pointers live ---------------------------------------- */
 #define HAMK_MEM_HOST    0
@@ -153,10 +157,30 @@ int hamk_set_stream(hamk_system* s, void* hip_stream);
 /* Block until everything queued on the handle's stream has finished.        */
 int hamk_synchronize(hamk_system* s);
 
+/* Which of the two GSL bindings in hmatrix-gsl's gsl-ode.c stepHam / evolveHam reproduce
+ * (`odeSolveV`, Hamilton.hs:445):
+ *   2 (default; gsl-ode.c's default build): gsl_odeiv2 -- gsl_odeiv2_driver_apply per output time.
+ *     evolve_apply does not write the controller's step size back on a final (clipped) step; the
+ *     direction of integration is the sign of the initial step, so a monotone DEcreasing time grid
+ *     integrates backwards and a grid that changes direction is HAMK_ERR_INVALID (GSL_EINVAL); a
+ *     step that must shrink but cannot is GSL_FAILURE: the trajectory stops, HAMK_ST_UNDERFLOW.
+ *   1 (gsl-ode.c built with -DGSLODE1): old gsl_odeiv -- `while (t < ti) gsl_odeiv_evolve_apply`.
+ *     h is written back after every accepted step; repeated / decreasing times do no stepping.
+ * One trajectory over a single interval (stepHam from h0 = dt/100) takes the same steps under
+ * both; they differ from the second output time of evolveHam on, at truncation level (~eps).
+ * The environment variable HAMK_GSL_API=1|2 sets the default of new handles.                     */
+int     hamk_system_set_gsl_api(hamk_system* s, int32_t api);
+int32_t hamk_system_get_gsl_api(const hamk_system* s);
+
 /* Generated HIP source of the specialised module (for inspection/tests).    */
 const char* hamk_system_source(const hamk_system* s);
 /* Number of bytes of gfx950 code object produced by the specialisation.     */
 int64_t hamk_system_code_size(const hamk_system* s);
+/* The gfx950 code object(s) the kernels are loaded from (which = 0: default build, 1: the build
+ * without MachineLICM, empty unless a kernel is taken from it).  Returns the size in bytes and, if
+ * buf != NULL and cap is large enough, copies the ELF into buf -- so a host can disassemble what
+ * actually runs (bench.py counts the fp64 instructions of the stepping loop from it).            */
+int64_t hamk_system_code_object(const hamk_system* s, int32_t which, void* buf, int64_t cap);
 /* One line per kernel: which of the two builds it is taken from (default options, or without
  * MachineLICM when that spills fewer SGPRs), its code bytes and its spilled SGPRs.             */
 const char* hamk_system_build_info(const hamk_system* s);
@@ -199,6 +223,15 @@ int hamk_hameqs_batch(hamk_system* s, int64_t B, const double* q, const double* 
 int hamk_rk4_steps(hamk_system* s, int64_t B, double* q, double* p,
                    double dt, int32_t nsteps, int32_t* status, int32_t mem);
 
+/* The same, with the launch checking its own invariant: H = hamiltonian (Hamilton.hs:353-361) is
+ * evaluated at entry and exit (two extra evaluations per launch, nothing per step) and
+ * HAMK_ST_DRIFT is set where |H_exit - H_entry| > drift_tol * max(1, |H_entry|).  A fixed step
+ * through a near-singularity (close encounter of the gravitational systems) is
+ * otherwise silently wrong -- the reference's analogous failure raises out of `inv`
+ * (Hamilton.hs:321,381).  drift_tol <= 0 disables the check (= hamk_rk4_steps).               */
+int hamk_rk4_steps_checked(hamk_system* s, int64_t B, double* q, double* p,
+                           double dt, int32_t nsteps, double drift_tol, int32_t* status, int32_t mem);
+
 /* stepHam dt: adaptive RKF45 with GSL's standard controller from 0 to dt,
  * h0 = dt/100, eps_abs = eps_rel = 1.49012e-08, IN PLACE.  Hamilton.hs:390-402,
  * :445-448.  nsub (optional, [B]) receives accepted+rejected sub-step counts. */
@@ -208,8 +241,8 @@ int hamk_step_ham_batch(hamk_system* s, int64_t B, double* q, double* p, double 
 /* evolveHam: states at each of the nt >= 2 requested times ts[] (host array);
  * qout/pout are [nt][n][B]; row 0 is the initial state (Hamilton.hs:443-462).
  * h0 = (ts[1]-ts[0])/100 and the step size carries across output times, as in
- * hmatrix-gsl's `odeSolveV`.  Pass h0 <= 0 / eps <= 0 for the reference
- * defaults.                                                                    */
+ * hmatrix-gsl's `odeSolveV` (how exactly: hamk_system_set_gsl_api).  Pass h0 <= 0 /
+ * eps <= 0 for the reference defaults.                                         */
 int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const double* p0,
                           int32_t nt, const double* ts, double* qout, double* pout,
                           double h0, double eps_abs, double eps_rel,
@@ -237,6 +270,19 @@ int hamk_memcpy(void* dst, const void* src, int64_t bytes, int32_t kind);   /* s
  * running on other streams -- hamk_synchronize the handles that produce the parts first.        */
 int hamk_gather_batch(int32_t nparts, int32_t n, const int64_t* B_parts, const double* const* parts,
                       double* out, int32_t out_mem);
+
+/* ---- ensemble checkpoint (no reference counterpart) -----------------------
+ * One file = 64-byte header (magic "HAMKCKP1", n, B, steps_done, seed, t), q[n][B], p[n][B] as raw
+ * little-endian fp64, SHA-256 of all of it.  q, p may be host or device arrays (mem); device state
+ * is staged in 8 MiB pieces.  Written aside and renamed: a crash leaves the previous file.
+ * steps_done / seed / t are the caller's bookkeeping (per-index splitmix64 seed of the initial
+ * conditions, steps taken, model time) and come back from hamk_checkpoint_info.  A resumed run is
+ * bit-identical to an uninterrupted one (every kernel is a pure function of the state).          */
+int hamk_checkpoint_write(const char* path, int32_t n, int64_t B, const double* q, const double* p,
+                          int32_t mem, int64_t steps_done, uint64_t seed, double t);
+int hamk_checkpoint_info(const char* path, int32_t* n, int64_t* B, int64_t* steps_done,
+                         uint64_t* seed, double* t);                    /* outputs may be NULL */
+int hamk_checkpoint_read(const char* path, int32_t n, int64_t B, double* q, double* p, int32_t mem);
 
 /* ---- diagnostics ---------------------------------------------------------- */
 const char* hamk_last_error(void);

@@ -25,10 +25,17 @@
  *   hmatrix       (inv, <>, #>, <.>, tr, diag; Hamilton.hs:267,321-324,377-387)
  *                   -> `inv` = LAPACK dgesv against the identity: LU with
  *                      partial (row) pivoting; restated below.
- *   hmatrix-gsl   (odeSolveV RKf45, Hamilton.hs:445) -> GSL gsl_odeiv (old
- *                   API): rkf45.c stepper, cstd.c standard controller with
- *                   a_y = a_dydt = 1, evolve.c evolve_apply, gsl-ode.c loop.
- *                   Restated from the published algorithm (SURVEY.md section 8c box).
+ *   hmatrix-gsl   (odeSolveV RKf45, Hamilton.hs:445) -> GSL: rkf45.c stepper,
+ *                   cstd.c standard controller with a_y = a_dydt = 1, evolve.c
+ *                   evolve_apply, and hmatrix-gsl's gsl-ode.c output loop.
+ *                   gsl-ode.c carries TWO bindings, chosen at its build time:
+ *                   `#ifdef GSLODE1` the old gsl_odeiv API (a `while (t < ti)
+ *                   gsl_odeiv_evolve_apply` loop), otherwise -- the default --
+ *                   gsl_odeiv2 through gsl_odeiv2_driver_apply.  They differ in
+ *                   the evolve rule (see evolve_apply below); both are restated,
+ *                   selected per system with orc_system_set_gsl_api (default 2).
+ *                   Restated from the published algorithm (SURVEY.md section 8c box
+ *                   for v1; DESIGN.md section 2.4 for what odeiv2 changes).
  *
  * Index conventions (Hamilton.hs:188-192, :221-222, :227-233):
  *   J[k][i]    = d f_k / d q_i                 (m rows, n columns)
@@ -54,6 +61,7 @@ typedef struct orc_system {
   double* inertia;
   orc_op* f_ops; int f_nops; int32_t* f_outs;
   orc_op* u_ops; int u_nops; int32_t u_out;
+  int gsl_api;   /* 1: gsl_odeiv (hmatrix-gsl built with -DGSLODE1), 2: gsl_odeiv2 driver (its default) */
 } orc_system;
 
 
@@ -292,6 +300,7 @@ orc_system* orc_system_create(int m, int n, const double* inertia, const orc_op*
   s->f_outs = (int32_t*)malloc(sizeof(int32_t) * m); memcpy(s->f_outs, f_outs, sizeof(int32_t) * m);
   s->u_ops = (orc_op*)malloc(sizeof(orc_op) * (u_nops + 1)); memcpy(s->u_ops, u_ops, sizeof(orc_op) * u_nops);
   s->u_nops = u_nops; s->u_out = u_out;
+  s->gsl_api = 2;
   return s;
 }
 void orc_system_destroy(orc_system* s) {
@@ -495,15 +504,33 @@ static int std_hadjust(int dim, double eps_abs, double eps_rel, const double* y,
   return 0;
 }
 
-/* GSL evolve.c gsl_odeiv_evolve_apply (old odeiv API) */
-static void evolve_apply(const orc_system* s, int dim, double eps_abs, double eps_rel, double* t, double t1,
-                         double* h, double* y, rkf_ws* w, long* nrhs, long* nacc, long* nrej) {
+/* GSL evolve.c: gsl_odeiv_evolve_apply (api 1) / gsl_odeiv2_evolve_apply (api 2), one call =
+ * one ACCEPTED step (or, api 2 only, a failure).  The two differ in exactly two places:
+ *   (a) the step size suggested for the next call: api 1 always writes the controller's h back;
+ *       api 2 does not on a final (clipped-to-t1) step -- "that step can be very small compared to
+ *       the previous step" -- so the h carried to the next output time is the last unclipped one;
+ *   (b) when the controller asks for a smaller step but h cannot shrink any more (the decreased h
+ *       no longer changes t): api 1 keeps the step size and accepts the step; api 2 leaves y
+ *       advanced, reports h and returns GSL_FAILURE (-> returns 1 here).
+ * api 2 also re-uses dydt_out of the previous step as dydt_in instead of evaluating f(t0, y) again
+ * (e->count > 0): the same numbers, one evaluation fewer; nrhs counts what each API really does.
+ * trace (optional): per attempt (t reached, h tried, accepted ? 1 : 0), at most trace_cap triples. */
+typedef struct { double* buf; long cap, n; } orc_trace;
+static void trace_put(orc_trace* tr, double t, double h, double acc) {
+  if (tr && tr->buf && tr->n < tr->cap) { tr->buf[3 * tr->n] = t; tr->buf[3 * tr->n + 1] = h; tr->buf[3 * tr->n + 2] = acc; }
+  if (tr) tr->n++;
+}
+static int evolve_apply(const orc_system* s, int dim, double eps_abs, double eps_rel, double* t, double t1,
+                        double* h, double* y, rkf_ws* w, long* nrhs, long* nacc, long* nrej, int have_dydt,
+                        orc_trace* tr) {
+  const int api2 = s->gsl_api != 1;
   const double t0 = *t;
   double h0 = *h;
   int final_step = 0;
   const double dt = t1 - t0;
   memcpy(w->y0, y, sizeof(double) * dim);
-  rhs(s, y, w->dydt_in); *nrhs += 1;
+  if (api2 && have_dydt) memcpy(w->dydt_in, w->dydt_out, sizeof(double) * dim);
+  else { rhs(s, y, w->dydt_in); *nrhs += 1; }
   for (;;) {
     if ((dt >= 0.0 && h0 > dt) || (dt < 0.0 && h0 < dt)) { h0 = dt; final_step = 1; } else final_step = 0;
     rkf45_apply(s, dim, h0, y, w->yerr, w->dydt_in, w->dydt_out, w, nrhs);
@@ -514,25 +541,42 @@ static void evolve_apply(const orc_system* s, int dim, double eps_abs, double ep
       const volatile double t_curr = *t;
       const volatile double t_next = (*t) + h0;
       if (fabs(h0) < fabs(h_old) && t_next != t_curr) {
+        trace_put(tr, *t, h_old, 0.0);
         memcpy(y, w->y0, sizeof(double) * dim);      /* undo step, retry with smaller h0 */
         *nrej += 1;
         continue;
+      } else if (api2) {
+        trace_put(tr, *t, h_old, -1.0);
+        *h = h0;                                     /* "notify user of step-size which caused the failure" */
+        return 1;                                    /* GSL_FAILURE; y and t stay advanced */
       } else {
         h0 = h_old;                                  /* keep current step size */
       }
     }
+    trace_put(tr, *t, h_old, 1.0);
     break;
   }
   *nacc += 1;
-  *h = h0;
+  if (!api2 || !final_step) *h = h0;
+  return 0;
 }
 
 /* evolveHam (Hamilton.hs:433-462) through hmatrix-gsl's gsl-ode.c loop:
  * out is [nt][2n] = rows [q; p]; row 0 = initial state; h carries across ts.
- * h0 <= 0 selects the reference's (ts[1]-ts[0])/100; eps <= 0 selects 1.49012e-08.
- * counts (optional, 3 longs): rhs evaluations, accepted steps, rejected steps. */
-void orc_evolve_ham(const orc_system* s, const double* q0, const double* p0, int nt, const double* ts,
-                    double* out, double h0, double eps_abs, double eps_rel, long* counts) {
+ * h0 > 0 is taken as given, otherwise the reference's (ts[1]-ts[0])/100 (Hamilton.hs:447);
+ * eps <= 0 selects 1.49012e-08 (:448).
+ * api 1: `for each ti: while (t < ti) gsl_odeiv_evolve_apply` -- a repeated or decreasing time does
+ *        no stepping.
+ * api 2: `for each ti: gsl_odeiv2_driver_apply(d, &t, ti, y)`; driver.c: the direction is the sign of
+ *        the initial step (h > 0 ? +1 : -1), the loop is `while (sign (t1 - t) > 0)`, a ti on the
+ *        wrong side is GSL_EINVAL, a failing evolve_apply ends the call -- gsl-ode.c then prints
+ *        "error in ode" and leaves the remaining rows as they are (uninitialised memory in the
+ *        reference; here: the last state reached).  hmin = 0, hmax = DBL_MAX, nmax = 0 (defaults).
+ * counts (optional, 4 longs): rhs evaluations, accepted steps, rejected steps,
+ *        failure (0 none, 1 GSL_FAILURE from evolve_apply, 2 GSL_EINVAL direction). */
+void orc_evolve_ham_trace(const orc_system* s, const double* q0, const double* p0, int nt, const double* ts,
+                          double* out, double h0, double eps_abs, double eps_rel, long* counts, double* trace,
+                          long trace_cap) {
   WS_ENTER;
   int n = s->n, dim = 2 * n;
   if (!(h0 > 0)) h0 = (ts[1] - ts[0]) / 100.0;
@@ -545,15 +589,29 @@ void orc_evolve_ham(const orc_system* s, const double* q0, const double* p0, int
   memcpy(y, q0, sizeof(double) * n); memcpy(y + n, p0, sizeof(double) * n);
   memcpy(out, y, sizeof(double) * dim);
   double t = ts[0], h = h0;
-  long nrhs = 0, nacc = 0, nrej = 0;
+  long nrhs = 0, nacc = 0, nrej = 0, fail = 0;
+  orc_trace tr = {trace, trace_cap, 0};
+  const int api2 = s->gsl_api != 1;
+  const double sign = (!api2 || h0 > 0.0) ? 1.0 : -1.0;
+  int have_dydt = 0;
   for (int i = 1; i < nt; i++) {
     const double ti = ts[i];
-    while (t < ti) evolve_apply(s, dim, eps_abs, eps_rel, &t, ti, &h, y, &w, &nrhs, &nacc, &nrej);
+    if (api2 && !fail && sign * (ti - t) < 0.0) fail = 2;
+    while (!fail && sign * (ti - t) > 0.0) {
+      if (evolve_apply(s, dim, eps_abs, eps_rel, &t, ti, &h, y, &w, &nrhs, &nacc, &nrej, have_dydt, &tr)) fail = 1;
+      have_dydt = 1;
+    }
     memcpy(out + (size_t)i * dim, y, sizeof(double) * dim);
   }
-  if (counts) { counts[0] = nrhs; counts[1] = nacc; counts[2] = nrej; }
-  WS_LEAVE; 
+  if (counts) { counts[0] = nrhs; counts[1] = nacc; counts[2] = nrej; counts[3] = fail; }
+  WS_LEAVE;
 }
+void orc_evolve_ham(const orc_system* s, const double* q0, const double* p0, int nt, const double* ts,
+                    double* out, double h0, double eps_abs, double eps_rel, long* counts) {
+  orc_evolve_ham_trace(s, q0, p0, nt, ts, out, h0, eps_abs, eps_rel, counts, NULL, 0);
+}
+void orc_system_set_gsl_api(orc_system* s, int api) { s->gsl_api = (api == 1) ? 1 : 2; }
+int orc_system_get_gsl_api(const orc_system* s) { return s->gsl_api; }
 
 /* stepHam r = evolveHam on (0, r), element 1 (Hamilton.hs:400-402) */
 void orc_step_ham(const orc_system* s, double r, double* q, double* p, long* counts) {
@@ -674,26 +732,28 @@ void orc_rk4_steps_batch(const orc_system* s, long B, double* q, double* p, doub
   }
 }
 
-void orc_step_ham_batch(const orc_system* s, long B, double* q, double* p, double dt, int32_t* nsub, int threads) {
+/* fail (optional, [B]): 0, or the api-2 failure code of orc_evolve_ham's counts[3] */
+void orc_step_ham_batch(const orc_system* s, long B, double* q, double* p, double dt, int32_t* nsub, int32_t* fail, int threads) {
   int n = s->n; set_threads(threads);
 #pragma omp parallel for schedule(dynamic, 64)
   for (long i = 0; i < B; i++) {
-    double a[64], b[64]; long counts[3];
+    double a[64], b[64]; long counts[4];
     GATHER(a, q, n, B, i); GATHER(b, p, n, B, i);
     orc_step_ham(s, dt, a, b, counts);
     SCATTER(q, a, n, B, i); SCATTER(p, b, n, B, i);
-    if (nsub) nsub[i] = (int32_t)(counts[1] + counts[2]);
+    if (nsub) nsub[i] = (int32_t)(counts[1] + counts[2] + (counts[3] == 1));   /* attempts, the failing one included */
+    if (fail) fail[i] = (int32_t)counts[3];
   }
 }
 
 /* qout/pout [nt][n][B] like hamk_evolve_ham_batch */
 void orc_evolve_ham_batch(const orc_system* s, long B, const double* q0, const double* p0, int nt,
                           const double* ts, double* qout, double* pout, double h0, double eps_abs,
-                          double eps_rel, int32_t* nsub, int threads) {
+                          double eps_rel, int32_t* nsub, int32_t* fail, int threads) {
   int n = s->n; set_threads(threads);
 #pragma omp parallel for schedule(dynamic, 64)
   for (long i = 0; i < B; i++) {
-    double a[64], b[64]; long counts[3];
+    double a[64], b[64]; long counts[4];
     double* out = (double*)malloc(sizeof(double) * 2 * n * nt);
     GATHER(a, q0, n, B, i); GATHER(b, p0, n, B, i);
     orc_evolve_ham(s, a, b, nt, ts, out, h0, eps_abs, eps_rel, counts);
@@ -701,7 +761,8 @@ void orc_evolve_ham_batch(const orc_system* s, long B, const double* q0, const d
       SCATTER(qout + (size_t)r * n * B, out + (size_t)r * 2 * n, n, B, i);
       SCATTER(pout + (size_t)r * n * B, out + (size_t)r * 2 * n + n, n, B, i);
     }
-    if (nsub) nsub[i] = (int32_t)(counts[1] + counts[2]);
+    if (nsub) nsub[i] = (int32_t)(counts[1] + counts[2] + (counts[3] == 1));   /* attempts, the failing one included */
+    if (fail) fail[i] = (int32_t)counts[3];
     free(out);
   }
 }

@@ -41,6 +41,7 @@ def lib():
         _lib.orc_keP.restype = ctypes.c_double
         _lib.orc_lagrangian.restype = ctypes.c_double
         _lib.orc_hamiltonian.restype = ctypes.c_double
+        _lib.orc_system_get_gsl_api.restype = ctypes.c_int
     return _lib
 
 
@@ -126,7 +127,7 @@ class OracleSystem:
 
     def step_ham(self, dt, q, p, counts: Optional[list] = None):
         q, p = _vec(q).copy(), _vec(p).copy()
-        c = (ctypes.c_long * 3)()
+        c = (ctypes.c_long * 4)()
         lib().orc_step_ham(self._h, ctypes.c_double(dt), _d(q), _d(p), c)
         if counts is not None:
             counts[:] = list(c)
@@ -135,7 +136,7 @@ class OracleSystem:
     def evolve_ham(self, q0, p0, ts, h0=0.0, eps_abs=0.0, eps_rel=0.0, counts: Optional[list] = None):
         q0, p0, ts = _vec(q0), _vec(p0), _vec(ts)
         out = np.empty((len(ts), 2 * self.n))
-        c = (ctypes.c_long * 3)()
+        c = (ctypes.c_long * 4)()
         lib().orc_evolve_ham(self._h, _d(q0), _d(p0), ctypes.c_int(len(ts)), _d(ts), _d(out),
                              ctypes.c_double(h0), ctypes.c_double(eps_abs), ctypes.c_double(eps_rel), c)
         if counts is not None:
@@ -186,17 +187,42 @@ class OracleSystem:
 
     def step_ham_batch(self, q, p, dt, threads=0):
         q, p = _vec(q).copy(), _vec(p).copy(); B = q.shape[1]; ns = np.zeros(B, dtype=np.int32)
+        self.last_fail = np.zeros(B, dtype=np.int32)
         lib().orc_step_ham_batch(self._h, ctypes.c_long(B), _d(q), _d(p), ctypes.c_double(dt),
-                                 ns.ctypes.data_as(_ip), ctypes.c_int(threads))
+                                 ns.ctypes.data_as(_ip), self.last_fail.ctypes.data_as(_ip), ctypes.c_int(threads))
         return q, p, ns
 
     def evolve_ham_batch(self, q0, p0, ts, h0=0.0, eps_abs=0.0, eps_rel=0.0, threads=0):
         q0, p0, ts = _vec(q0), _vec(p0), _vec(ts); B = q0.shape[1]; nt = len(ts)
         qo, po = np.empty((nt, self.n, B)), np.empty((nt, self.n, B)); ns = np.zeros(B, dtype=np.int32)
+        self.last_fail = np.zeros(B, dtype=np.int32)
         lib().orc_evolve_ham_batch(self._h, ctypes.c_long(B), _d(q0), _d(p0), ctypes.c_int(nt), _d(ts),
                                    _d(qo), _d(po), ctypes.c_double(h0), ctypes.c_double(eps_abs),
-                                   ctypes.c_double(eps_rel), ns.ctypes.data_as(_ip), ctypes.c_int(threads))
+                                   ctypes.c_double(eps_rel), ns.ctypes.data_as(_ip),
+                                   self.last_fail.ctypes.data_as(_ip), ctypes.c_int(threads))
         return qo, po, ns
+
+    # ---- which GSL binding of hmatrix-gsl's gsl-ode.c the adaptive stepper follows --------
+    @property
+    def gsl_api(self) -> int:
+        return int(lib().orc_system_get_gsl_api(self._h))
+
+    @gsl_api.setter
+    def gsl_api(self, api: int):
+        lib().orc_system_set_gsl_api(self._h, ctypes.c_int(int(api)))
+
+    def evolve_ham_trace(self, q0, p0, ts, h0=0.0, eps_abs=0.0, eps_rel=0.0, cap=100000):
+        """One trajectory with the per-attempt trace [(t reached, h tried, 1 accepted / 0 rejected /
+        -1 api-2 failure), ...]; returns (q rows, p rows, counts, trace)."""
+        q0, p0, ts = _vec(q0), _vec(p0), _vec(ts)
+        out = np.empty((len(ts), 2 * self.n))
+        c = (ctypes.c_long * 4)()
+        tr = np.zeros((cap, 3))
+        lib().orc_evolve_ham_trace(self._h, _d(q0), _d(p0), ctypes.c_int(len(ts)), _d(ts), _d(out),
+                                   ctypes.c_double(h0), ctypes.c_double(eps_abs), ctypes.c_double(eps_rel), c,
+                                   _d(tr), ctypes.c_long(cap))
+        k = int(c[1] + c[2] + (1 if c[3] == 1 else 0))
+        return out[:, :self.n].copy(), out[:, self.n:].copy(), list(c), tr[:min(k, cap)].copy()
 
 
 def max_threads() -> int:

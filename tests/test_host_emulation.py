@@ -108,26 +108,79 @@ def check_against_oracle(L, spec, o, B=48, start=11, tol=1e-11, steps=3, dt_ham=
     assert np.all(e3[same] <= 100 * tol * scale[same]), float(np.max(e3[same] / scale[same]))
 
 
-def test_evolveham_time_grid_on_host(emulate, oracle_lib):
-    """hmatrix-gsl's output loop (`for each ti: while (t < ti) step`, h carried across output times,
-    row 0 = the initial state; repeated and decreasing times do no stepping): the RKF45 body with a
-    time grid against the oracle's restatement, sub-step counts included."""
+@pytest.mark.parametrize("api", [1, 2])
+def test_evolveham_time_grid_on_host(emulate, oracle_lib, api):
+    """hmatrix-gsl's output loop under both of gsl-ode.c's bindings (hamk.h: hamk_system_set_gsl_api).
+    api 1, old gsl_odeiv: `for each ti: while (t < ti) step`, h written back after every accepted
+    step; repeated and decreasing times do no stepping.  api 2, gsl_odeiv2 driver (the default):
+    h is NOT written back on a final (clipped) step, a repeated time does no stepping.  Row 0 = the
+    initial state.  The RKF45 body with a time grid against the oracle's restatement of the same
+    binding: identical sub-step counts on every lane, states to roundoff."""
+    spec = E.get("doublePendulum")
+    o = oracle_lib.OracleSystem(spec)
+    o.gsl_api = api
+    L, _ = emulate(spec)
+    L.emu_set_gsl_api(api)
+    try:
+        B = 40
+        q, qd = E.sample_config(spec, 3, B)
+        p = o.to_phase_batch(q, qd)
+        ts = np.array([0.0, 0.05, 0.05, 0.02, 0.2, 0.21]) if api == 1 else np.array([0.0, 0.05, 0.05, 0.12, 0.2, 0.21])
+        qo, po = np.zeros((len(ts), spec.n, B)), np.zeros((len(ts), spec.n, B))
+        st, ns = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        L.emu_evolve_ham(P(q), P(p), len(ts), P(ts), P(qo), P(po), LL(B), I(st), I(ns))
+        oq, op, ons = o.evolve_ham_batch(q, p, ts)
+        assert not st.any() and not o.last_fail.any() and np.array_equal(qo[0], q) and np.array_equal(po[0], p)
+        assert np.array_equal(qo[2], qo[1])
+        if api == 1:
+            assert np.array_equal(qo[3], qo[1])
+        assert np.array_equal(ns, ons), (ns[:8], ons[:8])
+        assert relerr(qo, oq) < 1e-11 and relerr(po, op) < 1e-11
+        # the two bindings are different integrators from the second output time on
+        o.gsl_api = 3 - api
+        tsm = np.array([0.0, 0.05, 0.12, 0.2, 0.21])
+        xq, xp, xns = o.evolve_ham_batch(q, p, tsm)
+        o.gsl_api = api
+        yq, yp, yns = o.evolve_ham_batch(q, p, tsm)
+        assert np.array_equal(xq[1], yq[1]) and not np.array_equal(xq[2], yq[2]) and not np.array_equal(xns, yns)
+        assert relerr(xq, yq) < 1e-6                       # ... that agree to the controller's tolerance
+    finally:
+        L.emu_set_gsl_api(2)
+
+
+def test_odeiv2_backward_grid_and_failure_on_host(emulate, oracle_lib):
+    """gsl_odeiv2 semantics the old API does not have: (a) the direction of integration is the sign
+    of the initial step, so a monotone decreasing grid integrates BACKWARDS (the old API's
+    `while (t < ti)` does nothing); (b) a step that must shrink but cannot -- here: tolerances no
+    fp64 step can meet -- is GSL_FAILURE: the lane stops, ST_UNDERFLOW, later rows = last state."""
     spec = E.get("doublePendulum")
     o = oracle_lib.OracleSystem(spec)
     L, _ = emulate(spec)
-    B = 40
-    q, qd = E.sample_config(spec, 3, B)
+    B = 12
+    q, qd = E.sample_config(spec, 5, B)
     p = o.to_phase_batch(q, qd)
-    ts = np.array([0.0, 0.05, 0.05, 0.02, 0.2, 0.21])
-    qo, po = np.zeros((len(ts), spec.n, B)), np.zeros((len(ts), spec.n, B))
+    ts = np.array([0.0, -0.05, -0.12])
+    qo, po = np.zeros((3, spec.n, B)), np.zeros((3, spec.n, B))
     st, ns = np.zeros(B, np.int32), np.zeros(B, np.int32)
-    L.emu_evolve_ham(P(q), P(p), len(ts), P(ts), P(qo), P(po), LL(B), I(st), I(ns))
+    L.emu_evolve_ham(P(q), P(p), 3, P(ts), P(qo), P(po), LL(B), I(st), I(ns))
     oq, op, ons = o.evolve_ham_batch(q, p, ts)
-    assert not st.any() and np.array_equal(qo[0], q) and np.array_equal(po[0], p)
-    assert np.array_equal(qo[2], qo[1]) and np.array_equal(qo[3], qo[1])
-    same = ns == ons
-    assert same.mean() > 0.9
-    assert relerr(qo[:, :, same], oq[:, :, same]) < 1e-10 and relerr(po[:, :, same], op[:, :, same]) < 1e-10
+    assert not st.any() and np.array_equal(ns, ons) and ns.min() > 2
+    assert relerr(qo, oq) < 1e-11 and relerr(po, op) < 1e-11
+    fq, fp, _ = o.evolve_ham_batch(oq[2], op[2], np.array([-0.12, 0.0]))          # and forward again: back at the start
+    assert relerr(fq[1], q) < 1e-6 and relerr(fp[1], p) < 1e-6
+    o.gsl_api = 1
+    nq, _, nns = o.evolve_ham_batch(q, p, ts)
+    assert np.array_equal(nq[2], q) and not nns.any()                                # old API: no stepping at all
+    o.gsl_api = 2
+    # (b)
+    ts = 1.0e6 + np.array([0.0, 0.05, 0.1])           # 1 ulp of t is 1.2e-10: h shrinks below it long before any
+    eps = 1e-30                                        # step could meet this tolerance (roundoff in yerr ~ 1e-17 h)
+    st[:] = 0
+    L.emu_evolve_ham_eps(P(q), P(p), 3, P(ts), P(qo), P(po), LL(B), ctypes.c_double(eps), ctypes.c_double(eps), 5000, I(st), I(ns))
+    oq, op, ons = o.evolve_ham_batch(q, p, ts, eps_abs=eps, eps_rel=eps)
+    assert np.all(o.last_fail == 1) and np.all(st == 4), (o.last_fail, st)            # HAMK_ST_UNDERFLOW, nothing else
+    assert np.array_equal(ns, ons) and 8 <= ns.min() and ns.max() < 20                # 0.2x per rejection down to 1 ulp of t
+    assert relerr(qo, oq) < 1e-10 and np.array_equal(qo[2], qo[1]) and relerr(qo[1], q) < 1e-3
 
 
 def test_device_rkf45_step_is_fifth_order(emulate, oracle_lib):

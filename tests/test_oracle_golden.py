@@ -133,11 +133,18 @@ def test_trajectories_against_taylor_truth(systems, name):
 
 def test_gsl_step_accounting(systems):
     """stepHam 0.01 on the double pendulum from seInit: 4 accepted sub-steps
-    (1e-4 -> 5e-4 -> 2.5e-3 -> remainder), no rejects, 28 RHS evaluations."""
+    (1e-4 -> 5e-4 -> 2.5e-3 -> remainder), no rejects.  Old gsl_odeiv evaluates dydt_in at the top of
+    every evolve_apply: 4 x 7 = 28 RHS evaluations; gsl_odeiv2 re-uses
+    dydt_out of the previous step: 1 + 4 x 6 = 25.  Same states either way (one interval)."""
     o, spec = systems["doublePendulum"], E.get("doublePendulum")
-    counts = []
-    o.step_ham(0.01, spec.q0, [0.0, 0.0], counts)
-    assert counts == [28, 4, 0]
+    res = {}
+    for api, want in ((1, [28, 4, 0, 0]), (2, [25, 4, 0, 0])):
+        o.gsl_api = api
+        counts = []
+        res[api] = o.step_ham(0.01, spec.q0, [0.0, 0.0], counts)
+        assert counts == want, (api, counts)
+    o.gsl_api = 2
+    np.testing.assert_array_equal(res[1][0], res[2][0]); np.testing.assert_array_equal(res[1][1], res[2][1])
 
 
 def test_evolve_ham_rows_and_carry(systems):
