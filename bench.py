@@ -14,13 +14,20 @@ Multi-GPU: the ensemble shards by contiguous global index range (weak scaling: e
 owns --batch trajectories); there is no data-path collective; one RCCL all_gather of the
 final state runs after the timed region (reported as gather_ms).
 
-Prints ONE JSON line on rank 0.  `roofline.achieved` follows SURVEY.md section 8d: 32*n
-algorithmic bytes per trajectory-step (charged per RK4 step even though rk4-per-step steps
-are fused per launch; `roofline.state_bytes_moved_per_launch` is what a launch really reads and
-writes, matched by the PMC figure in `traffic`), divided by
-the kernel's average duration measured with HIP events on the launch stream.  The path is
-FP64-VALU bound, not HBM bound: the fp64 object next to it is the figure
-that says how good the kernel is.
+Prints ONE JSON line on rank 0.
+
+`roofline` has two readings, and says which one binds:
+  * the north-star yardstick: `achieved` = 32*n algorithmic bytes per
+    trajectory-step -- charged per RK4 step although --rk4-per-step steps are fused per launch and
+    the state stays in registers in between -- divided by the kernel's average duration measured
+    with HIP events on the launch stream.  It is NOTIONAL bandwidth: `roofline.hbm_physical` is what
+    a launch really moves (state in + state out + status), its GB/s, and the PMC figure it matches
+    (`traffic`, static from profiles/, labelled as such);
+  * `roofline.fp64`: what physically bounds the kernel.  fp64 flops and VALU
+    instructions per RK4 step are COUNTED from the code object of this system (llvm-objdump of its
+    stepping loop, scripts/isa_stats.py), giving achieved TFLOP/s against the 78.6 TFLOP/s vector
+    fp64 peak and the fraction of VALU issue slots used (every VALU instruction of a wavefront
+    occupies its SIMD's 16 lanes for 4 cycles; 1024 SIMDs x 2.4 GHz nominal).
 """
 from __future__ import annotations
 
@@ -41,6 +48,13 @@ from hamilton_amd import api, ensemble, examples  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6        # vector fp64 = 1/2 of the 157.3 TF fp32 vector peak
+N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs
+NOMINAL_HZ = 2.4e9
+# fused steps per launch = the config's nsteps (C2-C4: 1000, C5: 200)
+DEFAULT_RK4_PER_STEP = {"chain8": 200, "chain16": 200, "chain32": 200}
+BASELINE_CONFIG = {"doublePendulum": ("configs[1]", 1 << 20), "twoBody": ("configs[2]", 1 << 20), "spring": ("configs[2]", 1 << 20),
+                   "threeBodyPolar": ("configs[3]", 1 << 18), "chain8": ("configs[4]", 1 << 16), "chain16": ("configs[4]", 1 << 16),
+                   "chain32": ("configs[4]", 1 << 16)}
 
 
 def parse():
@@ -49,8 +63,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--system", default="doublePendulum")
-    ap.add_argument("--batch", type=int, default=1 << 20, help="trajectories per GPU")
-    ap.add_argument("--rk4-per-step", type=int, default=100, help="RK4 steps fused into one launch")
+    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default: the BASELINE.json size of --system)")
+    ap.add_argument("--rk4-per-step", type=int, default=None,
+                    help="RK4 steps fused into one launch (default: SURVEY 8d's nsteps of the config: 1000, chains 200)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default, the driver's contract): every rank owns --batch trajectories; "
                          "strong: --batch is the whole ensemble, sharded contiguously over the ranks")
@@ -59,24 +74,37 @@ def parse():
                     help="rk4: the BASELINE metric (hamk_rk4_steps).  stepham: the reference's own stepper "
                          "(adaptive RKF45, Hamilton.hs:390-402), one stepHam(dt) per launch -- secondary figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the baseline leg")
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the all-cores baseline leg")
+    ap.add_argument("--no-isa", action="store_true", help="skip the instruction count of the stepping loop (roofline.fp64)")
+    a = ap.parse_args()
+    if a.batch is None:
+        a.batch = BASELINE_CONFIG.get(a.system, (None, 1 << 20))[1]
+    if a.rk4_per_step is None:
+        a.rk4_per_step = DEFAULT_RK4_PER_STEP.get(a.system, 1000)
+    return a
 
 
 def cpu_baseline_leg(spec, s, dt, target_seconds):
     """Oracle (C restatement of the reference algorithm) on this box's host cores, on a bounded
-    sample of the same workload; also yields the metric's `max |dphase| vs CPU ref`."""
+    sample of the same workload -- all cores (`value`) and one thread (`single_thread`), SURVEY.md
+    section 8d; also yields the metric's `max |dphase| vs CPU ref`."""
     from oracle import oracle
     o = oracle.OracleSystem(spec)
     cores = oracle.max_threads()
     nsteps = 100
-    probe_B = 256 * cores
+    probe_B = 8
     q, qd = examples.sample_config(spec, 0, probe_B)
     p = o.to_phase_batch(q, qd)
     t0 = time.perf_counter()
-    o.rk4_steps_batch(q, p, dt, 10)
-    rate = probe_B * 10 / (time.perf_counter() - t0)
-    S = int(min(1 << 20, max(1024, rate * target_seconds / nsteps)))
+    o.rk4_steps_batch(q, p, dt, 5, threads=1)
+    rate1 = probe_B * 5 / (time.perf_counter() - t0)            # trajectory-steps/s of one thread
+    S1 = int(min(1 << 16, max(8, rate1 * min(6.0, target_seconds / 2) / nsteps)))
+    q, qd = examples.sample_config(spec, 0, S1)
+    p = o.to_phase_batch(q, qd)
+    t0 = time.perf_counter()
+    o.rk4_steps_batch(q, p, dt, nsteps, threads=1)
+    el1 = time.perf_counter() - t0
+    S = int(min(1 << 20, max(256, rate1 * cores * 0.6 * target_seconds / nsteps)))
     S -= S % 256
     q, qd = examples.sample_config(spec, 0, S)
     p = o.to_phase_batch(q, qd)
@@ -87,15 +115,21 @@ def cpu_baseline_leg(spec, s, dt, target_seconds):
     tq, tp = torch.from_numpy(q).cuda(), torch.from_numpy(p).cuda()
     one = api.rk4Steps(dt, 1, s, api.Phase(tq, tp))
     o1q, o1p = o.rk4_steps_batch(q, p, dt, 1)
-    ph = api.rk4Steps(dt, nsteps, s, api.Phase(tq, tp))
+    ph = api.rk4Steps(dt, nsteps, s, api.Phase(tq, tp), drift_tol=1e-6)
+    calm = (s.last_status == 0).cpu().numpy()                     # fixed steps through a close encounter amplify roundoff without bound
     torch.cuda.synchronize()
     d1 = max(np.max(np.abs(one.positions.cpu().numpy() - o1q)), np.max(np.abs(one.momenta.cpu().numpy() - o1p)))
-    dN = max(np.max(np.abs(ph.positions.cpu().numpy() - oq)), np.max(np.abs(ph.momenta.cpu().numpy() - op)))
+    dq_, dp_ = np.abs(ph.positions.cpu().numpy() - oq), np.abs(ph.momenta.cpu().numpy() - op)
+    dN = max(np.max(dq_[:, calm]), np.max(dp_[:, calm])) if calm.any() else float("nan")
     base = {"value": S * nsteps / el, "unit": "trajectory-steps/s", "cores": cores, "kind": "port",
             "sample": f"{S} trajectories x {nsteps} RK4 steps of the same seeded ensemble, "
-                      f"oracle/libhamk_oracle.so (OpenMP, {cores} threads), {el:.1f} s"}
+                      f"oracle/libhamk_oracle.so (OpenMP, {cores} threads), {el:.1f} s",
+            "single_thread": {"value": S1 * nsteps / el1, "cores": 1,
+                              "sample": f"{S1} trajectories x {nsteps} RK4 steps, one thread, {el1:.1f} s"}}
     parity = {"max_abs_dphase_1_step": float(d1), f"max_abs_dphase_{nsteps}_steps": float(dN),
-              "trajectories": S, "reference": "oracle (CPU restatement; reference Haskell toolchain absent)"}
+              "trajectories": S, f"trajectories_compared_at_{nsteps}_steps": int(calm.sum()),
+              "excluded": "lanes the launch flagged (HAMK_ST_DRIFT at 1e-6: close encounters, where any fixed-step result is meaningless)",
+              "reference": "oracle (CPU restatement; reference Haskell toolchain absent)"}
     return base, parity
 
 
@@ -164,14 +198,20 @@ def main():
 
     if a.integrator == "stepham":
         return stepham_bench(a, s, spec, dt, state, dist, dev, rank, world)
+    # every launch checks its own energy invariant (two extra hamiltonian evaluations per LAUNCH of
+    # rk4-per-step steps: HAMK_ST_DRIFT, SURVEY 8d C4 "flag close encounters via status"); the status
+    # words of the timed launches are OR-ed on the device (one 4 B/trajectory elementwise op per launch)
+    DRIFT_TOL = 1e-3
+    status_or = torch.zeros(B, dtype=torch.int32, device=dev)
     for _ in range(a.warmup):
-        api.rk4Steps(dt, a.rk4_per_step, s, state, inplace=True)
+        api.rk4Steps(dt, a.rk4_per_step, s, state, inplace=True, drift_tol=DRIFT_TOL)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()                                          # kernels launch on torch's current stream
     for _ in range(a.steps):
-        api.rk4Steps(dt, a.rk4_per_step, s, state, inplace=True)
+        api.rk4Steps(dt, a.rk4_per_step, s, state, inplace=True, drift_tol=DRIFT_TOL)
+        status_or |= s.last_status
     ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -182,7 +222,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_s = float(t[0]), float(t[1])
 
-    bad = int(torch.count_nonzero(s.last_status))
+    bad = int(torch.count_nonzero(status_or))
+    bad_drift = int(torch.count_nonzero(status_or & 16))
     h1 = api.hamiltonian(s, state)
     rel = (h1 - h0).abs() / h0.abs().clamp(min=1.0)
     drift = float(rel.max())
@@ -198,9 +239,9 @@ def main():
         assert gq.shape == (n, world * B)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        t = torch.tensor([bad, drift_flagged], dtype=torch.int64, device=dev)
+        t = torch.tensor([bad, drift_flagged, bad_drift], dtype=torch.int64, device=dev)
         dist.all_reduce(t)
-        bad, drift_flagged = int(t[0]), int(t[1])
+        bad, drift_flagged, bad_drift = int(t[0]), int(t[1]), int(t[2])
         t = torch.tensor([drift], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         drift = float(t[0])
@@ -212,31 +253,67 @@ def main():
         per_gpu_rate = B * a.rk4_per_step / kernel_s
         alg_bytes = 32.0 * n                             # read + write one Phase n per step
         achieved = per_gpu_rate * alg_bytes / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc) and a.system == "doublePendulum" and B == (1 << 20) and a.rk4_per_step == 100:
+        moved = alg_bytes * B + 4 * B                    # what one launch really reads and writes: state in/out + status
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{a.system}.json")
+        if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                if rec.get("trajectories") == B and rec.get("rk4_steps_per_launch") == a.rk4_per_step:
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = f"STATIC: profiles/pmc_traffic_{a.system}.json ({rec.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE')}), not measured by this run"
             except Exception:
                 traffic = None
+        wave = "HAMK_INSTANTIATE_WAVE" in s.source
+        lanes_per_traj = (16 if n <= 16 else 32) if wave else 1
+        for ln in s.source.splitlines():                 # sub-wave groups (hamk_wave.hpp Geo<N>::NP) when forced / chosen
+            if ln.strip().startswith("#define HAMK_WAVE_NP "):
+                lanes_per_traj = int(ln.split()[2])
+        fp64 = {"per_gpu_steps_per_s": per_gpu_rate, "peak_tflops": FP64_PEAK_TFLOPS, "lanes_per_trajectory": lanes_per_traj}
+        if not a.no_isa:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                import isa_stats
+                isa = isa_stats.rk4_step_stats(spec, s)
+            except Exception as e:                       # a missing llvm-objdump must not cost the bench line
+                isa = None
+                fp64["isa_error"] = repr(e)
+            if isa:
+                flops_step = isa["fp64_flops_per_lane_step"] * lanes_per_traj          # per trajectory-step
+                wave_steps_per_s = per_gpu_rate * lanes_per_traj / 64.0
+                fp64.update({
+                    "flops_per_step": flops_step, "achieved_tflops": per_gpu_rate * flops_step / 1e12,
+                    "frac_of_peak": per_gpu_rate * flops_step / 1e12 / FP64_PEAK_TFLOPS,
+                    "valu_insts_per_wave_step": isa["valu_per_wave_step"], "valu_f64_insts_per_wave_step": isa["valu_f64_per_wave_step"],
+                    "mfma_insts_per_wave_step": isa["mfma_per_wave_step"], "lds_insts_per_wave_step": isa["lds_per_wave_step"],
+                    "scratch_insts_per_wave_step": isa["scratch_per_wave_step"],
+                    "valu_issue_frac": wave_steps_per_s * isa["valu_per_wave_step"] * 4.0 / (N_SIMD * NOMINAL_HZ),
+                    "valu_issue_frac_note": "VALU wave-instructions/s x 4 cycles / (1024 SIMDs x 2.4 GHz nominal); the chip sustains ~1.96 GHz under fp64 load (profiles/r01_summary.json)",
+                    "count_source": isa["source"], "loop": isa["loop_is"]})
+        cfg_id, cfg_B = BASELINE_CONFIG.get(a.system, (None, None))
         out = {
             "metric": "RK4 phase-space steps/sec (ensemble)", "value": value, "unit": "trajectory-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (per-index splitmix64 initial conditions, seed 20241008)",
             "config": {"workload": f"{a.system} (System {spec.m} {spec.n}) ensemble"
-                                   + (", BASELINE.json configs[1]" if a.system == "doublePendulum" and a.batch == (1 << 20) else ""),
+                                   + (f", BASELINE.json {cfg_id}" if cfg_id and a.batch == cfg_B else ""),
                        "trajectories_per_gpu": B, "rk4_steps_per_launch": a.rk4_per_step, "dt": dt,
+                       "kernel_path": "wave-cooperative" if wave else "one trajectory per lane",
                        "parallelism": f"ensemble-shard x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "hamk_rk4_steps_k", "kernel_ms": kernel_s * 1e3,
                          "algorithmic_bytes_per_trajectory_step": alg_bytes,
                          "algorithmic_bytes_per_launch": alg_bytes * B * a.rk4_per_step,
-                         "state_bytes_moved_per_launch": alg_bytes * B + 4 * B,
-                         "note": "charged 32n B per RK4 step (SURVEY 8d); fp64-VALU bound, see fp64"},
-            "fp64": {"per_gpu_steps_per_s": per_gpu_rate, "peak_tflops": FP64_PEAK_TFLOPS},
-            "status_flagged": bad, "max_rel_energy_drift": drift, "energy_drift_over_1e-3": drift_flagged,
+                         "physically_binding": "fp64-valu",
+                         "note": "achieved/frac are the north-star yardstick of SURVEY 8d: 32n B CHARGED per fused RK4 step -- notional, "
+                                 "not bandwidth; real HBM traffic is hbm_physical; the binding roofline is fp64",
+                         "hbm_physical": {"bytes_moved_per_launch": moved, "GBps": moved / kernel_s / 1e9,
+                                          "frac_of_peak": moved / kernel_s / 1e9 / HBM_PEAK_GBS},
+                         "fp64": fp64},
+            "status_flagged": bad, "status_flagged_drift": bad_drift, "drift_tol_per_launch": DRIFT_TOL,
+            "max_rel_energy_drift": drift, "energy_drift_over_1e-3": drift_flagged,
         }
         if gather_ms is not None:
             out["gather_ms"] = gather_ms

@@ -87,6 +87,114 @@ def hottest_loop(ins):
     return best
 
 
+FP64_FLOPS = {"v_fma_f64": 2, "v_fmac_f64": 2, "v_mul_f64": 1, "v_add_f64": 1, "v_rcp_f64": 1, "v_rsq_f64": 1, "v_sqrt_f64": 1,
+              "v_div_fmas_f64": 2, "v_div_fixup_f64": 1, "v_div_scale_f64": 1, "v_ldexp_f64": 1, "v_max_f64": 1, "v_min_f64": 1,
+              "v_fract_f64": 1, "v_rndne_f64": 1, "v_floor_f64": 1, "v_ceil_f64": 1, "v_trunc_f64": 1, "v_trig_preop_f64": 1}
+MFMA_F64_FLOPS_PER_LANE = {"v_mfma_f64_16x16x4_f64": 16 * 16 * 4 * 2 // 64, "v_mfma_f64_4x4x4_4b_f64": 4 * 4 * 4 * 4 * 2 // 64}
+
+
+def guarded_mask(ins, span):
+    """Instructions of ins[span] that sit behind a forward conditional branch inside the span (the body
+    of an `if`: rare library / fallback paths, or wave-uniform stage selection): True = guarded."""
+    lo, hi = span
+    addr_index = {a: i for i, (a, _, _) in enumerate(ins)}
+    mask = [False] * (hi - lo + 1)
+    for i in range(lo, hi + 1):
+        a, mn, ops = ins[i]
+        if not mn.startswith("s_cbranch"):
+            continue
+        m2 = re.search(r"\+0x([0-9a-f]+)>", ops)
+        if not m2:
+            continue
+        tgt = ins[0][0] + int(m2.group(1), 16)
+        if tgt in addr_index and i < addr_index[tgt] <= hi + 1:
+            for k in range(i + 1, addr_index[tgt]):
+                mask[k - lo] = True
+    return mask
+
+
+def loop_stats(ins, span=None):
+    """Histogram of one span (default: the hottest loop) with the fp64 flop count of its straight-line
+    (unguarded) part: 2 per FMA, 1 per mul/add/rcp/..., 32 per lane per v_mfma_f64_16x16x4."""
+    span = span or hottest_loop(ins)
+    if span is None:
+        return None
+    mask = guarded_mask(ins, span)
+    h_all, h_main = collections.Counter(), collections.Counter()
+    flops_main = flops_all = 0
+    for k, (_, mn, _) in enumerate(ins[span[0]:span[1] + 1]):
+        base = mn[:-4] if mn.endswith(("_e32", "_e64")) else mn
+        base = base[:-5] if base.endswith(("_dpp", "_sdwa")) and False else base
+        f = FP64_FLOPS.get(base, 0) + MFMA_F64_FLOPS_PER_LANE.get(base, 0)
+        c = classify(mn)
+        h_all[c] += 1
+        flops_all += f
+        if not mask[k]:
+            h_main[c] += 1
+            flops_main += f
+    valu = lambda h: sum(v for c, v in h.items() if c.startswith("valu"))
+    return {"instructions": sum(h_all.values()), "valu": valu(h_all), "valu_f64": h_all["valu_f64"], "fp64_flops": flops_all,
+            "unguarded": {"instructions": sum(h_main.values()), "valu": valu(h_main), "valu_f64": h_main["valu_f64"],
+                          "fp64_flops": flops_main, "lds": h_main["lds"], "salu": h_main["salu"], "scratch": h_main["scratch"],
+                          "mfma": sum(1 for k, (_, mn, _) in enumerate(ins[span[0]:span[1] + 1]) if not mask[k] and mn.startswith("v_mfma"))},
+            "histogram": dict(h_all)}
+
+
+def disassemble(code_object: bytes):
+    """{kernel name: [(address, mnemonic, operands), ...]} of a gfx950 ELF."""
+    with tempfile.NamedTemporaryFile(suffix=".hsaco") as fh:
+        fh.write(code_object)
+        fh.flush()
+        dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", fh.name], capture_output=True, text=True).stdout
+    return parse(dis)
+
+
+def rk4_step_stats(spec, system=None):
+    """Static cost of ONE RK4 step of one wavefront for the system `spec` (hamilton_amd.examples.SystemSpec).
+    The stepping loop of the kernel that runs also holds the bodies of its rare branches (library
+    sin/cos for |x| >= 1.6e6 or NaN, far-from-anchor re-evaluation, ...: ~2000 instructions a lane
+    of a healthy ensemble never executes), so the count is taken from the SAME source built with
+    -DHAMK_PROBE_NO_SLOWPATH -- same AD mode, same stepping body as `system` (the module in use) --
+    whose hottest loop is one step (unrolled body) or one stage (stage-loop / wave bodies: x 4).
+    Cross-check: PMC SQ_INSTS_VALU per wave per step, profiles/r01_summary.json (434 executed vs 414
+    counted this way for config 2: the difference is the guards around the rare branches).
+    Returns None when llvm-objdump is unavailable."""
+    if not os.path.exists(OBJDUMP):
+        return None
+    from hamilton_amd import api
+    if system is None:
+        system = api.system_from_spec(spec)
+    src = system.source
+    wave = "HAMK_INSTANTIATE_WAVE" in src
+    env = {"HAMK_HIPRTC_FLAGS": (os.environ.get("HAMK_HIPRTC_FLAGS", "") + " -DHAMK_PROBE_NO_SLOWPATH").strip(),
+           "HAMK_RK4_LOOP": "1" if "RK4_STAGE_LOOP = true" in src else "0", "HAMK_WAVE": "1" if wave else "0",
+           "HAMK_AD_MODE": "H" if "MODE_H = true" in src else ("R" if "MODE_R = true" in src else "D")}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        probe = api.system_from_spec(spec)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    info = {l.split()[0]: l.split()[1] for l in probe.build_info.splitlines() if l}
+    co = probe.code_object(1 if "no-machine-licm" in info.get("hamk_rk4_steps_k", "") else 0)
+    ins = disassemble(co).get("hamk_rk4_steps_k") if co else None
+    st = loop_stats(ins) if ins else None
+    if st is None:
+        return None
+    per_step = 4 if ("RK4_STAGE_LOOP = true" in src or wave) else 1
+    return {"loop_is": "one RK4 step" if per_step == 1 else "one stage (x4 per step)",
+            "valu_per_wave_step": st["valu"] * per_step, "valu_f64_per_wave_step": st["valu_f64"] * per_step,
+            "fp64_flops_per_lane_step": st["fp64_flops"] * per_step,
+            "mfma_per_wave_step": sum(1 for _, mn, _ in ins[hottest_loop(ins)[0]:hottest_loop(ins)[1] + 1] if mn.startswith("v_mfma")) * per_step,
+            "lds_per_wave_step": st["histogram"].get("lds", 0) * per_step,
+            "scratch_per_wave_step": st["histogram"].get("scratch", 0) * per_step,
+            "source": "llvm-objdump of this system's module built with -DHAMK_PROBE_NO_SLOWPATH (rare library/fallback branch bodies removed), stepping loop of hamk_rk4_steps_k"}
+
+
 def main():
     from hamilton_amd import api, examples
     name = sys.argv[1] if len(sys.argv) > 1 else "doublePendulum"

@@ -1,16 +1,27 @@
-"""Turn gpurun_out/prof_<tag>/ (scripts/profile.sh) into the committed summaries under profiles/."""
+"""Turn gpurun_out/prof_<tag>_<system>/ (scripts/profile.sh) into the committed summaries under profiles/:
+<tag>_<system>_kernel_stats.csv, <tag>_<system>_summary.json and pmc_traffic_<system>.json (the file
+bench.py quotes, labelled static, as roofline.traffic when trajectories and steps per launch match)."""
 import collections, csv, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+system = sys.argv[2] if len(sys.argv) > 2 else "doublePendulum"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+src = os.path.join(root, "gpurun_out", f"prof_{tag}_{system}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 KERNEL = "hamk_rk4_steps_k"
 
-shutil.copy(os.path.join(src, "stats", f"{tag}_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "stats", f"{tag}_kernel_stats.csv"), os.path.join(dst, f"{tag}_{system}_kernel_stats.csv"))
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "stats", f"{tag}_kernel_stats.csv")))}
-summary = {"kernel": KERNEL, "rocprofv3_kernel_stats": {k: stats[KERNEL][k] for k in ("Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")}}
+summary = {"system": system, "kernel": KERNEL,
+           "rocprofv3_kernel_stats": {k: stats[KERNEL][k] for k in ("Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")}}
+bench = None
+bj = os.path.join(src, "bench_under_profiler.json")
+if os.path.exists(bj) and os.path.getsize(bj):
+    bench = json.loads(open(bj).read())
+    summary["bench_line_under_profiler"] = bench
+    summary["hip_event_kernel_ms_same_run"] = bench["roofline"]["kernel_ms"]
+    summary["rocprof_vs_hip_events"] = float(stats[KERNEL]["AverageNs"]) * 1e-6 / bench["roofline"]["kernel_ms"]
 
 pmc = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
@@ -28,23 +39,24 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
     if meta:
         summary["dispatch"] = {k: meta[k] for k in ("Grid_Size", "Workgroup_Size", "VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size")}
 summary["pmc_mean_per_launch"] = pmc
-if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+B = bench["config"]["trajectories_per_gpu"] if bench else None
+K = bench["config"]["rk4_steps_per_launch"] if bench else None
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and bench:
     # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE counts 128-B requests at 64 B
-    # (MI355X_MICROARCH.md "HBM"): doubled.  Calibration in our own access pattern: this kernel
-    # reads exactly 4*8*B bytes and writes 4*8*B + 4*B bytes per launch (B = 2^20).
+    # (MI355X_MICROARCH.md "HBM"): doubled.  The kernel reads 16 n B and writes 16 n B + 4 B (status)
+    # per trajectory per launch.
+    n = int(bench["roofline"]["algorithmic_bytes_per_trajectory_step"] / 32)
     fetch = pmc["FETCH_SIZE"] * 1024 * 2
     write = pmc["WRITE_SIZE"] * 1024
-    B = 1 << 20
     summary["hbm"] = {"fetch_bytes_corrected_x2": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
-                      "expected_read_bytes": 32 * B, "expected_write_bytes": 32 * B + 4 * B,
-                      "algorithmic_state_bytes_per_launch": 64 * B}
-    json.dump({"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
-               "source": f"profiles/{tag}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"},
-              open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc:
-    summary["valu_insts_per_wave_per_rk4_step"] = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"] / 100.0
-bj = os.path.join(src, "bench_under_profiler.json")
-if os.path.exists(bj) and os.path.getsize(bj):
-    summary["bench_line_under_profiler"] = json.loads(open(bj).read())
-json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
+                      "expected_read_bytes": 16 * n * B, "expected_write_bytes": 16 * n * B + 4 * B}
+    json.dump({"system": system, "trajectories": B, "rk4_steps_per_launch": K,
+               "hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
+               "source": f"profiles/{tag}_{system}_summary.json: rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) / WRITE_SIZE, separate passes"},
+              open(os.path.join(dst, f"pmc_traffic_{system}.json"), "w"), indent=1)
+if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc and K:
+    summary["valu_insts_per_wave_per_rk4_step"] = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"] / K
+    if "SQ_ACTIVE_INST_VALU" in pmc and "SQ_BUSY_CYCLES" in pmc:
+        summary["valu_busy_frac"] = pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_BUSY_CYCLES"]
+json.dump(summary, open(os.path.join(dst, f"{tag}_{system}_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -133,7 +133,9 @@ def test_stepham_vs_oracle(api, systems, name):
     oq, op, ons = o.step_ham_batch(q, p, dt)
     nsub = np.asarray(s.last_nsub)
     same = nsub == ons                                  # identical accept/reject sequence
-    assert same.mean() > 0.95, (name, same.mean())      # a controller threshold can flip on a roundoff tie
+    # measured on MI355X: 100 % (profiles/r01_parity_report.jsonl); a controller threshold can flip on a roundoff tie
+    assert same.mean() >= 0.99, (name, same.mean())
+    assert np.abs(np.bincount(nsub, minlength=64) - np.bincount(ons, minlength=64)).sum() <= 2 * int((~same).sum())
     assert relerr(ph.positions[:, same], oq[:, same]) < 1e-10
     assert relerr(ph.momenta[:, same], op[:, same]) < 1e-10
     # lanes whose step sequence differs still agree to the integrator's tolerance
@@ -314,7 +316,7 @@ def test_small_host_calls_see_fresh_inputs(api, systems):
         q, p, oq, op, ons, rq, rp = ins[(it * 7 + it // 3) % 4]
         st = api.stepHam(0.02, s, api.Phase(q, p))
         same = np.asarray(s.last_nsub) == ons
-        assert same.mean() > 0.95, (it, float(same.mean()))
+        assert same.mean() >= 0.99, (it, float(same.mean()))
         assert relerr(st.positions[:, same], oq[:, same]) < 1e-9 and relerr(st.momenta[:, same], op[:, same]) < 1e-9, it
         r4 = api.rk4Steps(0.01, 3, s, api.Phase(q, p))
         assert relerr(r4.positions, rq) < 1e-11 and relerr(r4.momenta, rp) < 1e-11, it
@@ -475,27 +477,35 @@ def test_all_codegen_variants_agree(api, oracle_lib, name, monkeypatch):
             assert relerr(ph.positions, oq) < 1e-11 and relerr(ph.momenta, op) < 1e-11, (name, mode, loop)
             st = api.stepHam(0.01, s, api.Phase(q, p))
             same = np.asarray(s.last_nsub) == sns          # identical accept/reject sequence as the oracle
-            assert same.mean() > 0.9, (name, mode, loop, same.mean())
+            assert same.mean() >= 0.99, (name, mode, loop, same.mean())
             assert relerr(st.positions[:, same], sq[:, same]) < 1e-10, (name, mode, loop)
             assert relerr(st.momenta[:, same], sp[:, same]) < 1e-10, (name, mode, loop)
 
 
 def test_evolveham_time_grid_edge_cases(api, systems):
-    """hmatrix-gsl's loop is `for each ti: while (t < ti) step` (SURVEY.md section 8c box): a repeated or
-    decreasing time does no stepping and returns the current state; a negative step does nothing."""
+    """Old gsl_odeiv binding (hamk_system_set_gsl_api(1)): hmatrix-gsl's loop is `for each ti: while
+    (t < ti) step` (SURVEY.md section 8c box): a repeated or decreasing time does no stepping and
+    returns the current state; a negative step does nothing.  (The default gsl_odeiv2 binding's
+    rules are in tests/test_gpu_configs.py::test_odeiv2_direction_rules.)"""
     spec, s, o = systems["doublePendulum"]
     q, qd = E.sample_config(spec, 3, 9)
     p = o.to_phase_batch(q, qd)
     ts = np.array([0.0, 0.1, 0.1, 0.05, 0.2])
-    rows = api.evolveHam(s, api.Phase(q, p), ts)
-    oq, op, _ = o.evolve_ham_batch(q, p, ts)
-    np.testing.assert_array_equal(rows[2].positions, rows[1].positions)
-    np.testing.assert_array_equal(rows[3].positions, rows[1].positions)
-    for r in range(1, 5):
-        assert relerr(rows[r].positions, oq[r]) < 1e-9 and relerr(rows[r].momenta, op[r]) < 1e-9
-    back = api.stepHam(-0.01, s, api.Phase(q, p))                 # t = 0 >= ti = -0.01: no steps
-    np.testing.assert_array_equal(back.positions, q)
-    np.testing.assert_array_equal(back.momenta, p)
+    s.gsl_api = 1
+    o.gsl_api = 1
+    try:
+        rows = api.evolveHam(s, api.Phase(q, p), ts)
+        oq, op, _ = o.evolve_ham_batch(q, p, ts)
+        np.testing.assert_array_equal(rows[2].positions, rows[1].positions)
+        np.testing.assert_array_equal(rows[3].positions, rows[1].positions)
+        for r in range(1, 5):
+            assert relerr(rows[r].positions, oq[r]) < 1e-9 and relerr(rows[r].momenta, op[r]) < 1e-9
+        back = api.stepHam(-0.01, s, api.Phase(q, p))                 # t = 0 >= ti = -0.01: no steps
+        np.testing.assert_array_equal(back.positions, q)
+        np.testing.assert_array_equal(back.momenta, p)
+    finally:
+        s.gsl_api = 2
+        o.gsl_api = 2
 
 
 def test_single_trajectory_frame_loop(api, systems):

@@ -94,7 +94,7 @@ def test_wave_adaptive_stepper_vs_oracle(api, oracle_lib, monkeypatch, name, for
     st = api.stepHam(dt, s, api.Phase(q, p))
     sq, sp, sns = o.step_ham_batch(q, p, dt)
     same = np.asarray(s.last_nsub) == sns
-    assert same.mean() > 0.9, (name, same.mean(), np.asarray(s.last_nsub)[:8], sns[:8])
+    assert same.mean() >= 0.97, (name, same.mean(), np.asarray(s.last_nsub)[:8], sns[:8])      # B = 37: one flipped lane allowed
     assert relerr(st.positions[:, same], sq[:, same]) < 1e-9 and relerr(st.momenta[:, same], sp[:, same]) < 1e-9
     assert not np.any(s.last_status)
     ts = np.array([0.0, dt, 2.5 * dt])
