@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the all-cores baseline leg")
     ap.add_argument("--no-isa", action="store_true", help="skip the instruction count of the stepping loop (roofline.fp64)")
+    ap.add_argument("--drift-tol", type=float, default=1e-3,
+                    help="per-launch energy check of the timed launches (HAMK_ST_DRIFT); 0 = plain hamk_rk4_steps")
     a = ap.parse_args()
     if a.batch is None:
         a.batch = BASELINE_CONFIG.get(a.system, (None, 1 << 20))[1]
@@ -104,7 +106,13 @@ def cpu_baseline_leg(spec, s, dt, target_seconds):
     t0 = time.perf_counter()
     o.rk4_steps_batch(q, p, dt, nsteps, threads=1)
     el1 = time.perf_counter() - t0
-    S = int(min(1 << 20, max(256, rate1 * cores * 0.6 * target_seconds / nsteps)))
+    probe_S = 16 * cores                                          # all cores: measure the rate, do not assume the scaling
+    q, qd = examples.sample_config(spec, 0, probe_S)
+    p = o.to_phase_batch(q, qd)
+    t0 = time.perf_counter()
+    o.rk4_steps_batch(q, p, dt, 5)
+    rate_all = probe_S * 5 / (time.perf_counter() - t0)
+    S = int(min(1 << 20, max(256, rate_all * target_seconds / nsteps)))
     S -= S % 256
     q, qd = examples.sample_config(spec, 0, S)
     p = o.to_phase_batch(q, qd)
@@ -119,16 +127,18 @@ def cpu_baseline_leg(spec, s, dt, target_seconds):
     calm = (s.last_status == 0).cpu().numpy()                     # fixed steps through a close encounter amplify roundoff without bound
     torch.cuda.synchronize()
     d1 = max(np.max(np.abs(one.positions.cpu().numpy() - o1q)), np.max(np.abs(one.momenta.cpu().numpy() - o1p)))
-    dq_, dp_ = np.abs(ph.positions.cpu().numpy() - oq), np.abs(ph.momenta.cpu().numpy() - op)
-    dN = max(np.max(dq_[:, calm]), np.max(dp_[:, calm])) if calm.any() else float("nan")
+    dall = np.maximum(np.abs(ph.positions.cpu().numpy() - oq).max(0), np.abs(ph.momenta.cpu().numpy() - op).max(0))
+    dN = float(np.max(dall[calm])) if calm.any() else None
     base = {"value": S * nsteps / el, "unit": "trajectory-steps/s", "cores": cores, "kind": "port",
             "sample": f"{S} trajectories x {nsteps} RK4 steps of the same seeded ensemble, "
                       f"oracle/libhamk_oracle.so (OpenMP, {cores} threads), {el:.1f} s",
             "single_thread": {"value": S1 * nsteps / el1, "cores": 1,
                               "sample": f"{S1} trajectories x {nsteps} RK4 steps, one thread, {el1:.1f} s"}}
-    parity = {"max_abs_dphase_1_step": float(d1), f"max_abs_dphase_{nsteps}_steps": float(dN),
-              "trajectories": S, f"trajectories_compared_at_{nsteps}_steps": int(calm.sum()),
-              "excluded": "lanes the launch flagged (HAMK_ST_DRIFT at 1e-6: close encounters, where any fixed-step result is meaningless)",
+    parity = {"max_abs_dphase_1_step": float(d1), f"max_abs_dphase_{nsteps}_steps": dN,
+              f"median_abs_dphase_{nsteps}_steps_all_lanes": float(np.median(dall)),
+              "trajectories": S, f"trajectories_in_max_at_{nsteps}_steps": int(calm.sum()),
+              "excluded_from_max": "lanes the launch flagged (HAMK_ST_DRIFT at 1e-6 over these 100 steps: close encounters / under-resolved "
+                                   "fast members, where roundoff is amplified without bound and any fixed-step result is meaningless)",
               "reference": "oracle (CPU restatement; reference Haskell toolchain absent)"}
     return base, parity
 
@@ -201,7 +211,7 @@ def main():
     # every launch checks its own energy invariant (two extra hamiltonian evaluations per LAUNCH of
     # rk4-per-step steps: HAMK_ST_DRIFT, SURVEY 8d C4 "flag close encounters via status"); the status
     # words of the timed launches are OR-ed on the device (one 4 B/trajectory elementwise op per launch)
-    DRIFT_TOL = 1e-3
+    DRIFT_TOL = a.drift_tol
     status_or = torch.zeros(B, dtype=torch.int32, device=dev)
     for _ in range(a.warmup):
         api.rk4Steps(dt, a.rk4_per_step, s, state, inplace=True, drift_tol=DRIFT_TOL)

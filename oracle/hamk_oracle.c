@@ -630,14 +630,14 @@ void orc_step_ham(const orc_system* s, double r, double* q, double* p, long* cou
 /* ------------------------------------------------------------------------ */
 static void set_threads(int threads) {
 #ifdef _OPENMP
-  if (threads > 0) omp_set_num_threads(threads);
+  omp_set_num_threads(threads > 0 ? threads : omp_get_num_procs());   /* <= 0: all cores, whatever an earlier call set */
 #else
   (void)threads;
 #endif
 }
 int orc_max_threads(void) {
 #ifdef _OPENMP
-  return omp_get_max_threads();
+  return omp_get_num_procs();
 #else
   return 1;
 #endif
