@@ -392,11 +392,30 @@ template <int N> HAMK_DEV Jet2<N> operator/(double c, const Jet2<N>& b) { return
 //                (|delta| < 1/8: 23 fp64 instructions, no range reduction, no integer
 //                quadrant logic, absolute error < 3e-18 + rounding); otherwise as FULL.
 //                Always relative to the anchor of the current step, so nothing accumulates.
-enum : int { TRIG_FULL = 0, TRIG_REUSE = 1, TRIG_ANCHOR = 2, TRIG_INCR = 3 };
+//   TRIG_DYN     decided per evaluation by two WAVE-UNIFORM flags of the cache (scalar branches):
+//                  anchor && full    as TRIG_ANCHOR
+//                  anchor && !full   CHAINED anchor: the first stage of step k+1 sits at y_k+1, one
+//                                    step (|delta| ~ dt |qd|) from the anchor of step k -- rotate that
+//                                    anchor to the new point and make the result the new anchor
+//                  !anchor           as TRIG_INCR
+//                The stepping loops set full on every HAMK_TRIG_CHAIN_K-th step, so a chain is at
+//                most K - 1 rotations long: each adds <= ~1.3e-16 absolute (rounding of the rotation
+//                formula; the Taylor kernels contribute < 3e-18), worst case linear in the chain
+//                length, typically its square root -- below the rounding the state itself collects
+//                over the same steps (tests/test_host_emulation.py::test_chained_sincos_accuracy).
+enum : int { TRIG_FULL = 0, TRIG_REUSE = 1, TRIG_ANCHOR = 2, TRIG_INCR = 3, TRIG_DYN = 4 };
+#ifndef HAMK_TRIG_CHAIN_K
+#define HAMK_TRIG_CHAIN_K 16           // 1: every step re-anchors with a full evaluation (no chaining)
+#endif
 
 template <int NS> struct TrigCache {
   double s[NS > 0 ? NS : 1], c[NS > 0 ? NS : 1];                           // current point
   double ax[NS > 0 ? NS : 1], as[NS > 0 ? NS : 1], ac[NS > 0 ? NS : 1];    // anchor
+  bool anchor = true, full = true;                                         // TRIG_DYN: wave-uniform
+  HAMK_DEV TrigCache() {                                                   // a defined anchor (0, sin 0, cos 0) from the start
+#pragma unroll
+    for (int k = 0; k < (NS > 0 ? NS : 1); ++k) { ax[k] = 0.0; as[k] = 0.0; ac[k] = 1.0; }
+  }
 };
 
 HAMK_DEV void sincos_incr(double x, double xa, double sa, double ca, double& s, double& c) {
@@ -431,6 +450,15 @@ template <int MODE, class TC> HAMK_DEV void trig_pair(double x, TC& tc, int k) {
     tc.ax[k] = x; tc.as[k] = tc.s[k]; tc.ac[k] = tc.c[k];
   } else if constexpr (MODE == TRIG_INCR) {
     sincos_incr(x, tc.ax[k], tc.as[k], tc.ac[k], tc.s[k], tc.c[k]);
+  } else if constexpr (MODE == TRIG_DYN) {
+#ifdef HAMK_PROBE_TRIG      // scripts/isa_stats.py: fix the case at compile time (0 full anchor, 1 chained anchor, 2 rotate only)
+    const bool anchor = (HAMK_PROBE_TRIG) < 2, full = (HAMK_PROBE_TRIG) == 0;
+#else
+    const bool anchor = tc.anchor, full = tc.full;
+#endif
+    if (anchor && full) sincos_f64(x, tc.s[k], tc.c[k]);
+    else sincos_incr(x, tc.ax[k], tc.as[k], tc.ac[k], tc.s[k], tc.c[k]);
+    if (anchor) { tc.ax[k] = x; tc.as[k] = tc.s[k]; tc.ac[k] = tc.c[k]; }
   }
 }
 
@@ -827,6 +855,7 @@ template <class S> struct StageTrig {
 #endif
   static constexpr int anchor = on ? TRIG_ANCHOR : TRIG_FULL;
   static constexpr int incr = on ? TRIG_INCR : TRIG_FULL;
+  static constexpr int dyn = on ? TRIG_DYN : TRIG_FULL;      // the fixed-step loops (chained anchors)
 };
 
 template <class S, int TRIG = TRIG_FULL>
@@ -902,7 +931,9 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
       double yt[D];
 #pragma unroll
       for (int j = 0; j < D; ++j) yt[j] = fma(a, k[j], y[j]);
-      rhs<S>(yt, k, st, tc);
+      tc.anchor = (sg == 0);                                    // stage 1 (re-)anchors, stages 2-4 rotate the anchor
+      tc.full = ((it >> 2) % HAMK_TRIG_CHAIN_K) == 0;
+      rhs<S, StageTrig<S>::dyn>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) acc[j] = fma(b, k[j], acc[j]);
       if (sg == 3) {
@@ -914,9 +945,12 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
       double k[D], yt[D], acc[D];
-      // stage 1 evaluates sincos in full and anchors it; stages 2-4 sit at y + a dt k, a few
-      // hundredths of a radian away, and rotate the anchor pair instead (TRIG_INCR)
-      rhs<S, StageTrig<S>::anchor>(y, k, st, tc);
+      // stage 1 anchors sincos -- by a full evaluation on every HAMK_TRIG_CHAIN_K-th step, otherwise by
+      // rotating the previous step's anchor (TRIG_DYN); stages 2-4 sit at y + a dt k, a few hundredths
+      // of a radian away, and rotate the anchor pair (TRIG_INCR)
+      tc.anchor = true;
+      tc.full = (s % HAMK_TRIG_CHAIN_K) == 0;
+      rhs<S, StageTrig<S>::dyn>(y, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) { acc[j] = fma(h6, k[j], y[j]); yt[j] = fma(h2, k[j], y[j]); }
       rhs<S, StageTrig<S>::incr>(yt, k, st, tc);

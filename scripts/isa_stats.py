@@ -150,14 +150,20 @@ def disassemble(code_object: bytes):
 
 
 def rk4_step_stats(spec, system=None):
-    """Static cost of ONE RK4 step of one wavefront for the system `spec` (hamilton_amd.examples.SystemSpec).
-    The stepping loop of the kernel that runs also holds the bodies of its rare branches (library
-    sin/cos for |x| >= 1.6e6 or NaN, far-from-anchor re-evaluation, ...: ~2000 instructions a lane
-    of a healthy ensemble never executes), so the count is taken from the SAME source built with
-    -DHAMK_PROBE_NO_SLOWPATH -- same AD mode, same stepping body as `system` (the module in use) --
-    whose hottest loop is one step (unrolled body) or one stage (stage-loop / wave bodies: x 4).
-    Cross-check: PMC SQ_INSTS_VALU per wave per step, profiles/r01_summary.json (434 executed vs 414
-    counted this way for config 2: the difference is the guards around the rare branches).
+    """Cost of ONE RK4 step of one wavefront for the system `spec` (hamilton_amd.examples.SystemSpec),
+    counted from code objects of the same source as `system` (the module in use: same AD mode, same
+    stepping body, same sincos chain length K), built with probe defines that make the count a
+    count of what a lane of a healthy ensemble EXECUTES:
+      -DHAMK_PROBE_NO_SLOWPATH  removes the bodies of the rare branches (library sin/cos for
+                                |x| >= 1.6e6 or NaN, far-from-anchor re-evaluation, ...: ~2000
+                                instructions inside the stepping loop that are never executed);
+      -DHAMK_PROBE_TRIG=0|1|2   fixes the wave-uniform sincos case of an evaluation at compile time
+                                (0 full anchor, 1 chained anchor, 2 rotate only), so the two sides
+                                of that scalar branch are not both counted.
+    The hottest loop is one step (unrolled body) or one stage (stage-loop / wave bodies).  Per step:
+      unrolled    A/K + C (1 - 1/K)                A, C: loop with TRIG = 0, 1
+      stage loop  A/K + C (1 - 1/K) + 3 I          A, C, I: loop with TRIG = 0, 1, 2
+    Cross-check: PMC SQ_INSTS_VALU per wave per step (profiles/*_summary.json).
     Returns None when llvm-objdump is unavailable."""
     if not os.path.exists(OBJDUMP):
         return None
@@ -166,33 +172,59 @@ def rk4_step_stats(spec, system=None):
         system = api.system_from_spec(spec)
     src = system.source
     wave = "HAMK_INSTANTIATE_WAVE" in src
-    env = {"HAMK_HIPRTC_FLAGS": (os.environ.get("HAMK_HIPRTC_FLAGS", "") + " -DHAMK_PROBE_NO_SLOWPATH").strip(),
-           "HAMK_RK4_LOOP": "1" if "RK4_STAGE_LOOP = true" in src else "0", "HAMK_WAVE": "1" if wave else "0",
-           "HAMK_AD_MODE": "H" if "MODE_H = true" in src else ("R" if "MODE_R = true" in src else "D")}
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        probe = api.system_from_spec(spec)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    info = {l.split()[0]: l.split()[1] for l in probe.build_info.splitlines() if l}
-    co = probe.code_object(1 if "no-machine-licm" in info.get("hamk_rk4_steps_k", "") else 0)
-    ins = disassemble(co).get("hamk_rk4_steps_k") if co else None
-    st = loop_stats(ins) if ins else None
-    if st is None:
-        return None
-    per_step = 4 if ("RK4_STAGE_LOOP = true" in src or wave) else 1
-    return {"loop_is": "one RK4 step" if per_step == 1 else "one stage (x4 per step)",
-            "valu_per_wave_step": st["valu"] * per_step, "valu_f64_per_wave_step": st["valu_f64"] * per_step,
-            "fp64_flops_per_lane_step": st["fp64_flops"] * per_step,
-            "mfma_per_wave_step": sum(1 for _, mn, _ in ins[hottest_loop(ins)[0]:hottest_loop(ins)[1] + 1] if mn.startswith("v_mfma")) * per_step,
-            "lds_per_wave_step": st["histogram"].get("lds", 0) * per_step,
-            "scratch_per_wave_step": st["histogram"].get("scratch", 0) * per_step,
-            "source": "llvm-objdump of this system's module built with -DHAMK_PROBE_NO_SLOWPATH (rare library/fallback branch bodies removed), stepping loop of hamk_rk4_steps_k"}
+    stage_loop = "RK4_STAGE_LOOP = true" in src or wave
+    m = re.search(r"#define HAMK_TRIG_CHAIN_K (\d+)", src)
+    K = int(m.group(1)) if m else 16
+    m = re.search(r"NTRIG_F = (\d+)", src)
+    chained = (not wave) and m is not None and 1 <= int(m.group(1)) <= 4          # hamk_device.hpp StageTrig
+    base_env = {"HAMK_RK4_LOOP": "1" if "RK4_STAGE_LOOP = true" in src else "0", "HAMK_WAVE": "1" if wave else "0",
+                "HAMK_AD_MODE": "H" if "MODE_H = true" in src else ("R" if "MODE_R = true" in src else "D"),
+                "HAMK_TRIG_CHAIN": str(K)}
+
+    def count(trig):
+        flags = (os.environ.get("HAMK_HIPRTC_FLAGS", "") + " -DHAMK_PROBE_NO_SLOWPATH").strip()
+        if trig is not None:
+            flags += f" -DHAMK_PROBE_TRIG={trig}"
+        env = dict(base_env, HAMK_HIPRTC_FLAGS=flags)
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            probe = api.system_from_spec(spec)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        info = {l.split()[0]: l.split()[1] for l in probe.build_info.splitlines() if l}
+        co = probe.code_object(1 if "no-machine-licm" in info.get("hamk_rk4_steps_k", "") else 0)
+        ins = disassemble(co).get("hamk_rk4_steps_k") if co else None
+        st = loop_stats(ins) if ins else None
+        if st is None:
+            return None
+        lo, hi = hottest_loop(ins)
+        return {"valu": st["valu"], "valu_f64": st["valu_f64"], "flops": st["fp64_flops"],
+                "mfma": sum(1 for _, mn, _ in ins[lo:hi + 1] if mn.startswith("v_mfma")),
+                "lds": st["histogram"].get("lds", 0), "scratch": st["histogram"].get("scratch", 0)}
+
+    if chained:
+        A, C = count(0), count(1)
+        I = count(2) if stage_loop else None
+        if A is None or C is None or (stage_loop and I is None):
+            return None
+        w = {k: A[k] / K + C[k] * (1.0 - 1.0 / K) + (3 * I[k] if stage_loop else 0) for k in A}
+        detail = {"full_anchor": A, "chained_anchor": C, "rotate_only": I, "chain_K": K}
+    else:
+        A = count(None)
+        if A is None:
+            return None
+        w = {k: A[k] * (4 if stage_loop else 1) for k in A}
+        detail = {"loop": A}
+    return {"loop_is": "one stage (x4 per step)" if stage_loop else "one RK4 step",
+            "valu_per_wave_step": w["valu"], "valu_f64_per_wave_step": w["valu_f64"], "fp64_flops_per_lane_step": w["flops"],
+            "mfma_per_wave_step": w["mfma"], "lds_per_wave_step": w["lds"], "scratch_per_wave_step": w["scratch"], "detail": detail,
+            "source": "llvm-objdump of this system's module built with -DHAMK_PROBE_NO_SLOWPATH (rare library/fallback branch bodies "
+                      "removed) and -DHAMK_PROBE_TRIG (wave-uniform sincos case fixed), stepping loop of hamk_rk4_steps_k, weighted per step"}
 
 
 def main():

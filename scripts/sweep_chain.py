@@ -1,0 +1,47 @@
+"""GPU: the fixed-step kernels with chained sincos anchors (hamk_device.hpp TRIG_DYN): RK4 steps/s at
+BASELINE ensemble size for a full re-anchor every K = 1 (no chaining: round-1 behaviour), 4, 16, 64
+steps; and, for chain8, what the throughput depends on (fused steps per launch, the drift check).
+Output: one JSON line per measurement (profiles/r02_sweep_chain.jsonl)."""
+import json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hamilton_amd import api, examples as E
+
+
+def timed(fn, warm, reps):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def run(name, B, nsteps, env, drift_tol=0.0, reps=8):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        spec = E.get(name)
+        s = api.system_from_spec(spec)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    q, qd = E.sample_config(spec, 0, B)
+    ph = api.toPhase(s, api.Config(torch.from_numpy(q).cuda(), torch.from_numpy(qd).cuda()))
+    st = api.Phase(ph.positions.clone(), ph.momenta.clone())
+    sec = timed(lambda: api.rk4Steps(spec.dt, nsteps, s, st, inplace=True, drift_tol=drift_tol), 3, reps)
+    info = {l.split()[0]: " ".join(l.split()[1:]) for l in s.build_info.splitlines() if l}
+    return dict(system=name, B=B, rk4_steps_per_launch=nsteps, env=env, drift_tol=drift_tol, ms=sec * 1e3,
+                steps_per_s=B * nsteps / sec, rk4_kernel=info["hamk_rk4_steps_k"])
+
+
+if __name__ == "__main__":
+    for name, B in (("doublePendulum", 1 << 20), ("twoBody", 1 << 20), ("spring", 1 << 20), ("threeBodyPolar", 1 << 18), ("pendulum", 1 << 20)):
+        for k in ("1", "4", "16", "64"):
+            print(json.dumps(run(name, B, 400, {"HAMK_TRIG_CHAIN": k})), flush=True)
+    for nsteps in (50, 200):
+        for tol in (0.0, 1e-3):
+            print(json.dumps(run("chain8", 1 << 16, nsteps, {}, drift_tol=tol, reps=12)), flush=True)
+    print(json.dumps(run("chain16", 1 << 16, 50, {}, reps=6)), flush=True)

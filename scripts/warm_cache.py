@@ -1,0 +1,69 @@
+"""Pre-compile (hiprtc cross-compiles for gfx950 without a GPU) the code objects the GPU test suite,
+bench.py and the sweep scripts will ask for, into a cache directory that travels with the repository
+snapshot (`.hamk_cache/`, git-ignored): a fresh GPU box then spends its minutes measuring, not
+compiling.  Use on the GPU side with HAMK_CACHE_DIR=$PWD/.hamk_cache.
+  python scripts/warm_cache.py [-j 8]"""
+import multiprocessing as mp
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+CACHE = os.path.join(ROOT, ".hamk_cache")
+
+
+def jobs():
+    out = []
+    base = ["pendulum", "doublePendulum", "room", "twoBody", "spring", "bezier", "threeBodyPolar", "opcodeZoo",
+            "chain4", "chain8", "chain12", "chain16", "chain17", "chain18", "chain20", "chain32"]
+    for n in base:
+        out.append((n, {}, True))
+        out.append((n, {"HAMK_GSL_API": "1"}, False))
+    for n in ("spring", "threeBodyPolar", "chain4", "opcodeZoo", "chain8", "chain16"):
+        out.append((n, {"HAMK_WAVE": "1"}, False))
+    for n in ("chain8", "chain16"):
+        out.append((n, {"HAMK_WAVE": "0"}, False))
+    for n in ("opcodeZoo", "doublePendulum", "spring", "threeBodyPolar"):
+        for mode in "HDR":
+            for loop in (None, "1"):
+                env = {"HAMK_AD_MODE": mode}
+                if loop:
+                    env["HAMK_RK4_LOOP"] = loop
+                out.append((n, env, False))
+    for n in ("doublePendulum", "twoBody", "spring", "threeBodyPolar", "pendulum"):
+        for k in ("1", "4", "64"):
+            out.append((n, {"HAMK_TRIG_CHAIN": k}, True))
+    for seed in range(16):
+        out.append((f"random{seed}", {}, False))
+    return out
+
+
+def build(job):
+    name, env, isa = job
+    os.environ["HAMK_CACHE_DIR"] = CACHE
+    os.environ.update(env)
+    from hamilton_amd import api, examples
+    try:
+        if name.startswith("random"):
+            from test_gpu_random_systems import random_spec
+            spec = random_spec(int(name[6:]))
+        else:
+            spec = examples.get(name)
+        s = api.system_from_spec(spec)
+        if isa:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import isa_stats
+            isa_stats.rk4_step_stats(spec, s)
+        return name, env, s.code_size
+    except Exception as e:          # a job that cannot be built here is simply not cached
+        return name, env, repr(e)[:200]
+
+
+if __name__ == "__main__":
+    j = int(sys.argv[sys.argv.index("-j") + 1]) if "-j" in sys.argv else 8
+    os.makedirs(CACHE, mode=0o700, exist_ok=True)
+    os.chmod(CACHE, 0o700)
+    with mp.Pool(j, maxtasksperchild=1) as pool:
+        for name, env, res in pool.imap_unordered(build, jobs()):
+            print(name, env, res, flush=True)

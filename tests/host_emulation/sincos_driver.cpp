@@ -13,6 +13,20 @@ void emu_sincos_incr(const double* xa, const double* d, double* s, double* c, lo
     hamk::sincos_incr(xa[i] + d[i], xa[i], sa, ca, s[i], c[i]);
   }
 }
+// a chain of `len` rotations through the library's own TRIG_DYN logic: full anchor at x0, then
+// x0 + d, x0 + 2 d, ... each obtained by rotating the previous anchor (which it then replaces);
+// s, c: the pair after the last rotation
+void emu_sincos_chain(const double* x0, const double* d, int len, double* s, double* c, long long n) {
+  for (long long i = 0; i < n; ++i) {
+    hamk::TrigCache<1> tc;
+    tc.anchor = true; tc.full = true;
+    double x = x0[i];
+    hamk::trig_pair<hamk::TRIG_DYN>(x, tc, 0);
+    tc.full = false;
+    for (int k = 0; k < len; ++k) { x += d[i]; hamk::trig_pair<hamk::TRIG_DYN>(x, tc, 0); }
+    s[i] = tc.s[0]; c[i] = tc.c[0];
+  }
+}
 void emu_frcp(const double* x, double* r, long long n) { for (long long i = 0; i < n; ++i) r[i] = hamk::frcp(x[i]); }
 void emu_rpow(const double* x, double* r5, double* r6, long long n) {
   for (long long i = 0; i < n; ++i) { r5[i] = hamk::rpow_inv<5>(x[i]); r6[i] = hamk::rpow_inv<6>(x[i]); }
