@@ -86,7 +86,8 @@ std::string validate_tape(const hamk_op* ops, int nops, int n_in, const int32_t*
 static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const char* pfx,
                      const std::vector<std::vector<int>>* sink_outs = nullptr,
                      const std::vector<std::string>* input_exprs = nullptr, const char* tc_name = "tc",
-                     std::vector<int>* slot_operand = nullptr, const char* trig_mode = "TRIG") {
+                     std::vector<int>* slot_operand = nullptr, const char* trig_mode = "TRIG",
+                     const std::vector<int>* shared_f_slot = nullptr) {
   // pair SIN/COS of a shared operand: one sincos
   std::vector<int> sin_of(nops, -1), cos_of(nops, -1);
   for (int i = 0; i < nops; ++i) {
@@ -100,6 +101,13 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
   auto slot = [&](int operand) {
     if (slot_of[operand] < 0) slot_of[operand] = nslots++;
     return std::string(tc_name) + ", " + std::to_string(slot_of[operand]);
+  };
+  // shared_f_slot (potential over generalized coordinates, evaluated right after f at the same q):
+  // a sincos of INPUT j for which f has a site with the same operand reads f's pair instead of
+  // evaluating it again (spring, Examples.hs:144-162: cos theta in f and in U)
+  auto shared = [&](int operand) {
+    if (!shared_f_slot || ops[operand].op != HAMK_OP_INPUT) return -1;
+    return (*shared_f_slot)[ops[operand].a];
   };
   // INPUT values are not materialised: every use reads `in[j]` in place.  With array inputs
   // that is a reference; with the wave kernels' LDS-backed proxies it keeps 32 input jets from
@@ -128,13 +136,16 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
       case HAMK_OP_SIN:
       case HAMK_OP_COS: {
         const int si = sin_of[p.a], ci = cos_of[p.a];
+        const int fs = shared(p.a);
+        const std::string where = fs >= 0 ? "tcf, " + std::to_string(fs) : slot(p.a);
+        const std::string mode = fs >= 0 ? "hamk::TRIG_REUSE" : trig_mode;
         if (si >= 0 && ci >= 0 && (si == i || ci == i) && !done[si] && !done[ci]) {
           o << "hamk::bare_t<decltype(" << v(p.a) << ")> " << v(si) << ", " << v(ci)
-            << "; hamk::sincos<" << trig_mode << ">(" << v(p.a) << ", " << v(si) << ", " << v(ci) << ", " << slot(p.a) << ");\n";
+            << "; hamk::sincos<" << mode << ">(" << v(p.a) << ", " << v(si) << ", " << v(ci) << ", " << where << ");\n";
           done[si] = done[ci] = 1;
         } else {
-          o << "const auto " << v(i) << " = hamk::" << (p.op == HAMK_OP_SIN ? "sin" : "cos") << "<" << trig_mode << ">(" << v(p.a)
-            << ", " << slot(p.a) << ");\n";
+          o << "const auto " << v(i) << " = hamk::" << (p.op == HAMK_OP_SIN ? "sin" : "cos") << "<" << mode << ">(" << v(p.a)
+            << ", " << where << ");\n";
         }
       } break;
       default: o << "const auto " << v(i) << " = hamk::" << unary_name(p.op) << "(" << v(p.a) << ");\n"; break;
@@ -414,6 +425,30 @@ std::string generate_source(const SystemDesc& d) {
   const int ntrig_u = emit_body(o, d.u_ops.data(), (int)d.u_ops.size(), "u");
   o << "    return hamk::lift<A>(" << value_name(d.u_ops, "u", d.u_out) << ");\n";
   o << "  }\n";
+  // the same potential evaluated right after f at the same generalized coordinates: sincos sites of
+  // inputs that f evaluates too read f's pair (tcf) instead of evaluating it again
+  {
+    std::vector<int> f_slot_of_input(d.n, -1);
+    bool any = false;
+    if (d.u_space == HAMK_U_GENERALIZED) {
+      for (int k = 0; k < ntrig_f; ++k) {
+        const int opi = slot_operand[k];
+        if (opi >= 0 && d.f_ops[opi].op == HAMK_OP_INPUT) f_slot_of_input[d.f_ops[opi].a] = k;
+      }
+      for (const hamk_op& p : d.u_ops)
+        if ((p.op == HAMK_OP_SIN || p.op == HAMK_OP_COS) && d.u_ops[p.a].op == HAMK_OP_INPUT && f_slot_of_input[d.u_ops[p.a].a] >= 0) any = true;
+    }
+    o << "  static constexpr bool U_SHARES_F_TRIG = " << (any ? "true" : "false") << ";\n";
+    o << "  template <class A, int TRIG, class TC, class TCF> __device__ __forceinline__ static A potential_after_f(const A (&in)[" << nu
+      << "], TC& tc, TCF& tcf) {\n";
+    if (any) {
+      emit_body(o, d.u_ops.data(), (int)d.u_ops.size(), "u", nullptr, nullptr, "tc", nullptr, "TRIG", &f_slot_of_input);
+      o << "    return hamk::lift<A>(" << value_name(d.u_ops, "u", d.u_out) << ");\n";
+    } else {
+      o << "    return potential<A, TRIG>(in, tc);\n";
+    }
+    o << "  }\n";
+  }
   // the same map, delivering each output to a sink as soon as it is defined
   o << "  template <class A, int TRIG, class IN, class TC, class Sink> __device__ __forceinline__ static void coords_sink(const IN& in, TC& tc, Sink& sink) {\n";
   std::vector<std::vector<int>> sink_outs(d.f_ops.size());

@@ -389,21 +389,36 @@ template <int N> HAMK_DEV Jet2<N> operator/(double c, const Jet2<N>& b) { return
 //   TRIG_ANCHOR  as FULL, and remember (operand, sin, cos) as this site's anchor
 //   TRIG_INCR    the operand is close to the anchor (an RK stage point y + a h k next to y):
 //                rotate the anchor pair by delta = operand - anchor with short Taylor kernels
-//                (|delta| < 1/8: 23 fp64 instructions, no range reduction, no integer
+//                (|delta| < 1/4: 26 fp64 instructions, no range reduction, no integer
 //                quadrant logic, absolute error < 3e-18 + rounding); otherwise as FULL.
 //                Always relative to the anchor of the current step, so nothing accumulates.
-//   TRIG_DYN     decided per evaluation by two WAVE-UNIFORM flags of the cache (scalar branches):
-//                  anchor && full    as TRIG_ANCHOR
-//                  anchor && !full   CHAINED anchor: the first stage of step k+1 sits at y_k+1, one
-//                                    step (|delta| ~ dt |qd|) from the anchor of step k -- rotate that
-//                                    anchor to the new point and make the result the new anchor
-//                  !anchor           as TRIG_INCR
-//                The stepping loops set full on every HAMK_TRIG_CHAIN_K-th step, so a chain is at
-//                most K - 1 rotations long: each adds <= ~1.3e-16 absolute (rounding of the rotation
-//                formula; the Taylor kernels contribute < 3e-18), worst case linear in the chain
-//                length, typically its square root -- below the rounding the state itself collects
-//                over the same steps (tests/test_host_emulation.py::test_chained_sincos_accuracy).
+//   TRIG_DYN     decided per evaluation by the WAVE-UNIFORM field `mode` of the cache (a scalar
+//                branch; a compile-time constant wherever the stepping loop knows the stage):
+//                  DYN_FULL_ANCHOR   as TRIG_ANCHOR
+//                  DYN_CHAIN         rotate the anchor to the new point (|delta| < 1/4) and make the
+//                                    result the new anchor
+//                  DYN_NARROW        rotate, |delta| < 1/8
+//                  DYN_SHORT         rotate, |delta| < 1/32
+//                The fixed-step RK4 loops anchor at the MIDPOINT of a step (stage 2, y + h/2 k1):
+//                    stage 1  y_k            delta = y_k - mid_k-1       ~ h/2 |qd|    DYN_NARROW
+//                    stage 2  y_k + h/2 k1   delta = mid_k - mid_k-1     ~ h |qd|      DYN_CHAIN (new anchor)
+//                    stage 3  y_k + h/2 k2   delta = h/2 (k2 - k1)       ~ h^2/4 |qdd| DYN_SHORT
+//                    stage 4  y_k + h k3     delta = h k3 - h/2 k1       ~ h/2 |qd|    DYN_NARROW
+//                so a step costs one wide rotation, two narrow and one short ones per sincos site
+//                (26 + 2 x 23 + 20 fp64 instructions against 42 + 3 x 23 with a full evaluation per
+//                step), and every range is matched to what the stage really moves: a lane beyond its
+//                range re-evaluates in full, and because a wavefront executes what ANY of its lanes
+//                needs, rare lanes make common waves -- in BASELINE config 2, 0.9 % of the lanes move
+//                more than 1/8 rad per step (|qd| up to 16 rad/s x dt) but 42 % of the wavefronts hold
+//                such a lane (measured with the oracle; none moves 1/4).
+//                The chain of anchors starts from a full evaluation at the top of a launch and is
+//                re-anchored by a full evaluation every HAMK_TRIG_CHAIN_K steps, so it is at most
+//                K - 1 rotations long: each adds <= ~1.3e-16 absolute (rounding of the rotation formula;
+//                the Taylor kernels contribute < 3e-18), worst case linear in the chain length,
+//                typically its square root -- below the rounding the state itself collects over the
+//                same steps (tests/test_host_emulation.py::test_chained_sincos_accuracy).
 enum : int { TRIG_FULL = 0, TRIG_REUSE = 1, TRIG_ANCHOR = 2, TRIG_INCR = 3, TRIG_DYN = 4 };
+enum : int { DYN_FULL_ANCHOR = 0, DYN_CHAIN = 1, DYN_NARROW = 2, DYN_SHORT = 3 };
 #ifndef HAMK_TRIG_CHAIN_K
 #define HAMK_TRIG_CHAIN_K 16           // 1: every step re-anchors with a full evaluation (no chaining)
 #endif
@@ -411,26 +426,46 @@ enum : int { TRIG_FULL = 0, TRIG_REUSE = 1, TRIG_ANCHOR = 2, TRIG_INCR = 3, TRIG
 template <int NS> struct TrigCache {
   double s[NS > 0 ? NS : 1], c[NS > 0 ? NS : 1];                           // current point
   double ax[NS > 0 ? NS : 1], as[NS > 0 ? NS : 1], ac[NS > 0 ? NS : 1];    // anchor
-  bool anchor = true, full = true;                                         // TRIG_DYN: wave-uniform
+  int mode = DYN_FULL_ANCHOR;                                              // TRIG_DYN: wave-uniform
   HAMK_DEV TrigCache() {                                                   // a defined anchor (0, sin 0, cos 0) from the start
 #pragma unroll
     for (int k = 0; k < (NS > 0 ? NS : 1); ++k) { ax[k] = 0.0; as[k] = 0.0; ac[k] = 1.0; }
   }
 };
 
+// Rotation of an anchor pair by delta = x - xa, |delta| < 1/4 (WIDE: kernels through delta^11 /
+// delta^12), < 1/8 (NARROW: one term less each) or < 1/32 (SHORT: two terms less each); beyond the
+// range (or NaN) the full evaluation, in a divergent branch.
+enum : int { INCR_WIDE = 0, INCR_NARROW = 1, INCR_SHORT = 2 };
+template <int RANGE = INCR_WIDE>
 HAMK_DEV void sincos_incr(double x, double xa, double sa, double ca, double& s, double& c) {
   const double d = x - xa;
-  const double z = d * d, z2 = z * z, z3 = z2 * z, z4 = z2 * z2;
+  const double z = d * d, z2 = z * z, z3 = z2 * z;
   // the leading coefficients of sincos_f64's kernels serve here too (they differ from the Taylor
-  // coefficients by < 4e-15, i.e. < 1e-17 in the result for |delta| < 1/8): 8 fewer fp64
-  // constants = 16 fewer SGPRs in a kernel that already spills SGPRs
-  double ps = 2.75573137070700676789e-06 * z3;
-  ps = fma(-1.98412698298579493134e-04, z2, ps);
+  // coefficients by < 4e-15, i.e. < 1e-17 in the result for |delta| < 1/4): no extra fp64
+  // constants = no extra SGPR pairs in kernels that are short of SGPRs
+  double ps, pc;
+  if constexpr (RANGE == INCR_WIDE) {
+    const double z4 = z2 * z2, z5 = z4 * z;
+    ps = -2.50507602534068634195e-08 * z4;
+    ps = fma(2.75573137070700676789e-06, z3, ps);
+    ps = fma(-1.98412698298579493134e-04, z2, ps);
+    pc = 2.08757232129817482790e-09 * z5;
+    pc = fma(-2.75573143513906633035e-07, z4, pc);
+    pc = fma(2.48015872894767294178e-05, z3, pc);
+  } else if constexpr (RANGE == INCR_NARROW) {
+    const double z4 = z2 * z2;
+    ps = 2.75573137070700676789e-06 * z3;
+    ps = fma(-1.98412698298579493134e-04, z2, ps);
+    pc = -2.75573143513906633035e-07 * z4;
+    pc = fma(2.48015872894767294178e-05, z3, pc);
+  } else {
+    ps = -1.98412698298579493134e-04 * z2;
+    pc = 2.48015872894767294178e-05 * z3;
+  }
   ps = fma(8.33333333332248946124e-03, z, ps);
   ps += -1.66666666666666324348e-01;
   const double sd = fma(d * z, ps, d);                    // sin(delta)
-  double pc = -2.75573143513906633035e-07 * z4;
-  pc = fma(2.48015872894767294178e-05, z3, pc);
   pc = fma(-1.38888888888741095749e-03, z2, pc);
   pc = fma(4.16666666666666019037e-02, z, pc);
   pc += -0.5;
@@ -438,7 +473,8 @@ HAMK_DEV void sincos_incr(double x, double xa, double sa, double ca, double& s, 
   s = sa + fma(sa, cm1, ca * sd);
   c = ca + fma(ca, cm1, -(sa * sd));
 #ifndef HAMK_PROBE_NO_SLOWPATH
-  if (!(fabs(d) < 0.125)) sincos_f64(x, s, c);            // far from the anchor (or NaN): full evaluation
+  constexpr double lim = (RANGE == INCR_WIDE) ? 0.25 : ((RANGE == INCR_NARROW) ? 0.125 : 0.03125);
+  if (!(fabs(d) < lim)) sincos_f64(x, s, c);              // far from the anchor (or NaN): full evaluation
 #endif
 }
 
@@ -449,16 +485,18 @@ template <int MODE, class TC> HAMK_DEV void trig_pair(double x, TC& tc, int k) {
     sincos_f64(x, tc.s[k], tc.c[k]);
     tc.ax[k] = x; tc.as[k] = tc.s[k]; tc.ac[k] = tc.c[k];
   } else if constexpr (MODE == TRIG_INCR) {
-    sincos_incr(x, tc.ax[k], tc.as[k], tc.ac[k], tc.s[k], tc.c[k]);
+    sincos_incr<INCR_WIDE>(x, tc.ax[k], tc.as[k], tc.ac[k], tc.s[k], tc.c[k]);
   } else if constexpr (MODE == TRIG_DYN) {
-#ifdef HAMK_PROBE_TRIG      // scripts/isa_stats.py: fix the case at compile time (0 full anchor, 1 chained anchor, 2 rotate only)
-    const bool anchor = (HAMK_PROBE_TRIG) < 2, full = (HAMK_PROBE_TRIG) == 0;
+#ifdef HAMK_PROBE_TRIG      // scripts/isa_stats.py: fix the case at compile time
+    const int mode = (HAMK_PROBE_TRIG);
 #else
-    const bool anchor = tc.anchor, full = tc.full;
+    const int mode = tc.mode;
 #endif
-    if (anchor && full) sincos_f64(x, tc.s[k], tc.c[k]);
-    else sincos_incr(x, tc.ax[k], tc.as[k], tc.ac[k], tc.s[k], tc.c[k]);
-    if (anchor) { tc.ax[k] = x; tc.as[k] = tc.s[k]; tc.ac[k] = tc.c[k]; }
+    if (mode == DYN_FULL_ANCHOR) sincos_f64(x, tc.s[k], tc.c[k]);
+    else if (mode == DYN_CHAIN) sincos_incr<INCR_WIDE>(x, tc.ax[k], tc.as[k], tc.ac[k], tc.s[k], tc.c[k]);
+    else if (mode == DYN_NARROW) sincos_incr<INCR_NARROW>(x, tc.ax[k], tc.as[k], tc.ac[k], tc.s[k], tc.c[k]);
+    else sincos_incr<INCR_SHORT>(x, tc.ax[k], tc.as[k], tc.ac[k], tc.s[k], tc.c[k]);
+    if (mode == DYN_FULL_ANCHOR || mode == DYN_CHAIN) { tc.ax[k] = x; tc.as[k] = tc.s[k]; tc.ac[k] = tc.c[k]; }
   }
 }
 
@@ -697,12 +735,13 @@ template <class S, class A> HAMK_DEV void mass_matrix(const A (&x)[S::M], double
 }
 
 // grad U(q): potential over generalized coordinates, or (u . f) for mkSystem'
+// tcf: the sincos pairs f has just been evaluated with at the same q (shared sites are read from it)
 template <class S> HAMK_DEV void grad_potential(const Jet1<S::N> (&qj)[S::N], const Jet1<S::N> (&xj)[S::M],
-                                                double (&gU)[S::N], double& U) {
+                                                double (&gU)[S::N], double& U, TrigCache<S::NTRIG_F>& tcf) {
   Jet1<S::N> u;
   TrigCache<S::NTRIG_U> tu;
   if constexpr (S::U_CART) u = S::template potential<Jet1<S::N>, TRIG_FULL>(xj, tu);
-  else u = S::template potential<Jet1<S::N>, TRIG_FULL>(qj, tu);
+  else u = S::template potential_after_f<Jet1<S::N>, TRIG_FULL>(qj, tu, tcf);
   U = u.v;
 #pragma unroll
   for (int i = 0; i < S::N; ++i) gU[i] = u.d[i];
@@ -791,7 +830,7 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
     }
     mass_matrix<S>(xj, K);
     solve_spd<N, S::INERTIA_POS>(K, p, v, st);
-    grad_potential<S>(qj, xj, gU, U);
+    grad_potential<S>(qj, xj, gU, U, tc);
 #pragma unroll
     for (int i = 0; i < N; ++i) dT[i] = 0.0;
 #pragma unroll
@@ -814,7 +853,7 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
     S::template coords<Jet1<N>, TRIG>(qj, xj, tc);
     mass_matrix<S>(xj, K);
     solve_spd<N, S::INERTIA_POS>(K, p, v, st);
-    grad_potential<S>(qj, xj, gU, U);
+    grad_potential<S>(qj, xj, gU, U, tc);
     if constexpr (S::MODE_R) {
       // MODE_R: the contraction is a gradient -- one forward (value, tangent along qd) pass and one
       // reverse pass over the tape (generated, S::dT_reverse), O(tape) instead of O(n * tape)
@@ -917,6 +956,12 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
   const double h2 = 0.5 * dt, h6 = dt * (1.0 / 6.0), h3 = dt * (1.0 / 3.0);
   double H0 = 0.0;
   if (drift_tol > 0.0) H0 = energy<S>(y, st);
+  if constexpr (StageTrig<S>::on) {                       // the chain of sincos anchors starts from a full evaluation
+    double q0[N], x0[S::M];                               // at the launch's initial state (values only; x0 is dead)
+#pragma unroll
+    for (int j = 0; j < N; ++j) q0[j] = y[j];
+    S::template coords<double, TRIG_ANCHOR>(q0, x0, tc);
+  }
   if constexpr (S::RK4_STAGE_LOOP) {
     // one copy of the right-hand side, executed 4 x nsteps times: keeps the live set to a
     // single hamEqs (n >= 3 would otherwise pay for four interleaved copies in VGPRs).
@@ -931,8 +976,9 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
       double yt[D];
 #pragma unroll
       for (int j = 0; j < D; ++j) yt[j] = fma(a, k[j], y[j]);
-      tc.anchor = (sg == 0);                                    // stage 1 (re-)anchors, stages 2-4 rotate the anchor
-      tc.full = ((it >> 2) % HAMK_TRIG_CHAIN_K) == 0;
+      // sincos: anchored at the step's midpoint (stage 2), see TRIG_DYN
+      tc.mode = (sg == 1) ? ((((it >> 2) + 1) % HAMK_TRIG_CHAIN_K == 0) ? DYN_FULL_ANCHOR : DYN_CHAIN)
+                          : ((sg == 2) ? DYN_SHORT : DYN_NARROW);
       rhs<S, StageTrig<S>::dyn>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) acc[j] = fma(b, k[j], acc[j]);
@@ -945,21 +991,22 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
       double k[D], yt[D], acc[D];
-      // stage 1 anchors sincos -- by a full evaluation on every HAMK_TRIG_CHAIN_K-th step, otherwise by
-      // rotating the previous step's anchor (TRIG_DYN); stages 2-4 sit at y + a dt k, a few hundredths
-      // of a radian away, and rotate the anchor pair (TRIG_INCR)
-      tc.anchor = true;
-      tc.full = (s % HAMK_TRIG_CHAIN_K) == 0;
+      // sincos: the anchor lives at the step's midpoint (stage 2), chained from step to step and
+      // re-anchored by a full evaluation every HAMK_TRIG_CHAIN_K steps (TRIG_DYN above)
+      tc.mode = DYN_NARROW;
       rhs<S, StageTrig<S>::dyn>(y, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) { acc[j] = fma(h6, k[j], y[j]); yt[j] = fma(h2, k[j], y[j]); }
-      rhs<S, StageTrig<S>::incr>(yt, k, st, tc);
+      tc.mode = ((s + 1) % HAMK_TRIG_CHAIN_K == 0) ? DYN_FULL_ANCHOR : DYN_CHAIN;
+      rhs<S, StageTrig<S>::dyn>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) { acc[j] = fma(h3, k[j], acc[j]); yt[j] = fma(h2, k[j], y[j]); }
-      rhs<S, StageTrig<S>::incr>(yt, k, st, tc);
+      tc.mode = DYN_SHORT;
+      rhs<S, StageTrig<S>::dyn>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) { acc[j] = fma(h3, k[j], acc[j]); yt[j] = fma(dt, k[j], y[j]); }
-      rhs<S, StageTrig<S>::incr>(yt, k, st, tc);
+      tc.mode = DYN_NARROW;
+      rhs<S, StageTrig<S>::dyn>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) y[j] = fma(h6, k[j], acc[j]);
     }

@@ -415,7 +415,47 @@ inline void rk4Steps(double dt, int nsteps, System& s, DevicePhase& d) {      //
 inline void stepHam(double r, System& s, DevicePhase& d) {                     // :390-402, in place, asynchronous
   check(hamk_step_ham_batch(s.handle(), d.B, d.positions.as<double>(), d.momenta.as<double>(), r, d.status.as<int32_t>(), nullptr, HAMK_MEM_DEVICE));
 }
+// ... with the launch checking its own energy invariant: HAMK_ST_DRIFT in d.status where
+// |H_exit - H_entry| > drift_tol * max(1, |H_entry|)   (hamk_rk4_steps_checked)
+inline void rk4StepsChecked(double dt, int nsteps, double drift_tol, System& s, DevicePhase& d) {
+  check(hamk_rk4_steps_checked(s.handle(), d.B, d.positions.as<double>(), d.momenta.as<double>(), dt, nsteps, drift_tol, d.status.as<int32_t>(), HAMK_MEM_DEVICE));
+}
 inline void synchronize(const System& s) { check(hamk_synchronize(s.handle())); }
+
+// Which binding of hmatrix-gsl's gsl-ode.c stepHam / evolveHam follow (hamk.h): 2 = gsl_odeiv2
+// driver (default), 1 = old gsl_odeiv (-DGSLODE1)
+inline void setGslApi(System& s, int api) { check(hamk_system_set_gsl_api(s.handle(), api)); }
+inline int gslApi(const System& s) { return hamk_system_get_gsl_api(s.handle()); }
+
+// Ensemble checkpoint / resume: the device-resident state to one flat file
+// and back; a run cut at a multiple of 16 steps continues bit-identically (hamk.h)
+struct CheckpointInfo { int32_t n = 0; int64_t B = 0, steps_done = 0; uint64_t seed = 0; double t = 0.0; };
+inline void saveCheckpoint(const std::string& path, const System& s, const DevicePhase& d, int64_t steps_done, uint64_t seed, double t) {
+  check(hamk_synchronize(s.handle()));
+  check(hamk_checkpoint_write(path.c_str(), d.n, d.B, d.positions.as<double>(), d.momenta.as<double>(), HAMK_MEM_DEVICE, steps_done, seed, t));
+}
+inline void saveCheckpoint(const std::string& path, const Phase& h, int64_t steps_done, uint64_t seed, double t) {
+  check(hamk_checkpoint_write(path.c_str(), h.n, h.B, h.positions.data(), h.momenta.data(), HAMK_MEM_HOST, steps_done, seed, t));
+}
+inline CheckpointInfo checkpointInfo(const std::string& path) {
+  CheckpointInfo i;
+  check(hamk_checkpoint_info(path.c_str(), &i.n, &i.B, &i.steps_done, &i.seed, &i.t));
+  return i;
+}
+inline DevicePhase loadCheckpointDevice(const std::string& path, CheckpointInfo* info = nullptr) {
+  const CheckpointInfo i = checkpointInfo(path);
+  DevicePhase d(i.n, i.B);
+  check(hamk_checkpoint_read(path.c_str(), i.n, i.B, d.positions.as<double>(), d.momenta.as<double>(), HAMK_MEM_DEVICE));
+  if (info) *info = i;
+  return d;
+}
+inline Phase loadCheckpoint(const std::string& path, CheckpointInfo* info = nullptr) {
+  const CheckpointInfo i = checkpointInfo(path);
+  Phase h; h.n = i.n; h.B = i.B; h.positions.resize((size_t)i.n * i.B); h.momenta.resize((size_t)i.n * i.B);
+  check(hamk_checkpoint_read(path.c_str(), i.n, i.B, h.positions.data(), h.momenta.data(), HAMK_MEM_HOST));
+  if (info) *info = i;
+  return h;
+}
 inline std::vector<double> hamiltonian(System& s, const DevicePhase& d) {      // :353-361
   DeviceArray h(8 * d.B), st(4 * d.B);
   check(hamk_observe_batch(s.handle(), d.B, d.positions.as<double>(), d.momenta.as<double>(), nullptr, nullptr, h.as<double>(), st.as<int32_t>(), HAMK_MEM_DEVICE));

@@ -157,12 +157,15 @@ def rk4_step_stats(spec, system=None):
       -DHAMK_PROBE_NO_SLOWPATH  removes the bodies of the rare branches (library sin/cos for
                                 |x| >= 1.6e6 or NaN, far-from-anchor re-evaluation, ...: ~2000
                                 instructions inside the stepping loop that are never executed);
-      -DHAMK_PROBE_TRIG=0|1|2   fixes the wave-uniform sincos case of an evaluation at compile time
-                                (0 full anchor, 1 chained anchor, 2 rotate only), so the two sides
-                                of that scalar branch are not both counted.
-    The hottest loop is one step (unrolled body) or one stage (stage-loop / wave bodies).  Per step:
-      unrolled    A/K + C (1 - 1/K)                A, C: loop with TRIG = 0, 1
-      stage loop  A/K + C (1 - 1/K) + 3 I          A, C, I: loop with TRIG = 0, 1, 2
+      -DHAMK_PROBE_TRIG=m       fixes the wave-uniform sincos mode of EVERY evaluation at compile time
+                                (m = 0 full anchor, 1 chained wide, 2 narrow, 3 short), so the sides
+                                of that scalar switch are not all counted.
+    The hottest loop is one step (unrolled body: four evaluations) or one stage (stage-loop / wave
+    bodies: one).  With L(m) the loop's count in mode m, a step -- stage modes narrow, chain (full on
+    every K-th step), short, narrow -- costs
+      stage loop  2 L(2) + L(3) + L(1) (1 - 1/K) + L(0) / K
+      unrolled    the same combination of L(m) / 4 ... plus nothing: L(m) = base + 4 t(m) is linear in
+                  the per-evaluation sincos cost t(m), so the combination weights are the same / 4
     Cross-check: PMC SQ_INSTS_VALU per wave per step (profiles/*_summary.json).
     Returns None when llvm-objdump is unavailable."""
     if not os.path.exists(OBJDUMP):
@@ -208,12 +211,12 @@ def rk4_step_stats(spec, system=None):
                 "lds": st["histogram"].get("lds", 0), "scratch": st["histogram"].get("scratch", 0)}
 
     if chained:
-        A, C = count(0), count(1)
-        I = count(2) if stage_loop else None
-        if A is None or C is None or (stage_loop and I is None):
+        L = [count(m) for m in (0, 1, 2, 3)]
+        if any(x is None for x in L):
             return None
-        w = {k: A[k] / K + C[k] * (1.0 - 1.0 / K) + (3 * I[k] if stage_loop else 0) for k in A}
-        detail = {"full_anchor": A, "chained_anchor": C, "rotate_only": I, "chain_K": K}
+        scale = 1.0 if stage_loop else 0.25
+        w = {k: scale * (2 * L[2][k] + L[3][k] + L[1][k] * (1.0 - 1.0 / K) + L[0][k] / K) for k in L[0]}
+        detail = {"loop_all_full_anchor": L[0], "loop_all_chain_wide": L[1], "loop_all_narrow": L[2], "loop_all_short": L[3], "chain_K": K}
     else:
         A = count(None)
         if A is None:

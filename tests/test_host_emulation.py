@@ -217,7 +217,7 @@ def test_chained_anchors_over_many_steps_on_host(emulate, oracle_lib, name, loop
     p = o.to_phase_batch(q, qd)
     oq, op = o.rk4_steps_batch(q, p, spec.dt, 40)
     res = {}
-    for k in ("16", "1"):
+    for k in ("16", "1"):                                     # 1: a full evaluation at every step's midpoint
         L, src = emulate(spec, {"HAMK_TRIG_CHAIN": k, "HAMK_RK4_LOOP": loop})
         assert ("HAMK_TRIG_CHAIN_K 1" in src) == (k == "1") and ("RK4_STAGE_LOOP = true" in src) == (loop == "1")
         q2, p2, st = q.copy(), p.copy(), np.zeros(B, np.int32)
@@ -325,23 +325,39 @@ def test_own_sincos_accuracy(elementary):
     es, ec = np.abs(s - np.sin(xl)).max(), np.abs(c - np.cos(xl)).max()
     assert float(es) < 2.0e-16 and float(ec) < 2.0e-16, (float(es), float(ec))
     xa = rng.uniform(-50, 50, 400000)
-    d = rng.uniform(-0.2, 0.2, xa.size)               # beyond |d| = 1/8 the routine falls back to the full evaluation
+    d = rng.uniform(-0.4, 0.4, xa.size)               # beyond |d| = 1/4 the routine falls back to the full evaluation
     elementary.emu_sincos_incr(P(xa), P(d), P(s[:xa.size]), P(c[:xa.size]), LL(xa.size))
     xl = (xa + d).astype(np.longdouble)
     es, ec = np.abs(s[:xa.size] - np.sin(xl)).max(), np.abs(c[:xa.size] - np.cos(xl)).max()
     assert float(es) < 3.0e-16 and float(ec) < 3.0e-16, (float(es), float(ec))
 
 
+def test_rotation_ranges(elementary):
+    """The three rotation kernels over their whole range (and a little beyond: full re-evaluation
+    there), against 80-bit long double: wide |delta| < 1/4, narrow < 1/8, short < 1/32."""
+    rng = np.random.default_rng(12)
+    n = 600_000
+    xa = rng.uniform(-50, 50, n)
+    s, c = np.zeros(n), np.zeros(n)
+    for rid, lim in ((0, 0.25), (1, 0.125), (2, 0.03125)):
+        d = rng.uniform(-1.3 * lim, 1.3 * lim, n)
+        d[:4] = [lim * (1 - 1e-12), -lim * (1 - 1e-12), lim, -lim]
+        elementary.emu_sincos_incr_range(P(xa), P(d), rid, P(s), P(c), LL(n))
+        xl = (xa + d).astype(np.longdouble)
+        es, ec = float(np.abs(s - np.sin(xl)).max()), float(np.abs(c - np.cos(xl)).max())
+        assert es < 3.0e-16 and ec < 3.0e-16, (rid, es, ec)
+
+
 def test_chained_sincos_accuracy(elementary):
     """TRIG_DYN chains (hamk_device.hpp): the anchor of step k+1 is the anchor of step k rotated by
     delta = dt * qd; a full evaluation every HAMK_TRIG_CHAIN_K = 16 steps bounds the chain at 15
-    rotations.  Against 80-bit long double over 1e6 chains with |delta| up to 0.12: the error after a
+    rotations.  Against 80-bit long double over 1e6 chains with |delta| up to 0.249: the error after a
     full-length chain stays within a few ulp (worst case linear in the length, typically ~sqrt) --
     below the rounding the integrated angle itself collects over the same 15 steps."""
     rng = np.random.default_rng(11)
     n = 1_000_000
     x0 = rng.uniform(-50, 50, n)
-    d = rng.uniform(-0.12, 0.12, n)
+    d = rng.uniform(-0.249, 0.249, n)
     s, c = np.zeros(n), np.zeros(n)
     worst = {}
     for length in (1, 15, 63):
