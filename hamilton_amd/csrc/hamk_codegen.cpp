@@ -396,7 +396,6 @@ std::string generate_source(const SystemDesc& d) {
   std::ostringstream o;
   o << "// generated by libhamk (hamk_codegen.cpp) from the expression tape of one System " << d.m << " " << d.n << "\n";
   if (d.rk4_min_waves > 1) o << "#define HAMK_RK4_MIN_WAVES " << d.rk4_min_waves << "\n";
-  if (d.trig_chain != 16) o << "#define HAMK_TRIG_CHAIN_K " << d.trig_chain << "\n";
   o << (d.wave ? "#include \"hamk_wave.hpp\"\n\n" : "#include \"hamk_device.hpp\"\n\n");
   o << "struct HamkSys {\n";
   o << "  static constexpr int N = " << d.n << ";\n";

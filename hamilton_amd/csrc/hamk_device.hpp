@@ -393,35 +393,28 @@ template <int N> HAMK_DEV Jet2<N> operator/(double c, const Jet2<N>& b) { return
 //                quadrant logic, absolute error < 3e-18 + rounding); otherwise as FULL.
 //                Always relative to the anchor of the current step, so nothing accumulates.
 //   TRIG_DYN     decided per evaluation by the WAVE-UNIFORM field `mode` of the cache (a scalar
-//                branch; a compile-time constant wherever the stepping loop knows the stage):
-//                  DYN_FULL_ANCHOR   as TRIG_ANCHOR
-//                  DYN_CHAIN         rotate the anchor to the new point (|delta| < 1/4) and make the
-//                                    result the new anchor
-//                  DYN_NARROW        rotate, |delta| < 1/8
-//                  DYN_SHORT         rotate, |delta| < 1/32
-//                The fixed-step RK4 loops anchor at the MIDPOINT of a step (stage 2, y + h/2 k1):
-//                    stage 1  y_k            delta = y_k - mid_k-1       ~ h/2 |qd|    DYN_NARROW
-//                    stage 2  y_k + h/2 k1   delta = mid_k - mid_k-1     ~ h |qd|      DYN_CHAIN (new anchor)
-//                    stage 3  y_k + h/2 k2   delta = h/2 (k2 - k1)       ~ h^2/4 |qdd| DYN_SHORT
-//                    stage 4  y_k + h k3     delta = h k3 - h/2 k1       ~ h/2 |qd|    DYN_NARROW
-//                so a step costs one wide rotation, two narrow and one short ones per sincos site
-//                (26 + 2 x 23 + 20 fp64 instructions against 42 + 3 x 23 with a full evaluation per
-//                step), and every range is matched to what the stage really moves: a lane beyond its
-//                range re-evaluates in full, and because a wavefront executes what ANY of its lanes
-//                needs, rare lanes make common waves -- in BASELINE config 2, 0.9 % of the lanes move
-//                more than 1/8 rad per step (|qd| up to 16 rad/s x dt) but 42 % of the wavefronts hold
-//                such a lane (measured with the oracle; none moves 1/4).
-//                The chain of anchors starts from a full evaluation at the top of a launch and is
-//                re-anchored by a full evaluation every HAMK_TRIG_CHAIN_K steps, so it is at most
-//                K - 1 rotations long: each adds <= ~1.3e-16 absolute (rounding of the rotation formula;
-//                the Taylor kernels contribute < 3e-18), worst case linear in the chain length,
-//                typically its square root -- below the rounding the state itself collects over the
-//                same steps (tests/test_host_emulation.py::test_chained_sincos_accuracy).
+//                branch; a compile-time constant wherever the stepping loop knows the stage).  The
+//                fixed-step RK4 loops move the anchor to the MIDPOINT of the step:
+//                    stage 1  y              full evaluation, anchor                  DYN_FULL_ANCHOR
+//                    stage 2  y + h/2 k1     delta = h/2 k1 ~ h/2 |qd|: rotate (|delta| < 1/8)
+//                                            and make the result the anchor            DYN_NARROW_ANCHOR
+//                    stage 3  y + h/2 k2     delta = h/2 (k2 - k1) ~ h^2/4 |qdd| < 1/32  DYN_SHORT
+//                    stage 4  y + h k3       delta = h k3 - h/2 k1 ~ h/2 |qd| < 1/8      DYN_NARROW
+//                -- 42 + 23 + 20 + 23 instructions per sincos site and step instead of 42 + 3 x 23 with
+//                every stage measured from y, where stage 4 sits a full h |qd| away.  The ranges are
+//                matched to what each stage really moves because a lane beyond its range re-evaluates
+//                in full and a wavefront executes what ANY of its lanes needs: rare lanes make common
+//                waves.  In BASELINE config 2, 0.9 % of the lanes move more than 1/8 rad per step (|qd|
+//                up to 16 rad/s x dt) but 42 % of the wavefronts hold such a lane (measured with the
+//                oracle) -- with every stage anchored at y that was the price of stage 4.
+//                A step stays a pure function of the state (the anchor never crosses a step), so
+//                N steps in one launch, in two launches or after a checkpoint are the same bits; stage
+//                3 and 4 pairs are two rotations away from a full evaluation: <= ~3e-16 absolute.
+//                (Chaining the anchor ACROSS steps -- stage 1 rotated from the previous midpoint, a full
+//                evaluation every K steps -- was built and measured: fewer instructions, no gain on
+//                MI355X, and it costs exactly that purity; profiles/r02_sweep_chain.jsonl.)
 enum : int { TRIG_FULL = 0, TRIG_REUSE = 1, TRIG_ANCHOR = 2, TRIG_INCR = 3, TRIG_DYN = 4 };
-enum : int { DYN_FULL_ANCHOR = 0, DYN_CHAIN = 1, DYN_NARROW = 2, DYN_SHORT = 3 };
-#ifndef HAMK_TRIG_CHAIN_K
-#define HAMK_TRIG_CHAIN_K 16           // 1: every step re-anchors with a full evaluation (no chaining)
-#endif
+enum : int { DYN_FULL_ANCHOR = 0, DYN_NARROW_ANCHOR = 1, DYN_NARROW = 2, DYN_SHORT = 3 };
 
 template <int NS> struct TrigCache {
   double s[NS > 0 ? NS : 1], c[NS > 0 ? NS : 1];                           // current point
@@ -433,16 +426,16 @@ template <int NS> struct TrigCache {
   }
 };
 
-// Rotation of an anchor pair by delta = x - xa, |delta| < 1/4 (WIDE: kernels through delta^11 /
-// delta^12), < 1/8 (NARROW: one term less each) or < 1/32 (SHORT: two terms less each); beyond the
-// range (or NaN) the full evaluation, in a divergent branch.
+// Rotation of an anchor pair (sa, ca) by d: kernels through d^11 / d^12 (WIDE, |d| < 1/4), one term
+// less each (NARROW, |d| < 1/8), two less (SHORT, |d| < 1/32); absolute error < 3e-18 + rounding.
 enum : int { INCR_WIDE = 0, INCR_NARROW = 1, INCR_SHORT = 2 };
-template <int RANGE = INCR_WIDE>
-HAMK_DEV void sincos_incr(double x, double xa, double sa, double ca, double& s, double& c) {
-  const double d = x - xa;
+template <int RANGE> HAMK_DEV constexpr double incr_limit() {
+  return (RANGE == INCR_WIDE) ? 0.25 : ((RANGE == INCR_NARROW) ? 0.125 : 0.03125);
+}
+template <int RANGE> HAMK_DEV void rotate_pair(double d, double sa, double ca, double& s, double& c) {
   const double z = d * d, z2 = z * z, z3 = z2 * z;
   // the leading coefficients of sincos_f64's kernels serve here too (they differ from the Taylor
-  // coefficients by < 4e-15, i.e. < 1e-17 in the result for |delta| < 1/4): no extra fp64
+  // coefficients by < 4e-15, i.e. < 1e-17 in the result for |d| < 1/4): no extra fp64
   // constants = no extra SGPR pairs in kernels that are short of SGPRs
   double ps, pc;
   if constexpr (RANGE == INCR_WIDE) {
@@ -465,16 +458,23 @@ HAMK_DEV void sincos_incr(double x, double xa, double sa, double ca, double& s, 
   }
   ps = fma(8.33333333332248946124e-03, z, ps);
   ps += -1.66666666666666324348e-01;
-  const double sd = fma(d * z, ps, d);                    // sin(delta)
+  const double sd = fma(d * z, ps, d);                    // sin(d)
   pc = fma(-1.38888888888741095749e-03, z2, pc);
   pc = fma(4.16666666666666019037e-02, z, pc);
   pc += -0.5;
-  const double cm1 = z * pc;                              // cos(delta) - 1
+  const double cm1 = z * pc;                              // cos(d) - 1
   s = sa + fma(sa, cm1, ca * sd);
   c = ca + fma(ca, cm1, -(sa * sd));
+}
+
+// sincos(x) from the anchor (xa, sa, ca); beyond the range (or NaN) the full evaluation, in a
+// divergent branch
+template <int RANGE = INCR_WIDE>
+HAMK_DEV void sincos_incr(double x, double xa, double sa, double ca, double& s, double& c) {
+  const double d = x - xa;
+  rotate_pair<RANGE>(d, sa, ca, s, c);
 #ifndef HAMK_PROBE_NO_SLOWPATH
-  constexpr double lim = (RANGE == INCR_WIDE) ? 0.25 : ((RANGE == INCR_NARROW) ? 0.125 : 0.03125);
-  if (!(fabs(d) < lim)) sincos_f64(x, s, c);              // far from the anchor (or NaN): full evaluation
+  if (!(fabs(d) < incr_limit<RANGE>())) sincos_f64(x, s, c);
 #endif
 }
 
@@ -492,11 +492,21 @@ template <int MODE, class TC> HAMK_DEV void trig_pair(double x, TC& tc, int k) {
 #else
     const int mode = tc.mode;
 #endif
+    // ONE copy of the full evaluation per site (it carries the library path for huge / non-finite
+    // arguments, ~2000 instructions): taken by every lane in mode FULL_ANCHOR, by the lanes beyond
+    // the range of their rotation otherwise
+    bool full = true;
+    if (mode != DYN_FULL_ANCHOR) {
+      const double d = x - tc.ax[k];
+      if (mode == DYN_SHORT) { rotate_pair<INCR_SHORT>(d, tc.as[k], tc.ac[k], tc.s[k], tc.c[k]); full = !(fabs(d) < incr_limit<INCR_SHORT>()); }
+      else { rotate_pair<INCR_NARROW>(d, tc.as[k], tc.ac[k], tc.s[k], tc.c[k]); full = !(fabs(d) < incr_limit<INCR_NARROW>()); }
+    }
+#ifdef HAMK_PROBE_NO_SLOWPATH
     if (mode == DYN_FULL_ANCHOR) sincos_f64(x, tc.s[k], tc.c[k]);
-    else if (mode == DYN_CHAIN) sincos_incr<INCR_WIDE>(x, tc.ax[k], tc.as[k], tc.ac[k], tc.s[k], tc.c[k]);
-    else if (mode == DYN_NARROW) sincos_incr<INCR_NARROW>(x, tc.ax[k], tc.as[k], tc.ac[k], tc.s[k], tc.c[k]);
-    else sincos_incr<INCR_SHORT>(x, tc.ax[k], tc.as[k], tc.ac[k], tc.s[k], tc.c[k]);
-    if (mode == DYN_FULL_ANCHOR || mode == DYN_CHAIN) { tc.ax[k] = x; tc.as[k] = tc.s[k]; tc.ac[k] = tc.c[k]; }
+#else
+    if (full) sincos_f64(x, tc.s[k], tc.c[k]);
+#endif
+    if (mode == DYN_FULL_ANCHOR || mode == DYN_NARROW_ANCHOR) { tc.ax[k] = x; tc.as[k] = tc.s[k]; tc.ac[k] = tc.c[k]; }
   }
 }
 
@@ -894,7 +904,7 @@ template <class S> struct StageTrig {
 #endif
   static constexpr int anchor = on ? TRIG_ANCHOR : TRIG_FULL;
   static constexpr int incr = on ? TRIG_INCR : TRIG_FULL;
-  static constexpr int dyn = on ? TRIG_DYN : TRIG_FULL;      // the fixed-step loops (chained anchors)
+  static constexpr int dyn = on ? TRIG_DYN : TRIG_FULL;      // the fixed-step loops (anchor at the step's midpoint)
 };
 
 template <class S, int TRIG = TRIG_FULL>
@@ -956,12 +966,6 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
   const double h2 = 0.5 * dt, h6 = dt * (1.0 / 6.0), h3 = dt * (1.0 / 3.0);
   double H0 = 0.0;
   if (drift_tol > 0.0) H0 = energy<S>(y, st);
-  if constexpr (StageTrig<S>::on) {                       // the chain of sincos anchors starts from a full evaluation
-    double q0[N], x0[S::M];                               // at the launch's initial state (values only; x0 is dead)
-#pragma unroll
-    for (int j = 0; j < N; ++j) q0[j] = y[j];
-    S::template coords<double, TRIG_ANCHOR>(q0, x0, tc);
-  }
   if constexpr (S::RK4_STAGE_LOOP) {
     // one copy of the right-hand side, executed 4 x nsteps times: keeps the live set to a
     // single hamEqs (n >= 3 would otherwise pay for four interleaved copies in VGPRs).
@@ -976,9 +980,8 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
       double yt[D];
 #pragma unroll
       for (int j = 0; j < D; ++j) yt[j] = fma(a, k[j], y[j]);
-      // sincos: anchored at the step's midpoint (stage 2), see TRIG_DYN
-      tc.mode = (sg == 1) ? ((((it >> 2) + 1) % HAMK_TRIG_CHAIN_K == 0) ? DYN_FULL_ANCHOR : DYN_CHAIN)
-                          : ((sg == 2) ? DYN_SHORT : DYN_NARROW);
+      tc.mode = sg;                                             // DYN_FULL_ANCHOR, _NARROW_ANCHOR, _NARROW (stage 4), _SHORT (stage 3)
+      if (sg >= 2) tc.mode = 5 - sg;
       rhs<S, StageTrig<S>::dyn>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) acc[j] = fma(b, k[j], acc[j]);
@@ -991,13 +994,12 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
       double k[D], yt[D], acc[D];
-      // sincos: the anchor lives at the step's midpoint (stage 2), chained from step to step and
-      // re-anchored by a full evaluation every HAMK_TRIG_CHAIN_K steps (TRIG_DYN above)
-      tc.mode = DYN_NARROW;
+      // sincos: full evaluation at y, the anchor then moves to the step's midpoint (TRIG_DYN above)
+      tc.mode = DYN_FULL_ANCHOR;
       rhs<S, StageTrig<S>::dyn>(y, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) { acc[j] = fma(h6, k[j], y[j]); yt[j] = fma(h2, k[j], y[j]); }
-      tc.mode = ((s + 1) % HAMK_TRIG_CHAIN_K == 0) ? DYN_FULL_ANCHOR : DYN_CHAIN;
+      tc.mode = DYN_NARROW_ANCHOR;
       rhs<S, StageTrig<S>::dyn>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) { acc[j] = fma(h3, k[j], acc[j]); yt[j] = fma(h2, k[j], y[j]); }

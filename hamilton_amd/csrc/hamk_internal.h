@@ -15,7 +15,6 @@ struct SystemDesc {
   bool rk4_stage_loop = false;
   bool rkf_stage_loop = false;
   int rk4_min_waves = 1;        // __launch_bounds__ second argument of the RK4 kernel (waves per SIMD)
-  int trig_chain = 16;          // fixed-step loops: a full sincos re-anchor every this many steps (1 = every step)
   bool wave = false;            // wave-cooperative kernels (hamk_wave.hpp) instead of one trajectory per lane
   std::vector<double> inertia;
   std::vector<hamk_op> f_ops;

@@ -76,6 +76,37 @@ class Tape:
         outs = (ctypes.c_int32 * max(1, len(self.outs)))(*self.outs)
         return arr, len(self.ops), outs
 
+    def canonical(self) -> "Tape":
+        """The same recording in CANONICAL form: only the values the outputs depend on, numbered in
+        depth-first post-order from the outputs (first operand before second, outputs in order).
+        A recorder is free to emit constants early or late and to leave folded-away operands behind;
+        the canonical form depends on the expression alone, so every host shim (this one,
+        include/hamilton.hpp, bindings/haskell) ships byte-identical tapes for the same function
+        (tests/test_recorders.py) -- and the code-object cache keys on it."""
+        binary = (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_POW, OP_ATAN2)
+        new_id = {}
+        out = Tape(self.n_in)
+        for root in self.outs:
+            stack = [(root, 0)]
+            while stack:
+                node, phase = stack.pop()
+                if node in new_id:
+                    continue
+                op, a, b, c = self.ops[node]
+                kids = [] if op in (OP_CONST, OP_INPUT) else ([a, b] if op in binary else [a])
+                if phase == 0:
+                    stack.append((node, 1))
+                    for k in reversed(kids):
+                        if k not in new_id:
+                            stack.append((k, 0))
+                else:
+                    na = new_id[a] if kids else a
+                    nb = new_id[b] if len(kids) == 2 else b
+                    new_id[node] = len(out.ops)
+                    out.ops.append((op, na, nb, c))
+        out.outs = [new_id[r] for r in self.outs]
+        return out
+
     def evaluate(self, xs: Sequence[float]) -> List[float]:
         """Plain-float interpretation (host-side sanity check of a recording)."""
         v: List[float] = []
@@ -236,9 +267,8 @@ class Var:
                 return a
             if ca == 1.0:
                 return Var(t, t.emit(OP_RECIP, b.idx))
-        if op in (OP_ADD, OP_MUL) and a.idx > b.idx:   # canonical order for hash-consing
-            a, b = b, a
-        return Var(t, t.emit(op, a.idx, b.idx))
+        return Var(t, t.emit(op, a.idx, b.idx))      # operands in the order written (no commutative reordering:
+        #                                              the tape must be a function of the expression alone, see Tape.canonical)
 
     def __add__(self, o): return self._bin(OP_ADD, o)
     def __radd__(self, o): return self._bin(OP_ADD, o, True)
@@ -379,4 +409,4 @@ def trace(fn: Callable, n_in: int, n_out: int | None = None) -> Tape:
         elif r.tape is not tape:
             raise ValueError("result belongs to a different recording")
         tape.outs.append(r.idx)
-    return tape
+    return tape.canonical()

@@ -59,6 +59,44 @@ class Tape {
   }
   const std::vector<hamk_op>& ops() const { return ops_; }
   int n_in() const { return n_in_; }
+  // The same recording in CANONICAL form: only the values the outputs depend on, numbered in
+  // depth-first post-order from the outputs (first operand before second, outputs in order) -- a
+  // function of the expression alone, whatever order a recorder emitted constants in.  Every host
+  // shim ships this form: byte-identical tapes for the same function (tests/test_recorders.py).
+  // `outs` is rewritten to the new ids.
+  std::vector<hamk_op> canonical(std::vector<int32_t>& outs) const {
+    auto kids = [](const hamk_op& o) {
+      if (o.op == HAMK_OP_CONST || o.op == HAMK_OP_INPUT) return 0;
+      return (o.op == HAMK_OP_ADD || o.op == HAMK_OP_SUB || o.op == HAMK_OP_MUL || o.op == HAMK_OP_DIV ||
+              o.op == HAMK_OP_POW || o.op == HAMK_OP_ATAN2) ? 2 : 1;
+    };
+    std::vector<int32_t> new_id(ops_.size(), -1);
+    std::vector<hamk_op> out;
+    std::vector<std::pair<int32_t, int>> stack;
+    for (int32_t root : outs) {
+      stack.push_back({root, 0});
+      while (!stack.empty()) {
+        auto [node, phase] = stack.back();
+        stack.pop_back();
+        if (new_id[node] >= 0) continue;
+        const hamk_op& o = ops_[node];
+        const int nk = kids(o);
+        if (phase == 0) {
+          stack.push_back({node, 1});
+          if (nk == 2 && new_id[o.b] < 0) stack.push_back({o.b, 0});
+          if (nk >= 1 && new_id[o.a] < 0) stack.push_back({o.a, 0});
+        } else {
+          hamk_op c = o;
+          if (nk >= 1) c.a = new_id[o.a];
+          if (nk == 2) c.b = new_id[o.b];
+          new_id[node] = (int32_t)out.size();
+          out.push_back(c);
+        }
+      }
+    }
+    for (int32_t& r : outs) r = new_id[r];
+    return out;
+  }
 
  private:
   static uint64_t bits(double c) { uint64_t u; std::memcpy(&u, &c, 8); return u; }
@@ -100,6 +138,14 @@ inline double powi(double x, int k) {
   while (k) { if (k & 1) r *= b; b *= b; k >>= 1; }
   return r;
 }
+inline Var neg(const Var& a) {                      // -c folds, -(-x) = x
+  double c;
+  if (a.is_const(&c)) return Var(-c);
+  Tape* t = a.tape();
+  const hamk_op& o = t->ops()[a.id_on(t)];
+  if (o.op == HAMK_OP_NEG) return Var(t, o.a);
+  return Var(t, t->emit(HAMK_OP_NEG, a.id_on(t)));
+}
 inline Var binary(int32_t op, const Var& a, const Var& b) {
   double ca = 0.0, cb = 0.0;
   const bool ka = a.is_const(&ca), kb = b.is_const(&cb);
@@ -114,20 +160,19 @@ inline Var binary(int32_t op, const Var& a, const Var& b) {
   Tape* t = tape_of(a, b);
   // exact identities only: never change a result bit
   if (op == HAMK_OP_ADD) { if (ka && ca == 0.0) return b; if (kb && cb == 0.0) return a; }
-  if (op == HAMK_OP_SUB) { if (kb && cb == 0.0) return a; if (ka && ca == 0.0) return Var(t, t->emit(HAMK_OP_NEG, b.id_on(t))); }
+  if (op == HAMK_OP_SUB) { if (kb && cb == 0.0) return a; if (ka && ca == 0.0) return neg(b); }
   if (op == HAMK_OP_MUL) {
     if (ka && ca == 1.0) return b;
     if (kb && cb == 1.0) return a;
-    if (ka && ca == -1.0) return Var(t, t->emit(HAMK_OP_NEG, b.id_on(t)));
-    if (kb && cb == -1.0) return Var(t, t->emit(HAMK_OP_NEG, a.id_on(t)));
+    if (ka && ca == -1.0) return neg(b);
+    if (kb && cb == -1.0) return neg(a);
   }
   if (op == HAMK_OP_DIV) {
     if (kb && cb == 1.0) return a;
     if (ka && ca == 1.0) return Var(t, t->emit(HAMK_OP_RECIP, b.id_on(t)));
   }
-  int32_t ia = a.id_on(t), ib = b.id_on(t);
-  if ((op == HAMK_OP_ADD || op == HAMK_OP_MUL) && ia > ib) std::swap(ia, ib);
-  return Var(t, t->emit(op, ia, ib));
+  const int32_t ia = a.id_on(t), ib = b.id_on(t);   // operands in the order written: the tape is a function of
+  return Var(t, t->emit(op, ia, ib));               // the expression alone (see canonical())
 }
 inline Var unary(int32_t op, const Var& x, double (*f)(double)) {
   double c;
@@ -140,7 +185,7 @@ inline Var operator+(const Var& a, const Var& b) { return detail::binary(HAMK_OP
 inline Var operator-(const Var& a, const Var& b) { return detail::binary(HAMK_OP_SUB, a, b); }
 inline Var operator*(const Var& a, const Var& b) { return detail::binary(HAMK_OP_MUL, a, b); }
 inline Var operator/(const Var& a, const Var& b) { return detail::binary(HAMK_OP_DIV, a, b); }
-inline Var operator-(const Var& a) { return detail::binary(HAMK_OP_SUB, Var(0.0), a); }
+inline Var operator-(const Var& a) { return detail::neg(a); }
 inline Var operator+(const Var& a) { return a; }
 
 #define HAMILTON_UNARY(name, OP) \
@@ -223,13 +268,20 @@ class System {
       : m_(m), n_(n) {
     if ((int)inertia.size() != m) throw std::invalid_argument("inertia must have m entries");
     Tape tf(n), tu(u_space == HAMK_U_CARTESIAN ? m : n);
-    std::vector<int32_t> f_outs = record(tf, n, [&](const std::vector<Var>& q) { return f(q); }, m);
-    std::vector<int32_t> u_outs = record(tu, tu.n_in(), [&](const std::vector<Var>& z) { return std::vector<Var>{u(z)}; }, 1);
+    f_outs_ = record(tf, n, [&](const std::vector<Var>& q) { return f(q); }, m);
+    u_outs_ = record(tu, tu.n_in(), [&](const std::vector<Var>& z) { return std::vector<Var>{u(z)}; }, 1);
+    f_ops_ = tf.canonical(f_outs_);
+    u_ops_ = tu.canonical(u_outs_);
     hamk_system* h = nullptr;
-    check(hamk_system_create(m, n, inertia.data(), tf.ops().data(), (int32_t)tf.ops().size(), f_outs.data(),
-                             tu.ops().data(), (int32_t)tu.ops().size(), u_outs[0], u_space, &h));
+    check(hamk_system_create(m, n, inertia.data(), f_ops_.data(), (int32_t)f_ops_.size(), f_outs_.data(),
+                             u_ops_.data(), (int32_t)u_ops_.size(), u_outs_[0], u_space, &h));
     h_.reset(h, hamk_system_destroy);
   }
+  // the tapes that crossed the ABI (canonical form)
+  const std::vector<hamk_op>& f_tape() const { return f_ops_; }
+  const std::vector<int32_t>& f_outs() const { return f_outs_; }
+  const std::vector<hamk_op>& u_tape() const { return u_ops_; }
+  const std::vector<int32_t>& u_outs() const { return u_outs_; }
   int m() const { return m_; }
   int n() const { return n_; }
   hamk_system* handle() const { return h_.get(); }
@@ -247,6 +299,8 @@ class System {
     return ids;
   }
   int m_, n_;
+  std::vector<hamk_op> f_ops_, u_ops_;
+  std::vector<int32_t> f_outs_, u_outs_;
   std::shared_ptr<hamk_system> h_;
 };
 
@@ -428,7 +482,7 @@ inline void setGslApi(System& s, int api) { check(hamk_system_set_gsl_api(s.hand
 inline int gslApi(const System& s) { return hamk_system_get_gsl_api(s.handle()); }
 
 // Ensemble checkpoint / resume: the device-resident state to one flat file
-// and back; a run cut at a multiple of 16 steps continues bit-identically (hamk.h)
+// and back; a resumed run continues bit-identically (hamk.h)
 struct CheckpointInfo { int32_t n = 0; int64_t B = 0, steps_done = 0; uint64_t seed = 0; double t = 0.0; };
 inline void saveCheckpoint(const std::string& path, const System& s, const DevicePhase& d, int64_t steps_done, uint64_t seed, double t) {
   check(hamk_synchronize(s.handle()));

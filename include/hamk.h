@@ -277,10 +277,7 @@ int hamk_gather_batch(int32_t nparts, int32_t n, const int64_t* B_parts, const d
  * is staged in 8 MiB pieces.  Written aside and renamed: a crash leaves the previous file.
  * steps_done / seed / t are the caller's bookkeeping (per-index splitmix64 seed of the initial
  * conditions, steps taken, model time) and come back from hamk_checkpoint_info.  Every kernel is a
- * pure function of the state, so a resumed run continues bit-identically -- for hamk_rk4_steps when
- * the cut falls on a multiple of 16 steps (each launch starts its sincos anchor chain afresh and
- * re-anchors every 16 steps; a cut elsewhere continues to rounding, not bitwise; HAMK_TRIG_CHAIN=1
- * turns chaining off), for stepHam / evolveHam at any output time.                              */
+ * pure function of the state, so a resumed run continues bit-identically.                         */
 int hamk_checkpoint_write(const char* path, int32_t n, int64_t B, const double* q, const double* p,
                           int32_t mem, int64_t steps_done, uint64_t seed, double t);
 int hamk_checkpoint_info(const char* path, int32_t* n, int64_t* B, int64_t* steps_done,

@@ -157,15 +157,14 @@ def rk4_step_stats(spec, system=None):
       -DHAMK_PROBE_NO_SLOWPATH  removes the bodies of the rare branches (library sin/cos for
                                 |x| >= 1.6e6 or NaN, far-from-anchor re-evaluation, ...: ~2000
                                 instructions inside the stepping loop that are never executed);
-      -DHAMK_PROBE_TRIG=m       fixes the wave-uniform sincos mode of EVERY evaluation at compile time
-                                (m = 0 full anchor, 1 chained wide, 2 narrow, 3 short), so the sides
-                                of that scalar switch are not all counted.
-    The hottest loop is one step (unrolled body: four evaluations) or one stage (stage-loop / wave
-    bodies: one).  With L(m) the loop's count in mode m, a step -- stage modes narrow, chain (full on
-    every K-th step), short, narrow -- costs
-      stage loop  2 L(2) + L(3) + L(1) (1 - 1/K) + L(0) / K
-      unrolled    the same combination of L(m) / 4 ... plus nothing: L(m) = base + 4 t(m) is linear in
-                  the per-evaluation sincos cost t(m), so the combination weights are the same / 4
+      -DHAMK_PROBE_TRIG=m       (stage-loop bodies only) fixes the wave-uniform sincos mode of the
+                                loop's one evaluation at compile time (m = 0 full anchor, 1 narrow
+                                rotation + new anchor, 2 narrow, 3 short), so the sides of that scalar
+                                switch are not all counted.
+    The hottest loop is one step (unrolled body: the four stage modes are compile-time constants
+    there) or one stage (stage-loop / wave bodies).  A step costs
+      unrolled    L                                  L: the loop
+      stage loop  L(0) + L(1) + L(2) + L(3)          L(m): the loop with the sincos mode fixed to m
     Cross-check: PMC SQ_INSTS_VALU per wave per step (profiles/*_summary.json).
     Returns None when llvm-objdump is unavailable."""
     if not os.path.exists(OBJDUMP):
@@ -176,13 +175,10 @@ def rk4_step_stats(spec, system=None):
     src = system.source
     wave = "HAMK_INSTANTIATE_WAVE" in src
     stage_loop = "RK4_STAGE_LOOP = true" in src or wave
-    m = re.search(r"#define HAMK_TRIG_CHAIN_K (\d+)", src)
-    K = int(m.group(1)) if m else 16
     m = re.search(r"NTRIG_F = (\d+)", src)
     chained = (not wave) and m is not None and 1 <= int(m.group(1)) <= 4          # hamk_device.hpp StageTrig
     base_env = {"HAMK_RK4_LOOP": "1" if "RK4_STAGE_LOOP = true" in src else "0", "HAMK_WAVE": "1" if wave else "0",
-                "HAMK_AD_MODE": "H" if "MODE_H = true" in src else ("R" if "MODE_R = true" in src else "D"),
-                "HAMK_TRIG_CHAIN": str(K)}
+                "HAMK_AD_MODE": "H" if "MODE_H = true" in src else ("R" if "MODE_R = true" in src else "D")}
 
     def count(trig):
         flags = (os.environ.get("HAMK_HIPRTC_FLAGS", "") + " -DHAMK_PROBE_NO_SLOWPATH").strip()
@@ -210,13 +206,12 @@ def rk4_step_stats(spec, system=None):
                 "mfma": sum(1 for _, mn, _ in ins[lo:hi + 1] if mn.startswith("v_mfma")),
                 "lds": st["histogram"].get("lds", 0), "scratch": st["histogram"].get("scratch", 0)}
 
-    if chained:
+    if chained and stage_loop:
         L = [count(m) for m in (0, 1, 2, 3)]
         if any(x is None for x in L):
             return None
-        scale = 1.0 if stage_loop else 0.25
-        w = {k: scale * (2 * L[2][k] + L[3][k] + L[1][k] * (1.0 - 1.0 / K) + L[0][k] / K) for k in L[0]}
-        detail = {"loop_all_full_anchor": L[0], "loop_all_chain_wide": L[1], "loop_all_narrow": L[2], "loop_all_short": L[3], "chain_K": K}
+        w = {k: sum(x[k] for x in L) for k in L[0]}
+        detail = {"loop_full_anchor": L[0], "loop_narrow_anchor": L[1], "loop_narrow": L[2], "loop_short": L[3]}
     else:
         A = count(None)
         if A is None:

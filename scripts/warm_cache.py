@@ -31,9 +31,6 @@ def jobs():
                 if loop:
                     env["HAMK_RK4_LOOP"] = loop
                 out.append((n, env, False))
-    for n in ("doublePendulum", "twoBody", "spring", "threeBodyPolar", "pendulum"):
-        for k in ("1", "4", "64"):
-            out.append((n, {"HAMK_TRIG_CHAIN": k}, True))
     for seed in range(16):
         out.append((f"random{seed}", {}, False))
     return out

@@ -23,18 +23,19 @@ void emu_sincos_incr_range(const double* xa, const double* d, int range, double*
     else hamk::sincos_incr<hamk::INCR_SHORT>(xa[i] + d[i], xa[i], sa, ca, s[i], c[i]);
   }
 }
-// a chain of `len` anchor rotations through the library's own TRIG_DYN logic: full anchor at x0, then
-// x0 + d, x0 + 2 d, ... each obtained by rotating the previous anchor (which it then replaces);
-// s, c: the pair after the last rotation
-void emu_sincos_chain(const double* x0, const double* d, int len, double* s, double* c, long long n) {
+// the four evaluations of one RK4 step through the library's own TRIG_DYN logic: full anchor at x,
+// narrow rotation to x + d1 (becomes the anchor), short rotation to x + d1 + d2, narrow rotation to
+// x + d1 + d3; s[4], c[4] per point
+void emu_sincos_step(const double* x, const double* d1, const double* d2, const double* d3, double* s, double* c, long long n) {
   for (long long i = 0; i < n; ++i) {
     hamk::TrigCache<1> tc;
-    tc.mode = hamk::DYN_FULL_ANCHOR;
-    double x = x0[i];
-    hamk::trig_pair<hamk::TRIG_DYN>(x, tc, 0);
-    tc.mode = hamk::DYN_CHAIN;
-    for (int k = 0; k < len; ++k) { x += d[i]; hamk::trig_pair<hamk::TRIG_DYN>(x, tc, 0); }
-    s[i] = tc.s[0]; c[i] = tc.c[0];
+    const double pts[4] = {x[i], x[i] + d1[i], x[i] + d1[i] + d2[i], x[i] + d1[i] + d3[i]};
+    const int modes[4] = {hamk::DYN_FULL_ANCHOR, hamk::DYN_NARROW_ANCHOR, hamk::DYN_SHORT, hamk::DYN_NARROW};
+    for (int k = 0; k < 4; ++k) {
+      tc.mode = modes[k];
+      hamk::trig_pair<hamk::TRIG_DYN>(pts[k], tc, 0);
+      s[4 * i + k] = tc.s[0]; c[4 * i + k] = tc.c[0];
+    }
   }
 }
 void emu_frcp(const double* x, double* r, long long n) { for (long long i = 0; i < n; ++i) r[i] = hamk::frcp(x[i]); }

@@ -110,4 +110,4 @@ def test_c_client_runs_on_gpu(c_binary):
     out = subprocess.check_output([c_binary, "run"], text=True)
     m = re.search(r"hamEqs dq = (\S+) dp = (\S+) status = (\S+)", out)
     dq, dp, st = float(m.group(1)), float(m.group(2)), int(m.group(3))
-    assert st == 0 and abs(dq) < 1e-16 and abs(dp + 5.0 * math.sin(0.3)) < 1e-14   # K = 1: dq = p, dp = -dU/dtheta
+    assert st == 0 and abs(dq) < 1e-16 and abs(dp + math.sin(0.3)) < 1e-14         # K = 1: dq = p, dp = -dU/dtheta

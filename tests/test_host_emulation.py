@@ -205,30 +205,29 @@ def test_device_rkf45_step_is_fifth_order(emulate, oracle_lib):
     assert ratios and all(40 < r < 100 for r in ratios), (errs, ratios)
 
 
-@pytest.mark.parametrize("name,loop", [("doublePendulum", "0"), ("doublePendulum", "1"), ("twoBody", "0"), ("threeBodyPolar", "1")])
-def test_chained_anchors_over_many_steps_on_host(emulate, oracle_lib, name, loop):
-    """Fixed-step loops with chained sincos anchors (a full re-anchor every 16 steps): 40 RK4 steps --
-    two full chains and a half -- against the oracle, unrolled and stage-loop bodies; and against the
-    same kernel with chaining off (HAMK_TRIG_CHAIN=1): the two differ by rounding only."""
+@pytest.mark.parametrize("name,loop", [("doublePendulum", "0"), ("doublePendulum", "1"), ("twoBody", "0"), ("spring", "0"), ("threeBodyPolar", "1")])
+def test_fixed_step_loop_over_many_steps_on_host(emulate, oracle_lib, name, loop):
+    """The RK4 loops with the sincos anchor at each step's midpoint, unrolled and stage-loop bodies:
+    40 steps against the oracle -- and a step is a pure function of the state: 40 steps in one launch
+    and in launches of 25 + 15 are the same bits (no anchor crosses a step)."""
     spec = E.get(name)
     o = oracle_lib.OracleSystem(spec)
     B = 64
     q, qd = E.sample_config(spec, 17, B)
     p = o.to_phase_batch(q, qd)
     oq, op = o.rk4_steps_batch(q, p, spec.dt, 40)
-    res = {}
-    for k in ("16", "1"):                                     # 1: a full evaluation at every step's midpoint
-        L, src = emulate(spec, {"HAMK_TRIG_CHAIN": k, "HAMK_RK4_LOOP": loop})
-        assert ("HAMK_TRIG_CHAIN_K 1" in src) == (k == "1") and ("RK4_STAGE_LOOP = true" in src) == (loop == "1")
-        q2, p2, st = q.copy(), p.copy(), np.zeros(B, np.int32)
-        L.emu_rk4(P(q2), P(p2), LL(B), ctypes.c_double(spec.dt), 40, I(st))
-        assert not st.any()
-        res[k] = (q2, p2)
-        err = np.maximum(np.abs(q2 - oq).max(0), np.abs(p2 - op).max(0))
-        calm = np.abs(op).max(0) < 50                         # twoBody: members on their way into a close encounter
-        assert calm.mean() > 0.8 and float(err[calm].max()) < 2e-11, (name, k, float(err[calm].max()))
-    d = max(np.abs(res["16"][0] - res["1"][0])[:, calm].max(), np.abs(res["16"][1] - res["1"][1])[:, calm].max())
-    assert 0 < d < 1e-11, d
+    L, src = emulate(spec, {"HAMK_RK4_LOOP": loop})
+    assert ("RK4_STAGE_LOOP = true" in src) == (loop == "1")
+    q2, p2, st = q.copy(), p.copy(), np.zeros(B, np.int32)
+    L.emu_rk4(P(q2), P(p2), LL(B), ctypes.c_double(spec.dt), 40, I(st))
+    assert not st.any()
+    err = np.maximum(np.abs(q2 - oq).max(0), np.abs(p2 - op).max(0))
+    calm = np.abs(op).max(0) < 50                             # twoBody: members on their way into a close encounter
+    assert calm.mean() > 0.8 and float(err[calm].max()) < 2e-11, (name, float(err[calm].max()))
+    q3, p3 = q.copy(), p.copy()
+    L.emu_rk4(P(q3), P(p3), LL(B), ctypes.c_double(spec.dt), 25, I(st))
+    L.emu_rk4(P(q3), P(p3), LL(B), ctypes.c_double(spec.dt), 15, I(st))
+    assert np.array_equal(q3, q2) and np.array_equal(p3, p2)
 
 
 @pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS)
@@ -348,28 +347,24 @@ def test_rotation_ranges(elementary):
         assert es < 3.0e-16 and ec < 3.0e-16, (rid, es, ec)
 
 
-def test_chained_sincos_accuracy(elementary):
-    """TRIG_DYN chains (hamk_device.hpp): the anchor of step k+1 is the anchor of step k rotated by
-    delta = dt * qd; a full evaluation every HAMK_TRIG_CHAIN_K = 16 steps bounds the chain at 15
-    rotations.  Against 80-bit long double over 1e6 chains with |delta| up to 0.249: the error after a
-    full-length chain stays within a few ulp (worst case linear in the length, typically ~sqrt) --
-    below the rounding the integrated angle itself collects over the same 15 steps."""
+def test_midpoint_anchored_sincos_accuracy(elementary):
+    """The four sincos evaluations of one RK4 step as the fixed-step loops make them (TRIG_DYN in
+    hamk_device.hpp): full at y, narrow rotation to the midpoint (new anchor), short and narrow
+    rotations from there -- against 80-bit long double over 1e6 steps with stage offsets up to the
+    ranges' limits and a little beyond (lanes beyond a range re-evaluate in full): every pair within a
+    few 1e-16, i.e. two rotations cost about one ulp."""
     rng = np.random.default_rng(11)
     n = 1_000_000
-    x0 = rng.uniform(-50, 50, n)
-    d = rng.uniform(-0.249, 0.249, n)
-    s, c = np.zeros(n), np.zeros(n)
-    worst = {}
-    for length in (1, 15, 63):
-        elementary.emu_sincos_chain(P(x0), P(d), length, P(s), P(c), LL(n))
-        x = x0.copy()
-        for _ in range(length):
-            x += d                                           # the same fp64 accumulation the chain saw
-        xl = x.astype(np.longdouble)
-        es, ec = np.abs(s - np.sin(xl)), np.abs(c - np.cos(xl))
-        worst[length] = (float(max(es.max(), ec.max())), float(np.sqrt(np.mean(es.astype(np.float64) ** 2))))
-    assert worst[1][0] < 4e-16 and worst[15][0] < 1.5e-15 and worst[15][1] < 4e-16, worst
-    assert worst[63][0] < 5e-15, worst                       # a 4x longer chain than the library uses
+    x = rng.uniform(-50, 50, n)
+    d1 = rng.uniform(-0.14, 0.14, n)
+    d2 = rng.uniform(-0.035, 0.035, n)
+    d3 = rng.uniform(-0.14, 0.14, n)
+    s, c = np.zeros(4 * n), np.zeros(4 * n)
+    elementary.emu_sincos_step(P(x), P(d1), P(d2), P(d3), P(s), P(c), LL(n))
+    pts = np.stack([x, x + d1, x + d1 + d2, x + d1 + d3], axis=1).reshape(-1).astype(np.longdouble)
+    es, ec = np.abs(s - np.sin(pts)).reshape(n, 4), np.abs(c - np.cos(pts)).reshape(n, 4)
+    worst = [float(max(es[:, k].max(), ec[:, k].max())) for k in range(4)]
+    assert worst[0] < 2.0e-16 and worst[1] < 3.0e-16 and worst[2] < 4.5e-16 and worst[3] < 4.5e-16, worst
 
 
 def test_reciprocal_and_controller_power(elementary):

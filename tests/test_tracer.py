@@ -29,7 +29,8 @@ def test_constant_folding_and_identities():
     c = t.const(2.0) * 3 + 1
     assert t.const_value(c.idx) == 7.0
     assert (-(-x)).idx == x.idx
-    assert (x + 1).idx == (1 + x).idx          # commutative ops are hash-consed
+    assert (x + 1).idx == (x + 1).idx           # identical subexpressions are hash-consed ...
+    assert (x + 1).idx != (1 + x).idx           # ... operands stay in the order written (the tape is a function of the expression)
 
 
 def test_power_rules():
