@@ -23,6 +23,12 @@
 --     pair of storable vectors in structure-of-arrays order (q[j*B + i]).
 --   * comparisons on 'Traced' ('Ord', 'RealFrac', 'isNaN', ...) throw
 --     'UntraceableFunction': such systems keep the pure ad+hmatrix closures.
+--   * what crosses the ABI is the CANONICAL form of the recording ('canonical': only the
+--     values the outputs depend on, numbered depth-first post-order from the outputs) with
+--     the folding rules of the other host shims (hamilton_amd/tracer.py, include/hamilton.hpp):
+--     a function of the expression alone -- independent of the order in which lazy
+--     evaluation happened to force the recording -- and therefore byte-identical to what
+--     the Python and C++ shims send for the same system (tests/test_recorders.py there).
 module Numeric.Hamilton.HIP
   ( HipSystem
   , traceSystem
@@ -44,6 +50,16 @@ module Numeric.Hamilton.HIP
   , stepHamDevice
   , synchronize
   , gatherEnsembles
+    -- * which GSL binding of hmatrix-gsl 'stepHam' / 'evolveHam' reproduce (hamk.h)
+  , GslApi (..)
+  , setGslApi
+    -- * fixed-step launches that check their own energy invariant; ensemble checkpoints
+  , rk4StepsCheckedDevice
+  , statusDrift
+  , saveCheckpoint
+  , loadCheckpoint
+  , CheckpointInfo (..)
+  , checkpointInfo
   , UntraceableFunction (..)
   ) where
 
@@ -51,6 +67,11 @@ import Control.Exception
 import Control.Monad
 import Data.IORef
 import Data.Int
+import Data.Word
+import qualified Data.Map.Strict as M
+import qualified Data.Sequence as Seq
+import Data.Foldable (toList)
+import GHC.Float (castDoubleToWord64)
 import qualified Data.Vector.Sized as V
 import qualified Data.Vector.Storable as VS
 import qualified Data.Vector.Storable.Mutable as VSM
@@ -112,6 +133,16 @@ foreign import ccall safe "hamk_memcpy"
   c_memcpy :: Ptr Double -> Ptr Double -> Int64 -> Int32 -> IO CInt
 foreign import ccall safe "hamk_gather_batch"
   c_gather :: Int32 -> Int32 -> Ptr Int64 -> Ptr (Ptr Double) -> Ptr Double -> Int32 -> IO CInt
+foreign import ccall unsafe "hamk_system_set_gsl_api"
+  c_set_gsl_api :: Ptr HamkSystem -> Int32 -> IO CInt
+foreign import ccall safe "hamk_rk4_steps_checked"
+  c_rk4_steps_checked :: Ptr HamkSystem -> Int64 -> Ptr Double -> Ptr Double -> Double -> Int32 -> Double -> Ptr Int32 -> Int32 -> IO CInt
+foreign import ccall safe "hamk_checkpoint_write"
+  c_ck_write :: CString -> Int32 -> Int64 -> Ptr Double -> Ptr Double -> Int32 -> Int64 -> Word64 -> Double -> IO CInt
+foreign import ccall safe "hamk_checkpoint_info"
+  c_ck_info :: CString -> Ptr Int32 -> Ptr Int64 -> Ptr Int64 -> Ptr Word64 -> Ptr Double -> IO CInt
+foreign import ccall safe "hamk_checkpoint_read"
+  c_ck_read :: CString -> Int32 -> Int64 -> Ptr Double -> Ptr Double -> Int32 -> IO CInt
 
 memHost, memDevice :: Int32
 memHost = 0
@@ -130,7 +161,11 @@ data UntraceableFunction = UntraceableFunction String deriving Show
 instance Exception UntraceableFunction
 
 -- | A traced value: either a late-bound constant or the id of a tape value.
-data Traced = K !Double | T !(IORef [Op]) !Int32
+data Traced = K !Double | T !(IORef TapeSt) !Int32
+
+-- the recording so far: ops in emission order + the hash-consing table (identical
+-- subexpressions share one value)
+data TapeSt = TapeSt !(Seq.Seq Op) !(M.Map (Int32, Int32, Int32, Word64) Int32)
 
 opConst, opInput, opAdd, opSub, opMul, opDiv, opNeg, opRecip, opSin, opCos, opTan, opAsin, opAcos,
   opAtan, opSinh, opCosh, opTanh, opExp, opLog, opSqrt, opPowC, opPowI, opPow, opAtan2, opAsinh,
@@ -139,24 +174,64 @@ opConst, opInput, opAdd, opSub, opMul, opDiv, opNeg, opRecip, opSin, opCos, opTa
   , opAtan, opSinh, opCosh, opTanh, opExp, opLog, opSqrt, opPowC, opPowI, opPow, opAtan2, opAsinh
   , opAcosh, opAtanh ] = [0 .. 26]
 
-emit :: IORef [Op] -> Op -> Int32
-emit ref o = unsafePerformIO $ atomicModifyIORef' ref $ \ops -> (ops ++ [o], fromIntegral (length ops))
+emit :: IORef TapeSt -> Op -> Int32
+emit ref o@(Op c a b d) = unsafePerformIO $ atomicModifyIORef' ref $ \st@(TapeSt ops memo) ->
+  let key = (c, a, b, castDoubleToWord64 d)
+  in case M.lookup key memo of
+       Just i -> (st, i)
+       Nothing -> let i = fromIntegral (Seq.length ops) in (TapeSt (ops Seq.|> o) (M.insert key i memo), i)
 {-# NOINLINE emit #-}
 
-onTape :: IORef [Op] -> Traced -> Int32
+opAt :: IORef TapeSt -> Int32 -> Op
+opAt ref i = unsafePerformIO $ do TapeSt ops _ <- readIORef ref; return (Seq.index ops (fromIntegral i))
+{-# NOINLINE opAt #-}
+
+onTape :: IORef TapeSt -> Traced -> Int32
 onTape ref (K c) = emit ref (Op opConst 0 0 c)
 onTape _ (T _ i) = i
 
+tapeOf :: Traced -> Traced -> IORef TapeSt
+tapeOf (T r _) _ = r
+tapeOf _ (T r _) = r
+tapeOf _ _ = error "Numeric.Hamilton.HIP: two constants have no tape"
+
+-- -c folds, -(-x) = x
+neg :: Traced -> Traced
+neg (K c) = K (negate c)
+neg (T r i) = case opAt r i of
+  Op o a _ _ | o == opNeg -> T r a
+  _ -> T r (emit r (Op opNeg i 0 0))
+
+-- constants fold; the exact identities (x+0, 0+x, x-0, 0-x, x*1, 1*x, x*(-1), (-1)*x, x/1, 1/x) are
+-- applied -- never anything that could change a result bit; operands stay in the order written
 bin :: Int32 -> (Double -> Double -> Double) -> Traced -> Traced -> Traced
 bin _ f (K a) (K b) = K (f a b)
-bin o _ a b = let ref = tapeOf a b in T ref (emit ref (Op o (onTape ref a) (onTape ref b) 0))
-  where tapeOf (T r _) _ = r
-        tapeOf _ (T r _) = r
-        tapeOf _ _ = error "unreachable"
+bin o _ a b
+  | o == opAdd, K 0 <- a = b
+  | o == opAdd, K 0 <- b = a
+  | o == opSub, K 0 <- b = a
+  | o == opSub, K 0 <- a = neg b
+  | o == opMul, K 1 <- a = b
+  | o == opMul, K 1 <- b = a
+  | o == opMul, K (-1) <- a = neg b
+  | o == opMul, K (-1) <- b = neg a
+  | o == opDiv, K 1 <- b = a
+  | o == opDiv, K 1 <- a = let r = tapeOf a b in T r (emit r (Op opRecip (onTape r b) 0 0))
+  | otherwise = let r = tapeOf a b
+                    ia = onTape r a          -- first operand first: same emission order as the other shims
+                    ib = ia `seq` onTape r b
+                in T r (emit r (Op o ia ib 0))
 
 un :: Int32 -> (Double -> Double) -> Traced -> Traced
 un _ f (K a) = K (f a)
 un o _ (T r i) = T r (emit r (Op o i 0 0))
+
+-- x ^ k of the other shims (`powi`): k = 0 folds to 1, k = 1 to x
+powI :: Traced -> Int -> Traced
+powI (K c) k = K (c ^^ k)
+powI _ 0 = K 1
+powI x 1 = x
+powI (T r i) k = T r (emit r (Op opPowI i (fromIntegral k) 0))
 
 untraceable :: String -> a
 untraceable = throw . UntraceableFunction
@@ -165,7 +240,7 @@ instance Num Traced where
   (+) = bin opAdd (+)
   (-) = bin opSub (-)
   (*) = bin opMul (*)
-  negate = un opNeg negate
+  negate = neg
   abs _ = untraceable "abs"
   signum _ = untraceable "signum"
   fromInteger = K . fromInteger
@@ -184,7 +259,7 @@ instance Floating Traced where
   asinh = un opAsinh asinh; acosh = un opAcosh acosh; atanh = un opAtanh atanh
   K a ** K b = K (a ** b)
   x@(T r i) ** K c
-    | c == fromIntegral (round c :: Int) && abs c <= 64 = T r (emit r (Op opPowI i (round c) 0))  -- x ** 2 with x < 0 (Examples.hs:154)
+    | c == fromIntegral (round c :: Int) && abs c <= 64 = powI x (round c)     -- x ** 2 with x < 0 (Examples.hs:154)
     | otherwise = T r (emit r (Op opPowC i 0 c))
   a ** b = bin opPow (**) a b
 
@@ -208,12 +283,34 @@ data HipSystem (m :: Nat) (n :: Nat) = HipSystem !(ForeignPtr HamkSystem)
 
 record :: Int -> ([Traced] -> [Traced]) -> IO ([Op], [Int32])
 record nIn fn = do
-  ref <- newIORef []
+  ref <- newIORef (TapeSt Seq.empty M.empty)
   let ins = [T ref (emit ref (Op opInput (fromIntegral j) 0 0)) | j <- [0 .. nIn - 1]]
-  outs <- evaluate (map (onTape ref) (fn ins))
-  mapM_ evaluate outs
-  ops <- readIORef ref
-  return (ops, outs)
+  mapM_ (\(T _ i) -> evaluate i) ins
+  outs <- mapM (evaluate . onTape ref) (fn ins)
+  TapeSt ops _ <- readIORef ref
+  return (canonical (toList ops) outs)
+
+-- | Canonical form of a recording: only the values the outputs depend on, numbered depth-first
+--   post-order from the outputs (first operand before second, outputs in order).  The same
+--   function as @Tape.canonical@ (hamilton_amd/tracer.py) and @Tape::canonical@ (include/hamilton.hpp).
+canonical :: [Op] -> [Int32] -> ([Op], [Int32])
+canonical ops outs = (reverse rev, map (newId M.!) outs)
+  where
+    arr = Seq.fromList ops
+    kids (Op o a b _)
+      | o == opConst || o == opInput = []
+      | o `elem` [opAdd, opSub, opMul, opDiv, opPow, opAtan2] = [a, b]
+      | otherwise = [a]
+    (newId, rev, _) = foldl visit (M.empty, [], 0 :: Int32) outs
+    visit st@(seen, acc, next) node
+      | M.member node seen = st
+      | otherwise =
+          let o@(Op c a b d) = Seq.index arr (fromIntegral node)
+              ks = kids o
+              (seen', acc', next') = foldl visit (seen, acc, next) ks
+              a' = if null ks then a else seen' M.! a
+              b' = if length ks == 2 then seen' M.! b else b
+          in (M.insert node next' seen', Op c a' b' d : acc', next' + 1)
 
 create :: forall m n. (KnownNat m, KnownNat n)
        => Int32 -> [Double] -> ([Traced] -> [Traced]) -> ([Traced] -> Traced) -> IO (HipSystem m n)
@@ -389,3 +486,65 @@ gatherEnsembles parts = do
   q <- newOut (n * total); p <- newOut (n * total)
   one devPositions q; one devMomenta p
   Ensemble total <$> VS.unsafeFreeze q <*> VS.unsafeFreeze p
+
+-- ---------------------------------------------------------------------------
+-- which binding of hmatrix-gsl's gsl-ode.c the adaptive stepper reproduces
+-- ---------------------------------------------------------------------------
+-- | hmatrix-gsl's @gsl-ode.c@ carries two bindings: @gsl_odeiv2@ through
+--   @gsl_odeiv2_driver_apply@ (its default build, and this library's default) and the old
+--   @gsl_odeiv@ loop (@-DGSLODE1@).  They differ from the second output time of 'evolveHam' on
+--   (hamk.h: @hamk_system_set_gsl_api@).
+data GslApi = GslOdeiv1 | GslOdeiv2 deriving (Eq, Show)
+
+setGslApi :: HipSystem m n -> GslApi -> IO ()
+setGslApi (HipSystem h) api = withForeignPtr h $ \s ->
+  c_set_gsl_api s (if api == GslOdeiv1 then 1 else 2) >>= check "setGslApi"
+
+-- ---------------------------------------------------------------------------
+-- fixed-step launches that check their own invariant; checkpoints
+-- ---------------------------------------------------------------------------
+-- | HAMK_ST_DRIFT: the launch lost more than the given fraction of its energy.
+statusDrift :: Int32
+statusDrift = 16
+
+-- | As 'rk4StepsDevice', the launch checking H at entry and exit against @driftTol@; returns the
+--   per-trajectory status words (bit 'statusDrift' where the invariant was lost: a fixed step through
+--   a close encounter -- the reference's analogous failure raises out of @inv@, Hamilton.hs:321,381).
+rk4StepsCheckedDevice :: forall m n. KnownNat n => Double -> Int -> Double -> HipSystem m n -> DeviceEnsemble n -> IO (VS.Vector Int32)
+rk4StepsCheckedDevice dt k driftTol sys@(HipSystem h) (DeviceEnsemble b dq dp) = do
+  st <- VSM.new b
+  withForeignPtr h $ \s -> withForeignPtr dq $ \pq -> withForeignPtr dp $ \pp -> alloca $ \pd -> do
+    c_device_malloc pd (fromIntegral (4 * b)) >>= check "deviceMalloc"
+    dst <- peek pd
+    c_rk4_steps_checked s (fromIntegral b) pq pp dt (fromIntegral k) driftTol (castPtr dst) memDevice >>= check "rk4StepsChecked"
+    synchronize sys
+    VSM.unsafeWith st $ \ps -> c_memcpy (castPtr ps) dst (fromIntegral (4 * b)) 1 >>= check "download"
+    finalizeForeignPtr =<< newForeignPtr p_device_free dst
+  VS.unsafeFreeze st
+
+data CheckpointInfo = CheckpointInfo { ckN :: !Int, ckSize :: !Int, ckStepsDone :: !Int, ckSeed :: !Word64, ckTime :: !Double }
+  deriving Show
+
+-- | Dump a device-resident ensemble (plus the caller's bookkeeping) to one flat file; written aside
+--   and renamed.  A resumed run continues bit-identically (every kernel is a pure function of the state).
+saveCheckpoint :: forall m n. KnownNat n => FilePath -> HipSystem m n -> DeviceEnsemble n -> Int -> Word64 -> Double -> IO ()
+saveCheckpoint path sys (DeviceEnsemble b dq dp) stepsDone seed t = do
+  synchronize sys
+  withCString path $ \cp -> withForeignPtr dq $ \pq -> withForeignPtr dp $ \pp ->
+    c_ck_write cp (fromIntegral (natVal (Proxy @n))) (fromIntegral b) pq pp memDevice (fromIntegral stepsDone) seed t
+      >>= check "saveCheckpoint"
+
+checkpointInfo :: FilePath -> IO CheckpointInfo
+checkpointInfo path = withCString path $ \cp -> alloca $ \pn -> alloca $ \pb -> alloca $ \ps -> alloca $ \pz -> alloca $ \pt -> do
+  c_ck_info cp pn pb ps pz pt >>= check "checkpointInfo"
+  CheckpointInfo <$> (fromIntegral <$> peek pn) <*> (fromIntegral <$> peek pb) <*> (fromIntegral <$> peek ps) <*> peek pz <*> peek pt
+
+loadCheckpoint :: forall n. KnownNat n => FilePath -> IO (DeviceEnsemble n, CheckpointInfo)
+loadCheckpoint path = do
+  info <- checkpointInfo path
+  when (ckN info /= fromIntegral (natVal (Proxy @n))) $ throwIO (ErrorCall "loadCheckpoint: the file holds a system of another size")
+  let cnt = ckN info * ckSize info
+  dq <- deviceArray cnt; dp <- deviceArray cnt
+  withCString path $ \cp -> withForeignPtr dq $ \pq -> withForeignPtr dp $ \pp ->
+    c_ck_read cp (fromIntegral (ckN info)) (fromIntegral (ckSize info)) pq pp memDevice >>= check "loadCheckpoint"
+  return (DeviceEnsemble (ckSize info) dq dp, info)
