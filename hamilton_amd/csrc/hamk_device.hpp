@@ -380,6 +380,55 @@ template <int N> HAMK_DEV Jet1<N> operator/(double c, const Jet1<N>& b) { return
 template <int N> HAMK_DEV JetH<N> operator/(double c, const JetH<N>& b) { return scale(recip(b), c); }
 template <int N> HAMK_DEV Jet2<N> operator/(double c, const Jet2<N>& b) { return scale(recip(b), c); }
 
+// ---- sincos through a table in LDS ---------------------------------------------------------------
+// The stepping kernels evaluate sincos thousands of times per lane, always to full fp64 accuracy.
+// sincos_f64 above spends 42 instructions because it has nothing to start from; with the 512
+// pairs (sin, cos)(i 2pi/512) resident in LDS the same result takes 22: k = rint(x 512/2pi), a
+// three-FMA Cody-Waite reduction against 2pi/512 split into 26-bit pieces (k * piece exact for
+// |k| < 2^27, i.e. |x| < 1.6e6 as above), ONE 16-byte LDS gather of pair (k mod 512) and a
+// rotation by the remainder |r| <= pi/512 = 0.0061 with kernels through r^5 / r^6 (truncation
+// < 7e-20).  Error: the table entry (correctly rounded from 80-bit: <= 0.5 ulp) + the rotation's
+// rounding: <= ~2e-16 absolute, the same as sincos_f64 (tests/test_host_emulation.py).  No anchors,
+// no divergent re-evaluation: every stage of every step costs the same, and a step is a pure
+// function of the state.  The table is 8 KiB of LDS per block, copied in at kernel entry from the
+// module's constant data (hamk_trig_lut_init, emitted by hamk_codegen.cpp before this header).
+#define HAMK_LUT_N 512
+#ifndef HAMK_USE_LUT
+#define HAMK_USE_LUT 1
+#endif
+#ifdef HAMK_HOST_EMULATION
+#define HAMK_LUT hamk_trig_lut_init                     /* tests/host_emulation: plain memory */
+#else
+__shared__ double hamk_trig_lut[2 * HAMK_LUT_N];        /* allocated only in kernels that reach sincos_lut */
+#define HAMK_LUT hamk_trig_lut
+#endif
+// every thread of the block, before any thread leaves the kernel
+HAMK_DEV void lut_load() {
+#ifndef HAMK_HOST_EMULATION
+  for (int i = threadIdx.x; i < 2 * HAMK_LUT_N; i += blockDim.x) hamk_trig_lut[i] = hamk_trig_lut_init[i];
+  __syncthreads();
+#endif
+}
+HAMK_DEV void sincos_lut(double x, double& s, double& c) {
+  const double k = rint(x * 0x1.45f306dc9c883p+6);               // 512 / 2pi
+  double r = fma(-k, 0x1.921fb58p-7, x);                         // 2pi/512 bits  0..25
+  r = fma(-k, -0x1.dde974p-34, r);                               //              26..51
+  r = fma(-k, 0x1.1a62633145c07p-61, r);                         //              52..
+  const int idx = ((int)k) & (HAMK_LUT_N - 1);
+  const double sa = HAMK_LUT[2 * idx], ca = HAMK_LUT[2 * idx + 1];
+  const double z = r * r;
+  const double ps = fma(8.33333333333333321769e-03, z, -1.66666666666666657415e-01);
+  const double sd = fma(r * z, ps, r);                           // sin r
+  double pc = fma(-1.38888888888888894189e-03, z, 4.16666666666666643537e-02);
+  pc = fma(pc, z, -0.5);
+  const double cm1 = z * pc;                                     // cos r - 1
+  s = sa + fma(sa, cm1, ca * sd);
+  c = ca + fma(ca, cm1, -(sa * sd));
+#ifndef HAMK_PROBE_NO_SLOWPATH
+  if (!(fabs(x) < 1.6e6)) { s = ::sin(x); c = ::cos(x); }        // huge, NaN, Inf: library path
+#endif
+}
+
 // sin and cos of one argument always come as a pair (codegen fuses the tape's
 // SIN/COS of a shared operand): one fp64 sincos feeds value, gradient and Hessian.
 // The primal pair lives in a TrigCache slot, filled according to the sweep's TRIG mode:
@@ -413,7 +462,8 @@ template <int N> HAMK_DEV Jet2<N> operator/(double c, const Jet2<N>& b) { return
 //                (Chaining the anchor ACROSS steps -- stage 1 rotated from the previous midpoint, a full
 //                evaluation every K steps -- was built and measured: fewer instructions, no gain on
 //                MI355X, and it costs exactly that purity; profiles/r02_sweep_chain.jsonl.)
-enum : int { TRIG_FULL = 0, TRIG_REUSE = 1, TRIG_ANCHOR = 2, TRIG_INCR = 3, TRIG_DYN = 4 };
+//   TRIG_LUT     sincos_lut: the LDS table (stepping kernels, HAMK_USE_LUT); replaces the anchor modes
+enum : int { TRIG_FULL = 0, TRIG_REUSE = 1, TRIG_ANCHOR = 2, TRIG_INCR = 3, TRIG_DYN = 4, TRIG_LUT = 5 };
 enum : int { DYN_FULL_ANCHOR = 0, DYN_NARROW_ANCHOR = 1, DYN_NARROW = 2, DYN_SHORT = 3 };
 
 template <int NS> struct TrigCache {
@@ -481,6 +531,8 @@ HAMK_DEV void sincos_incr(double x, double xa, double sa, double ca, double& s, 
 template <int MODE, class TC> HAMK_DEV void trig_pair(double x, TC& tc, int k) {
   if constexpr (MODE == TRIG_FULL) {
     sincos_f64(x, tc.s[k], tc.c[k]);
+  } else if constexpr (MODE == TRIG_LUT) {
+    sincos_lut(x, tc.s[k], tc.c[k]);
   } else if constexpr (MODE == TRIG_ANCHOR) {
     sincos_f64(x, tc.s[k], tc.c[k]);
     tc.ax[k] = x; tc.as[k] = tc.s[k]; tc.ac[k] = tc.c[k];
@@ -897,14 +949,18 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
 // TRIG_INCR pays only where sincos is a large share of the right-hand side and the anchors fit
 // in registers; elsewhere the stage evaluations stay TRIG_FULL.
 template <class S> struct StageTrig {
+  // HAMK_USE_LUT: every sincos of the stepping kernels goes through the LDS table, whatever the number
+  // of sites.  Without it (kept for comparison, profiles/r02_sweep_trig.jsonl): the anchor scheme, which
+  // pays only where the anchors fit in registers (1-4 sites).
+  static constexpr bool lut = (HAMK_USE_LUT != 0) && (S::NTRIG_F >= 1);
 #ifdef HAMK_NO_INCR
   static constexpr bool on = false;
 #else
-  static constexpr bool on = (S::NTRIG_F >= 1 && S::NTRIG_F <= 4);
+  static constexpr bool on = !lut && (S::NTRIG_F >= 1 && S::NTRIG_F <= 4);
 #endif
-  static constexpr int anchor = on ? TRIG_ANCHOR : TRIG_FULL;
-  static constexpr int incr = on ? TRIG_INCR : TRIG_FULL;
-  static constexpr int dyn = on ? TRIG_DYN : TRIG_FULL;      // the fixed-step loops (anchor at the step's midpoint)
+  static constexpr int anchor = lut ? TRIG_LUT : (on ? TRIG_ANCHOR : TRIG_FULL);
+  static constexpr int incr = lut ? TRIG_LUT : (on ? TRIG_INCR : TRIG_FULL);
+  static constexpr int dyn = lut ? TRIG_LUT : (on ? TRIG_DYN : TRIG_FULL);   // the fixed-step loops
 };
 
 template <class S, int TRIG = TRIG_FULL>
@@ -956,6 +1012,7 @@ template <class S>
 HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, double dt, int nsteps, double drift_tol,
                        int* __restrict__ status) {
   constexpr int N = S::N, D = 2 * N;
+  if constexpr (StageTrig<S>::lut) lut_load();
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   double y[D];
@@ -1187,6 +1244,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
                          double eps_abs, double eps_rel, int row0, int inplace, int max_sub, int gsl_api,
                          int* __restrict__ status, int* __restrict__ nsub) {
   constexpr int N = S::N, D = 2 * N;
+  if constexpr (StageTrig<S>::lut) lut_load();
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const bool api2 = gsl_api != 1;
@@ -1264,7 +1322,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
             }
             break;
         }
-        rhs<S>(yt, out, st, tc);
+        rhs<S, StageTrig<S>::lut ? TRIG_LUT : TRIG_FULL>(yt, out, st, tc);
         switch (sg) {
           case 0:
 #pragma unroll

@@ -1,7 +1,7 @@
-"""GPU: the fixed-step kernels with chained sincos anchors (hamk_device.hpp TRIG_DYN): RK4 steps/s at
-BASELINE ensemble size for a full re-anchor every K = 1 (no chaining: round-1 behaviour), 4, 16, 64
-steps; and, for chain8, what the throughput depends on (fused steps per launch, the drift check).
-Output: one JSON line per measurement (profiles/r02_sweep_chain.jsonl)."""
+"""GPU: the fixed-step kernels with sincos through the LDS table (hamk_device.hpp sincos_lut, the
+default) against the anchor scheme it replaces (HAMK_TRIG_LUT=0: full evaluation + rotations about the
+step's midpoint for 1-4 sincos sites, full evaluations beyond): RK4 steps/s at BASELINE ensemble size.
+Output: one JSON line per measurement (profiles/r02_sweep_trig.jsonl)."""
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -39,13 +39,10 @@ def run(name, B, nsteps, env, drift_tol=0.0, reps=8):
 
 def variants():
     out = []
-    for name, B in (("doublePendulum", 1 << 20), ("twoBody", 1 << 20), ("spring", 1 << 20), ("threeBodyPolar", 1 << 18), ("pendulum", 1 << 20)):
-        out.append((name, B, 400, {}, 0.0, 8))
-        out.append((name, B, 400, {"HAMK_NOLICM": "0"}, 0.0, 8))              # every kernel from the default build
-        out.append((name, B, 400, {"HAMK_NOLICM": "1"}, 0.0, 8))              # ... from the build without MachineLICM
-    for nsteps in (50, 200):
-        out.append(("chain8", 1 << 16, nsteps, {}, 0.0, 12))
-    out.append(("chain16", 1 << 16, 50, {}, 0.0, 6))
+    for name, B, ns in (("doublePendulum", 1 << 20, 400), ("twoBody", 1 << 20, 400), ("spring", 1 << 20, 400), ("threeBodyPolar", 1 << 18, 400),
+                        ("pendulum", 1 << 20, 400), ("chain8", 1 << 16, 200), ("chain16", 1 << 16, 50)):
+        out.append((name, B, ns, {}, 0.0, 10))                                # sincos through the LDS table (default)
+        out.append((name, B, ns, {"HAMK_TRIG_LUT": "0"}, 0.0, 10))            # the anchor scheme (1-4 sites) / full evaluations
     return out
 
 

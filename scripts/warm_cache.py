@@ -31,6 +31,8 @@ def jobs():
                 if loop:
                     env["HAMK_RK4_LOOP"] = loop
                 out.append((n, env, False))
+    for n in ("doublePendulum", "twoBody", "spring", "threeBodyPolar", "pendulum", "chain8", "chain16"):
+        out.append((n, {"HAMK_TRIG_LUT": "0"}, False))
     for seed in range(16):
         out.append((f"random{seed}", {}, False))
     return out

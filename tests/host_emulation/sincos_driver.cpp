@@ -1,7 +1,17 @@
 // TEST INFRASTRUCTURE: exposes the library's own fp64 sincos routines (hamk_device.hpp) to the CPU
 // suite through the host shim.
+#include <cmath>
+static double hamk_trig_lut_init[1024];          // what hamk_codegen.cpp emits into every generated system
+namespace { struct LutInit { LutInit() {
+  for (int i = 0; i < 512; ++i) {
+    const long double a = (long double)i * (2.0L * 3.14159265358979323846264338327950288L / 512.0L);
+    hamk_trig_lut_init[2 * i] = (double)sinl(a); hamk_trig_lut_init[2 * i + 1] = (double)cosl(a);
+  } } } lut_init_; }
 #include "hamk_device.hpp"
 extern "C" {
+void emu_sincos_lut(const double* x, double* s, double* c, long long n) {
+  for (long long i = 0; i < n; ++i) hamk::sincos_lut(x[i], s[i], c[i]);
+}
 void emu_sincos(const double* x, double* s, double* c, long long n) {
   for (long long i = 0; i < n; ++i) hamk::sincos_f64(x[i], s[i], c[i]);
 }
