@@ -969,7 +969,7 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   s->desc.rk4_stage_loop = (n >= 7);
   if (const char* e = std::getenv("HAMK_RK4_LOOP")) s->desc.rk4_stage_loop = (e[0] == '1');
   if (const char* e = std::getenv("HAMK_RK4_WAVES")) s->desc.rk4_min_waves = std::atoi(e);
-  if (const char* e = std::getenv("HAMK_TRIG_LUT")) s->desc.use_lut = (e[0] != '0');      // experiments: 0 = the anchor scheme
+  if (const char* e = std::getenv("HAMK_TRIG_LUT")) { if (e[0] >= '0' && e[0] <= '2') s->desc.use_lut = e[0] - '0'; }   // experiments
   if (const char* e = std::getenv("HAMK_GSL_API")) s->gsl_api = (e[0] == '1') ? 1 : 2;
   s->desc.rkf_stage_loop = (n >= 4);
   if (const char* e = std::getenv("HAMK_RKF_LOOP")) s->desc.rkf_stage_loop = (e[0] == '1');

@@ -394,7 +394,7 @@ template <int N> HAMK_DEV Jet2<N> operator/(double c, const Jet2<N>& b) { return
 // module's constant data (hamk_trig_lut_init, emitted by hamk_codegen.cpp before this header).
 #define HAMK_LUT_N 512
 #ifndef HAMK_USE_LUT
-#define HAMK_USE_LUT 1
+#define HAMK_USE_LUT 2      /* 0: no table; 1: every sincos of the stepping kernels through the table; 2: see StageTrig */
 #endif
 #ifdef HAMK_HOST_EMULATION
 #define HAMK_LUT hamk_trig_lut_init                     /* tests/host_emulation: plain memory */
@@ -553,10 +553,11 @@ template <int MODE, class TC> HAMK_DEV void trig_pair(double x, TC& tc, int k) {
       if (mode == DYN_SHORT) { rotate_pair<INCR_SHORT>(d, tc.as[k], tc.ac[k], tc.s[k], tc.c[k]); full = !(fabs(d) < incr_limit<INCR_SHORT>()); }
       else { rotate_pair<INCR_NARROW>(d, tc.as[k], tc.ac[k], tc.s[k], tc.c[k]); full = !(fabs(d) < incr_limit<INCR_NARROW>()); }
     }
+    // (with the LDS table loaded -- HAMK_USE_LUT -- the full evaluation is sincos_lut: 22 instructions)
 #ifdef HAMK_PROBE_NO_SLOWPATH
-    if (mode == DYN_FULL_ANCHOR) sincos_f64(x, tc.s[k], tc.c[k]);
+    if (mode == DYN_FULL_ANCHOR) { if constexpr (HAMK_USE_LUT != 0) sincos_lut(x, tc.s[k], tc.c[k]); else sincos_f64(x, tc.s[k], tc.c[k]); }
 #else
-    if (full) sincos_f64(x, tc.s[k], tc.c[k]);
+    if (full) { if constexpr (HAMK_USE_LUT != 0) sincos_lut(x, tc.s[k], tc.c[k]); else sincos_f64(x, tc.s[k], tc.c[k]); }
 #endif
     if (mode == DYN_FULL_ANCHOR || mode == DYN_NARROW_ANCHOR) { tc.ax[k] = x; tc.as[k] = tc.s[k]; tc.ac[k] = tc.c[k]; }
   }
@@ -948,19 +949,30 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
 
 // TRIG_INCR pays only where sincos is a large share of the right-hand side and the anchors fit
 // in registers; elsewhere the stage evaluations stay TRIG_FULL.
+// How the stepping kernels evaluate sincos (measured on MI355X, profiles/r02_sweep_trig.jsonl):
+//   * the LDS table makes a full-accuracy evaluation cost 22 instructions instead of 42, but every
+//     evaluation is a 16-byte gather at a lane-dependent address: ~20-25 LDS cycles per wavefront
+//     (bank conflicts), and one LDS unit serves the 16 resident wavefronts of a CU.  A kernel whose
+//     step is short and trig-dense (config 2: 8 evaluations per 370-instruction step) would keep that
+//     unit ~2/3 busy and gains little;
+//   * rotations about the step's midpoint (TRIG_DYN) cost 20-23 instructions and no LDS traffic, but
+//     need 3 registers per site and one full evaluation per step.
+//   HAMK_USE_LUT = 2 (default): 1-4 sites -> the step's ONE full evaluation through the table, stages
+//     2-4 by rotation (88 instructions per site and step, 2 gathers per step in config 2);
+//     5 or more sites (the chains: anchors do not fit in registers) -> every evaluation through the table;
+//   HAMK_USE_LUT = 1: every evaluation through the table;  0: no table (round-1 arithmetic).
+// The adaptive stepper (RKF45) takes every evaluation through the table when there is one.
 template <class S> struct StageTrig {
-  // HAMK_USE_LUT: every sincos of the stepping kernels goes through the LDS table, whatever the number
-  // of sites.  Without it (kept for comparison, profiles/r02_sweep_trig.jsonl): the anchor scheme, which
-  // pays only where the anchors fit in registers (1-4 sites).
-  static constexpr bool lut = (HAMK_USE_LUT != 0) && (S::NTRIG_F >= 1);
+  static constexpr bool few = (S::NTRIG_F >= 1 && S::NTRIG_F <= 4);
+  static constexpr bool lut = (HAMK_USE_LUT != 0) && (S::NTRIG_F >= 1);          // the kernel loads the table
 #ifdef HAMK_NO_INCR
   static constexpr bool on = false;
 #else
-  static constexpr bool on = !lut && (S::NTRIG_F >= 1 && S::NTRIG_F <= 4);
+  static constexpr bool on = few && (HAMK_USE_LUT != 1);                         // rotations in the fixed-step loops
 #endif
-  static constexpr int anchor = lut ? TRIG_LUT : (on ? TRIG_ANCHOR : TRIG_FULL);
-  static constexpr int incr = lut ? TRIG_LUT : (on ? TRIG_INCR : TRIG_FULL);
-  static constexpr int dyn = lut ? TRIG_LUT : (on ? TRIG_DYN : TRIG_FULL);   // the fixed-step loops
+  static constexpr int anchor = lut ? TRIG_LUT : (few ? TRIG_ANCHOR : TRIG_FULL);
+  static constexpr int incr = lut ? TRIG_LUT : (few ? TRIG_INCR : TRIG_FULL);
+  static constexpr int dyn = on ? TRIG_DYN : (lut ? TRIG_LUT : TRIG_FULL);       // the fixed-step loops
 };
 
 template <class S, int TRIG = TRIG_FULL>

@@ -15,7 +15,7 @@ struct SystemDesc {
   bool rk4_stage_loop = false;
   bool rkf_stage_loop = false;
   int rk4_min_waves = 1;        // __launch_bounds__ second argument of the RK4 kernel (waves per SIMD)
-  bool use_lut = true;          // stepping kernels: sincos through the LDS table (hamk_device.hpp sincos_lut)
+  int use_lut = 2;              // stepping kernels: sincos through the LDS table (hamk_device.hpp StageTrig: 0, 1, 2)
   bool wave = false;            // wave-cooperative kernels (hamk_wave.hpp) instead of one trajectory per lane
   std::vector<double> inertia;
   std::vector<hamk_op> f_ops;

@@ -41,8 +41,9 @@ def variants():
     out = []
     for name, B, ns in (("doublePendulum", 1 << 20, 400), ("twoBody", 1 << 20, 400), ("spring", 1 << 20, 400), ("threeBodyPolar", 1 << 18, 400),
                         ("pendulum", 1 << 20, 400), ("chain8", 1 << 16, 200), ("chain16", 1 << 16, 50)):
-        out.append((name, B, ns, {}, 0.0, 10))                                # sincos through the LDS table (default)
-        out.append((name, B, ns, {"HAMK_TRIG_LUT": "0"}, 0.0, 10))            # the anchor scheme (1-4 sites) / full evaluations
+        out.append((name, B, ns, {"HAMK_TRIG_LUT": "2"}, 0.0, 10))            # default: table for the full evaluation, rotations (1-4 sites)
+        out.append((name, B, ns, {"HAMK_TRIG_LUT": "1"}, 0.0, 10))            # every sincos through the LDS table
+        out.append((name, B, ns, {"HAMK_TRIG_LUT": "0"}, 0.0, 10))            # no table: round-1 arithmetic + midpoint anchors
     return out
 
 

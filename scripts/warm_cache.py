@@ -33,6 +33,7 @@ def jobs():
                 out.append((n, env, False))
     for n in ("doublePendulum", "twoBody", "spring", "threeBodyPolar", "pendulum", "chain8", "chain16"):
         out.append((n, {"HAMK_TRIG_LUT": "0"}, False))
+        out.append((n, {"HAMK_TRIG_LUT": "1"}, False))
     for seed in range(16):
         out.append((f"random{seed}", {}, False))
     return out
