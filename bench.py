@@ -106,12 +106,17 @@ def cpu_baseline_leg(spec, s, dt, target_seconds):
     t0 = time.perf_counter()
     o.rk4_steps_batch(q, p, dt, nsteps, threads=1)
     el1 = time.perf_counter() - t0
-    probe_S = 16 * cores                                          # all cores: measure the rate, do not assume the scaling
-    q, qd = examples.sample_config(spec, 0, probe_S)
-    p = o.to_phase_batch(q, qd)
-    t0 = time.perf_counter()
-    o.rk4_steps_batch(q, p, dt, 5)
-    rate_all = probe_S * 5 / (time.perf_counter() - t0)
+    probe_S = 16 * cores                                          # all cores: measure the rate, do not assume the scaling;
+    while True:                                                   # grow the probe until thread start-up no longer dominates it
+        q, qd = examples.sample_config(spec, 0, probe_S)
+        p = o.to_phase_batch(q, qd)
+        t0 = time.perf_counter()
+        o.rk4_steps_batch(q, p, dt, 5)
+        el_probe = time.perf_counter() - t0
+        rate_all = probe_S * 5 / el_probe
+        if el_probe > 0.4 or probe_S >= (1 << 19):
+            break
+        probe_S *= 4
     S = int(min(1 << 20, max(256, rate_all * target_seconds / nsteps)))
     S -= S % 256
     q, qd = examples.sample_config(spec, 0, S)

@@ -969,6 +969,23 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   s->desc.rk4_stage_loop = (n >= 7);
   if (const char* e = std::getenv("HAMK_RK4_LOOP")) s->desc.rk4_stage_loop = (e[0] == '1');
   if (const char* e = std::getenv("HAMK_RK4_WAVES")) s->desc.rk4_min_waves = std::atoi(e);
+  {
+    // sincos in the stepping kernels (hamk_device.hpp StageTrig).  Every evaluation through the LDS table is
+    // the fewest instructions, but each is a 16-byte gather at a lane-dependent address (~20-25 LDS cycles
+    // per wavefront) and the CU's 16 wavefronts share one LDS unit: where a right-hand side is short and
+    // trig-dense the unit saturates, and taking only the step's one full evaluation from the table (stages
+    // 2-4 by rotation in registers) is faster.  Measured on MI355X (profiles/r02_sweep_trig.jsonl): rotation
+    // wins for doublePendulum (2 sites per ~90-instruction RHS: 8.36 vs 8.21e10) and pendulum, the table for
+    // twoBody (+8 %), threeBodyPolar (+8 %) and the chains (+24 % at n = 8); spring is a tie.  The rule
+    // below reproduces those choices from an estimate of the instructions per RHS and sincos site.
+    std::vector<char> seen(f_nops > 0 ? f_nops : 1, 0);
+    int sites = 0;
+    for (int i = 0; i < f_nops; ++i)
+      if ((f_ops[i].op == HAMK_OP_SIN || f_ops[i].op == HAMK_OP_COS) && !seen[f_ops[i].a]) { seen[f_ops[i].a] = 1; ++sites; }
+    const double width = s->desc.mode_h ? 1.0 + n + 0.5 * n * (n + 1) : 3.0 * n + 3.0;      // jet components carried per tape value
+    const double est_rhs = (f_nops + u_nops) * width + 2.0 * m * n * n + n * n * n / 3.0;
+    s->desc.use_lut = (sites >= 1 && sites <= 4 && est_rhs / sites < 100.0) ? 2 : 1;
+  }
   if (const char* e = std::getenv("HAMK_TRIG_LUT")) { if (e[0] >= '0' && e[0] <= '2') s->desc.use_lut = e[0] - '0'; }   // experiments
   if (const char* e = std::getenv("HAMK_GSL_API")) s->gsl_api = (e[0] == '1') ? 1 : 2;
   s->desc.rkf_stage_loop = (n >= 4);

@@ -396,7 +396,7 @@ std::string generate_source(const SystemDesc& d) {
   std::ostringstream o;
   o << "// generated by libhamk (hamk_codegen.cpp) from the expression tape of one System " << d.m << " " << d.n << "\n";
   if (d.rk4_min_waves > 1) o << "#define HAMK_RK4_MIN_WAVES " << d.rk4_min_waves << "\n";
-  if (d.use_lut != 2) o << "#define HAMK_USE_LUT " << d.use_lut << "\n";
+  o << "#define HAMK_USE_LUT " << d.use_lut << "\n";
   // (sin, cos)(i 2pi/512), correctly rounded from 80-bit: the constant data behind sincos_lut's LDS table
   o << "#ifdef HAMK_HOST_EMULATION\nstatic const double hamk_trig_lut_init[1024] = {\n#else\n__device__ const double hamk_trig_lut_init[1024] = {\n#endif\n";
   for (int i = 0; i < 512; ++i) {

@@ -44,6 +44,10 @@ def variants():
         out.append((name, B, ns, {"HAMK_TRIG_LUT": "2"}, 0.0, 10))            # default: table for the full evaluation, rotations (1-4 sites)
         out.append((name, B, ns, {"HAMK_TRIG_LUT": "1"}, 0.0, 10))            # every sincos through the LDS table
         out.append((name, B, ns, {"HAMK_TRIG_LUT": "0"}, 0.0, 10))            # no table: round-1 arithmetic + midpoint anchors
+    for name, ns in (("chain16", 50), ("chain12", 100)):                      # register-bound lane kernels: which build, table or not
+        for lut in ("1", "0"):
+            for nolicm in ("0", "1"):
+                out.append((name, 1 << 16, ns, {"HAMK_TRIG_LUT": lut, "HAMK_NOLICM": nolicm}, 0.0, 8))
     return out
 
 
