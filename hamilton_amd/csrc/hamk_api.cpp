@@ -985,6 +985,9 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
     const double width = s->desc.mode_h ? 1.0 + n + 0.5 * n * (n + 1) : 3.0 * n + 3.0;      // jet components carried per tape value
     const double est_rhs = (f_nops + u_nops) * width + 2.0 * m * n * n + n * n * n / 3.0;
     s->desc.use_lut = (sites >= 1 && sites <= 4 && est_rhs / sites < 100.0) ? 2 : 1;
+    // the largest lane kernels (n >= 14: 512 VGPRs and hundreds spilled) are bound by their scratch traffic;
+    // measured, the table variant schedules worse there (chain16 9.4e8 vs 1.05e9 steps/s; chain12 +5 % with it)
+    if (n >= 14 && !s->desc.wave) s->desc.use_lut = 0;
   }
   if (const char* e = std::getenv("HAMK_TRIG_LUT")) { if (e[0] >= '0' && e[0] <= '2') s->desc.use_lut = e[0] - '0'; }   // experiments
   if (const char* e = std::getenv("HAMK_GSL_API")) s->gsl_api = (e[0] == '1') ? 1 : 2;
