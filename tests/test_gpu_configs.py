@@ -149,9 +149,10 @@ def test_full_size(api, oracle_lib, cid, name, B, nsteps, nsample, DRIFT_TOL):
     eo = float(per_lane[keep].max()) if keep.any() else float("nan")
     eo_all = float(per_lane.max())
     record(test="full_size_oracle", cid=cid, kept=float(keep.mean()), err_kept=eo, err_all=eo_all, err_median=float(np.median(per_lane)))
+    # measured on MI355X (profiles/r02_gpu_test_record.jsonl): <= 8e-15 on the kept lanes, <= 3e-14 on all, median ~2e-15
     if keep.any():
-        assert eo < 1e-8, (cid, float(keep.mean()), eo)
-    assert float(np.median(per_lane)) < 1e-9 and eo_all < 1e-4, (cid, float(np.median(per_lane)), eo_all)   # roundoff, amplified on the wild members
+        assert eo < 1e-12, (cid, float(keep.mean()), eo)
+    assert float(np.median(per_lane)) < 2e-14 and eo_all < 1e-10, (cid, float(np.median(per_lane)), eo_all)   # roundoff, amplified on the wild members
     # (d) order of convergence: halve dt, double the steps
     def rev_and_drift(dt_, n_):
         fwd = api.rk4Steps(dt_, n_, s, ph0)
@@ -169,10 +170,11 @@ def test_full_size(api, oracle_lib, cid, name, B, nsteps, nsample, DRIFT_TOL):
            ratio_rev=r_rev, ratio_drift=r_drift, wave="HAMK_INSTANTIATE_WAVE" in s.source)
     # RK4: global error ~ dt^4, the time-reversal defect and the energy drift one order better or
     # equal; where a quantity is already at roundoff level the ratio says nothing and is skipped
+    # measured: 31.5-32.0 (the defect of reversing an RK4 step is O(h^5)) and 15-26
     if float(e2.median()) > 1e-13:
-        assert 12.0 < r_rev < 80.0, (cid, r_rev)
+        assert 24.0 < r_rev < 40.0, (cid, r_rev)
     if float(d2.median()) > 1e-14:
-        assert 8.0 < r_drift < 80.0, (cid, r_drift)
+        assert 10.0 < r_drift < 40.0, (cid, r_drift)
     if not cid.startswith("C5"):
         assert frac_flagged < 0.2, (cid, frac_flagged)
 
