@@ -89,9 +89,23 @@ class HamkError(RuntimeError):
         self.code = code
 
 
+def _default_cache_dir():
+    """A pre-compiled code-object cache that travels with the source tree (`.hamk_cache/`, filled by
+    scripts/warm_cache.py or __graft_entry__.build(); hiprtc cross-compiles without a GPU) is used when
+    the caller has not chosen a location: a fresh GPU box then measures instead of compiling.  Entries
+    are verified (SHA-256 of key material and payload) and the directory must be owner-only, or
+    libhamk ignores it (hamk_api.cpp)."""
+    if "HAMK_CACHE_DIR" in os.environ:
+        return
+    d = os.path.join(os.path.dirname(_HERE), ".hamk_cache")
+    if os.path.isdir(d):
+        os.environ["HAMK_CACHE_DIR"] = d
+
+
 def lib():
     global _lib
     if _lib is None:
+        _default_cache_dir()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
