@@ -1,0 +1,1301 @@
+// FROZEN COPY of hamilton_amd/csrc/hamk_device.hpp as of round 1 (commit 362ecf5): the device library version whose
+// unrolled RKF45 kernel of this system is miscompiled.  Not used by the product.
+// hamk_device.hpp -- hand-written CDNA4 (gfx950) device library for the
+// equations-of-motion path of mstksg/hamilton.
+//
+// What the reference does per right-hand-side evaluation with three libraries
+// (ad: jacobianT/hessianF/grad, Hamilton.hs:221-224; hmatrix: <>, #>, inv,
+// :377-387; hmatrix-gsl: odeSolveV RKf45, :445) is fused here into single
+// kernels that keep one trajectory per wavefront lane, entirely in registers:
+//
+//   * forward-mode AD on truncated-Taylor "jets" (Jet1 / JetH / Jet2 below)
+//     over the user's coordinate map f and potential U.  f and U arrive as the
+//     member templates `coords` / `potential` of a system struct `S` that
+//     hamk_codegen.cpp emits from the expression tape (include/hamk.h) -- the
+//     device-side counterpart of the reference's rank-2 polymorphic arguments
+//     (`forall a. RealFloat a => ...`, Hamilton.hs:212,215): the same function
+//     instantiated at double, Jet1, JetH, Jet2;
+//   * K = J^T M J, solved (never inverted) in registers: 1x1, adjugate 2x2,
+//     unrolled LDL^T; an LU-partial-pivoting fallback lane path exists only for
+//     systems with a non-positive inertia (reference: hmatrix `inv`, LAPACK
+//     dgesv; Hamilton.hs:321,381);
+//   * dT/dq_i = -(M J qd) . ((dJ/dq_i) qd): the contraction the reference writes
+//     as p.K^-1 J^T M (dJ/dq_i) K^-1 p (Hamilton.hs:382-385) without forming
+//     K^-1 or the m x n x n Hessian tensor;
+//   * classic RK4 (BASELINE.json north_star) and GSL-semantics adaptive RKF45
+//     (stepHam/evolveHam, Hamilton.hs:390-462) stepping loops around it;
+//   * an fp64 sincos written for this path (sincos_f64) and its anchored
+//     incremental form for Runge-Kutta stage points (sincos_incr).
+// Systems with more than 16 coordinates use the wave-cooperative kernels of
+// hamk_wave.hpp instead (same generated f/U code, one AD direction per lane).
+//
+// Memory: ensemble state is SoA fp64, q[j*B + i]; a wave reads 64 consecutive
+// doubles (512 B) per component -- fully coalesced.  Algorithmic HBM traffic is
+// 32 n bytes per trajectory per launch (read + write one Phase); everything
+// else lives in VGPRs.  The kernels are FP64-VALU bound.
+//
+// Compiled per system by hiprtc (hamk_api.cpp) with
+//   -O3 -ffp-contract=fast -fno-honor-nans -fno-signed-zeros
+// The last two let the compiler delete the structural zeros of the AD seeds
+// (d q_j / d q_i = delta_ij, second-order seeds = 0) -- x*0 -> 0, x+0 -> x --
+// which is where a dual-number evaluator otherwise burns most of its flops.
+// They are value-preserving for finite data; non-finite states are detected on
+// raw bit patterns (is_nonfinite_bits) so the flags cannot fold the check away.
+#pragma once
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>
+#endif
+
+#define HAMK_DEV __device__ __forceinline__
+
+namespace hamk {
+
+typedef long long i64;
+
+enum : int { ST_SINGULAR = 1, ST_NONFINITE = 2, ST_UNDERFLOW = 4, ST_MAXSTEPS = 8 };
+
+// hiprtc has no <type_traits>
+template <class T> struct bare { typedef T type; };
+template <class T> struct bare<const T> { typedef T type; };
+template <class T> struct bare<T&> { typedef typename bare<T>::type type; };
+template <class T> struct bare<const T&> { typedef T type; };
+template <class T> using bare_t = typename bare<T>::type;
+
+HAMK_DEV double quiet_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
+
+// ===========================================================================
+// Jets.  All are "value + derivatives along a fixed set of directions"; the
+// generated f/U code is generic over them.
+//   Jet1<N>: value, gradient d[N]
+//   JetH<N>: value, gradient d[N], packed symmetric Hessian h[N(N+1)/2]
+//   Jet2<N>: value, D_v, gradient d[N], mixed D_i D_v dd[N]  (v: a runtime direction)
+// ===========================================================================
+template <int N> struct Jet1 { double v; double d[N]; };
+template <int N> struct JetH { double v; double d[N]; double h[N * (N + 1) / 2]; };
+template <int N> struct Jet2 { double v, dv; double d[N]; double dd[N]; };
+
+template <int N> HAMK_DEV constexpr int hidx(int i, int j) {   // i <= j
+  return i * N - (i * (i - 1)) / 2 + (j - i);
+}
+
+// ---- lifting constants ----------------------------------------------------
+template <class A> struct Lift;
+template <> struct Lift<double> { static HAMK_DEV double of(double c) { return c; } };
+template <int N> struct Lift<Jet1<N>> {
+  static HAMK_DEV Jet1<N> of(double c) {
+    Jet1<N> r; r.v = c;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = 0.0;
+    return r;
+  }
+};
+template <int N> struct Lift<JetH<N>> {
+  static HAMK_DEV JetH<N> of(double c) {
+    JetH<N> r; r.v = c;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < N * (N + 1) / 2; ++i) r.h[i] = 0.0;
+    return r;
+  }
+};
+template <int N> struct Lift<Jet2<N>> {
+  static HAMK_DEV Jet2<N> of(double c) {
+    Jet2<N> r; r.v = c; r.dv = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { r.d[i] = 0.0; r.dd[i] = 0.0; }
+    return r;
+  }
+};
+template <class A> HAMK_DEV A lift(double c) { return Lift<A>::of(c); }
+template <class A> HAMK_DEV A lift(const A& a) { return a; }
+
+// ---- chain rule for y = g(x) given g, g', g'' at x.v -----------------------
+HAMK_DEV double chain(double, double g0, double, double) { return g0; }
+template <int N> HAMK_DEV Jet1<N> chain(const Jet1<N>& x, double g0, double g1, double) {
+  Jet1<N> r; r.v = g0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = g1 * x.d[i];
+  return r;
+}
+template <int N> HAMK_DEV JetH<N> chain(const JetH<N>& x, double g0, double g1, double g2) {
+  JetH<N> r; r.v = g0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = g1 * x.d[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double t = g2 * x.d[i];
+#pragma unroll
+    for (int j = i; j < N; ++j) r.h[hidx<N>(i, j)] = fma(t, x.d[j], g1 * x.h[hidx<N>(i, j)]);
+  }
+  return r;
+}
+template <int N> HAMK_DEV Jet2<N> chain(const Jet2<N>& x, double g0, double g1, double g2) {
+  Jet2<N> r; r.v = g0; r.dv = g1 * x.dv;
+  const double t = g2 * x.dv;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    r.d[i] = g1 * x.d[i];
+    r.dd[i] = fma(t, x.d[i], g1 * x.dd[i]);
+  }
+  return r;
+}
+
+// ---- general two-argument chain rule (pow, atan2) ---------------------------
+HAMK_DEV double chain2(double, double, double f0, double, double, double, double, double) { return f0; }
+template <int N>
+HAMK_DEV Jet1<N> chain2(const Jet1<N>& a, const Jet1<N>& b, double f0, double fa, double fb, double, double, double) {
+  Jet1<N> r; r.v = f0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = fa * a.d[i] + fb * b.d[i];
+  return r;
+}
+template <int N>
+HAMK_DEV JetH<N> chain2(const JetH<N>& a, const JetH<N>& b, double f0, double fa, double fb, double faa, double fab,
+                        double fbb) {
+  JetH<N> r; r.v = f0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = fa * a.d[i] + fb * b.d[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = i; j < N; ++j)
+      r.h[hidx<N>(i, j)] = fa * a.h[hidx<N>(i, j)] + fb * b.h[hidx<N>(i, j)] + faa * a.d[i] * a.d[j] +
+                           fab * (a.d[i] * b.d[j] + a.d[j] * b.d[i]) + fbb * b.d[i] * b.d[j];
+  return r;
+}
+template <int N>
+HAMK_DEV Jet2<N> chain2(const Jet2<N>& a, const Jet2<N>& b, double f0, double fa, double fb, double faa, double fab,
+                        double fbb) {
+  Jet2<N> r; r.v = f0; r.dv = fa * a.dv + fb * b.dv;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    r.d[i] = fa * a.d[i] + fb * b.d[i];
+    r.dd[i] = fa * a.dd[i] + fb * b.dd[i] + faa * a.d[i] * a.dv + fab * (a.d[i] * b.dv + a.dv * b.d[i]) +
+              fbb * b.d[i] * b.dv;
+  }
+  return r;
+}
+
+// ---- ring operations ----------------------------------------------------------
+// Jet1
+template <int N> HAMK_DEV Jet1<N> operator+(const Jet1<N>& a, const Jet1<N>& b) {
+  Jet1<N> r; r.v = a.v + b.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i];
+  return r;
+}
+template <int N> HAMK_DEV Jet1<N> operator-(const Jet1<N>& a, const Jet1<N>& b) {
+  Jet1<N> r; r.v = a.v - b.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i];
+  return r;
+}
+template <int N> HAMK_DEV Jet1<N> operator*(const Jet1<N>& a, const Jet1<N>& b) {
+  Jet1<N> r; r.v = a.v * b.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = fma(a.v, b.d[i], a.d[i] * b.v);
+  return r;
+}
+template <int N> HAMK_DEV Jet1<N> operator-(const Jet1<N>& a) {
+  Jet1<N> r; r.v = -a.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = -a.d[i];
+  return r;
+}
+template <int N> HAMK_DEV Jet1<N> scale(const Jet1<N>& a, double c) {
+  Jet1<N> r; r.v = a.v * c;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * c;
+  return r;
+}
+template <int N> HAMK_DEV Jet1<N> shift(const Jet1<N>& a, double c) { Jet1<N> r = a; r.v = a.v + c; return r; }
+
+// JetH
+template <int N> HAMK_DEV JetH<N> operator+(const JetH<N>& a, const JetH<N>& b) {
+  JetH<N> r; r.v = a.v + b.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i];
+#pragma unroll
+  for (int i = 0; i < N * (N + 1) / 2; ++i) r.h[i] = a.h[i] + b.h[i];
+  return r;
+}
+template <int N> HAMK_DEV JetH<N> operator-(const JetH<N>& a, const JetH<N>& b) {
+  JetH<N> r; r.v = a.v - b.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i];
+#pragma unroll
+  for (int i = 0; i < N * (N + 1) / 2; ++i) r.h[i] = a.h[i] - b.h[i];
+  return r;
+}
+template <int N> HAMK_DEV JetH<N> operator*(const JetH<N>& a, const JetH<N>& b) {
+  JetH<N> r; r.v = a.v * b.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = fma(a.v, b.d[i], a.d[i] * b.v);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = i; j < N; ++j) {
+      const int k = hidx<N>(i, j);
+      r.h[k] = fma(a.v, b.h[k], fma(b.v, a.h[k], fma(a.d[i], b.d[j], a.d[j] * b.d[i])));
+    }
+  return r;
+}
+template <int N> HAMK_DEV JetH<N> operator-(const JetH<N>& a) {
+  JetH<N> r; r.v = -a.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = -a.d[i];
+#pragma unroll
+  for (int i = 0; i < N * (N + 1) / 2; ++i) r.h[i] = -a.h[i];
+  return r;
+}
+template <int N> HAMK_DEV JetH<N> scale(const JetH<N>& a, double c) {
+  JetH<N> r; r.v = a.v * c;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * c;
+#pragma unroll
+  for (int i = 0; i < N * (N + 1) / 2; ++i) r.h[i] = a.h[i] * c;
+  return r;
+}
+template <int N> HAMK_DEV JetH<N> shift(const JetH<N>& a, double c) { JetH<N> r = a; r.v = a.v + c; return r; }
+
+// Jet2
+template <int N> HAMK_DEV Jet2<N> operator+(const Jet2<N>& a, const Jet2<N>& b) {
+  Jet2<N> r; r.v = a.v + b.v; r.dv = a.dv + b.dv;
+#pragma unroll
+  for (int i = 0; i < N; ++i) { r.d[i] = a.d[i] + b.d[i]; r.dd[i] = a.dd[i] + b.dd[i]; }
+  return r;
+}
+template <int N> HAMK_DEV Jet2<N> operator-(const Jet2<N>& a, const Jet2<N>& b) {
+  Jet2<N> r; r.v = a.v - b.v; r.dv = a.dv - b.dv;
+#pragma unroll
+  for (int i = 0; i < N; ++i) { r.d[i] = a.d[i] - b.d[i]; r.dd[i] = a.dd[i] - b.dd[i]; }
+  return r;
+}
+template <int N> HAMK_DEV Jet2<N> operator*(const Jet2<N>& a, const Jet2<N>& b) {
+  Jet2<N> r; r.v = a.v * b.v; r.dv = fma(a.v, b.dv, a.dv * b.v);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    r.d[i] = fma(a.v, b.d[i], a.d[i] * b.v);
+    r.dd[i] = fma(a.v, b.dd[i], fma(a.dd[i], b.v, fma(a.d[i], b.dv, a.dv * b.d[i])));
+  }
+  return r;
+}
+template <int N> HAMK_DEV Jet2<N> operator-(const Jet2<N>& a) {
+  Jet2<N> r; r.v = -a.v; r.dv = -a.dv;
+#pragma unroll
+  for (int i = 0; i < N; ++i) { r.d[i] = -a.d[i]; r.dd[i] = -a.dd[i]; }
+  return r;
+}
+template <int N> HAMK_DEV Jet2<N> scale(const Jet2<N>& a, double c) {
+  Jet2<N> r; r.v = a.v * c; r.dv = a.dv * c;
+#pragma unroll
+  for (int i = 0; i < N; ++i) { r.d[i] = a.d[i] * c; r.dd[i] = a.dd[i] * c; }
+  return r;
+}
+template <int N> HAMK_DEV Jet2<N> shift(const Jet2<N>& a, double c) { Jet2<N> r = a; r.v = a.v + c; return r; }
+
+// mixed jet/double forms (constants of the tape stay plain doubles)
+#define HAMK_MIXED(J)                                                                                   \
+  template <int N> HAMK_DEV J<N> operator+(const J<N>& a, double c) { return shift(a, c); }             \
+  template <int N> HAMK_DEV J<N> operator+(double c, const J<N>& a) { return shift(a, c); }             \
+  template <int N> HAMK_DEV J<N> operator-(const J<N>& a, double c) { return shift(a, -c); }            \
+  template <int N> HAMK_DEV J<N> operator-(double c, const J<N>& a) { return shift(-a, c); }            \
+  template <int N> HAMK_DEV J<N> operator*(const J<N>& a, double c) { return scale(a, c); }             \
+  template <int N> HAMK_DEV J<N> operator*(double c, const J<N>& a) { return scale(a, c); }             \
+  template <int N> HAMK_DEV J<N> operator/(const J<N>& a, double c) { return scale(a, 1.0 / c); }
+HAMK_MIXED(Jet1)
+HAMK_MIXED(JetH)
+HAMK_MIXED(Jet2)
+#undef HAMK_MIXED
+
+// ---- elementary functions (double and every jet) -------------------------------
+template <class A> HAMK_DEV double val(const A& a) { return a.v; }
+HAMK_DEV double val(double a) { return a; }
+
+// ---- fp64 sincos tuned for this path ----------------------------------------------
+// The double pendulum's right-hand side is two sincos + ~70 other fp64 operations, and
+// the kernels are FP64-VALU bound, so the library routine's ~60-instruction sincos
+// (double-double Cody-Waite + Payne-Hanek dispatch) would be two thirds of the step.
+// Here: k = rint(x * 2/pi); three-FMA Cody-Waite against pi/2 split into 33-bit pieces
+// (k * piece is exact for |k| < 2^20, so the reduced argument carries ~1e-16 relative
+// error); degree-13/12 minimax kernels on [-pi/4, pi/4] (coefficients as published in
+// fdlibm k_sin.c / k_cos.c); quadrant fix-up on integer bits.  ~20 fp64 instructions,
+// <= 1 ulp.  |x| >= 2^20 * pi/2, NaN and Inf take the library path (rare, divergent).
+HAMK_DEV void sincos_f64(double x, double& s, double& c) {
+  // fast path for every lane, unconditionally (one skip-branch around the rare slow path
+  // instead of an if/else diamond: half the scalar branch traffic in the inner loop)
+  const double k = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-k, 1.57079632673412561417e+00, x);          // pi/2 bits  0..32
+  r = fma(-k, 6.07710050630396597660e-11, r);                  //          33..65
+  r = fma(-k, 2.02226624871116645580e-21, r);                  //          66..98
+  // power-basis accumulation (acc += coeff * z^k) instead of Horner: every step is a
+  // v_fmac with a dying accumulator, so no constant has to be copied into the
+  // accumulator register first, and the z^k chain runs beside the two sums.
+  const double z = r * r, z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z;
+  double ps = 1.58969099521155010221e-10 * z5;
+  ps = fma(-2.50507602534068634195e-08, z4, ps);
+  ps = fma(2.75573137070700676789e-06, z3, ps);
+  ps = fma(-1.98412698298579493134e-04, z2, ps);
+  ps = fma(8.33333333332248946124e-03, z, ps);
+  ps += -1.66666666666666324348e-01;
+  const double sr = fma(r * z, ps, r);
+  double pc = -1.13596475577881948265e-11 * z5;
+  pc = fma(2.08757232129817482790e-09, z4, pc);
+  pc = fma(-2.75573143513906633035e-07, z3, pc);
+  pc = fma(2.48015872894767294178e-05, z2, pc);
+  pc = fma(-1.38888888888741095749e-03, z, pc);
+  pc += 4.16666666666666019037e-02;
+  const double cr = fma(z, fma(z, pc, -0.5), 1.0);
+  // quadrant: swap on bit 0; signs applied as XOR on the high dword (sin: bit 1 of q,
+  // cos: bit 1 of q+1) -- integer ops, no compares
+  const unsigned int q = (unsigned int)(int)k;
+  const bool swap = (q & 1u) != 0u;
+  const double s0 = swap ? cr : sr;
+  const double c0 = swap ? sr : cr;
+  s = __hiloint2double((int)((unsigned int)__double2hiint(s0) ^ ((q << 30) & 0x80000000u)), __double2loint(s0));
+  c = __hiloint2double((int)((unsigned int)__double2hiint(c0) ^ (((q + 1u) << 30) & 0x80000000u)), __double2loint(c0));
+  // huge, NaN, Inf: library path.  Two calls, not ::sincos(x, &s, &c): the pointer form leaves an
+  // address-taken stack slot (scratch) in every kernel that inlines this.
+#ifndef HAMK_PROBE_NO_SLOWPATH                             // scripts/isa_stats.py: count the fast path alone
+  if (!(fabs(x) < 1.6e6)) { s = ::sin(x); c = ::cos(x); }
+#endif
+}
+
+// 1/d for normal-range d: hardware estimate + two Newton steps (5 instructions instead
+// of the ~11 of an IEEE divide with scaling/fix-up); <= 1 ulp.  Used for pivots and
+// derivative factors, never where the reference's semantics hinge on exact division.
+HAMK_DEV double frcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
+template <class A> HAMK_DEV A recip(const A& x) {
+  const double r = frcp(val(x));
+  const double r2 = r * r;
+  return chain(x, r, -r2, 2.0 * r2 * r);
+}
+template <class A> HAMK_DEV A operator/(const A& a, const A& b) { return a * recip(b); }
+template <int N> HAMK_DEV Jet1<N> operator/(double c, const Jet1<N>& b) { return scale(recip(b), c); }
+template <int N> HAMK_DEV JetH<N> operator/(double c, const JetH<N>& b) { return scale(recip(b), c); }
+template <int N> HAMK_DEV Jet2<N> operator/(double c, const Jet2<N>& b) { return scale(recip(b), c); }
+
+// sin and cos of one argument always come as a pair (codegen fuses the tape's
+// SIN/COS of a shared operand): one fp64 sincos feeds value, gradient and Hessian.
+// The primal pair lives in a TrigCache slot, filled according to the sweep's TRIG mode:
+//   TRIG_FULL    evaluate sincos_f64 at the operand, keep the pair for later sweeps
+//   TRIG_REUSE   same point as the previous sweep (the Jet2 sweep of MODE_D): read the pair;
+//                the compiler cannot merge two inlined copies of a branching routine
+//   TRIG_ANCHOR  as FULL, and remember (operand, sin, cos) as this site's anchor
+//   TRIG_INCR    the operand is close to the anchor (an RK stage point y + a h k next to y):
+//                rotate the anchor pair by delta = operand - anchor with short Taylor kernels
+//                (|delta| < 1/8: 23 fp64 instructions, no range reduction, no integer
+//                quadrant logic, absolute error < 3e-18 + rounding); otherwise as FULL.
+//                Always relative to the anchor of the current step, so nothing accumulates.
+enum : int { TRIG_FULL = 0, TRIG_REUSE = 1, TRIG_ANCHOR = 2, TRIG_INCR = 3 };
+
+template <int NS> struct TrigCache {
+  double s[NS > 0 ? NS : 1], c[NS > 0 ? NS : 1];                           // current point
+  double ax[NS > 0 ? NS : 1], as[NS > 0 ? NS : 1], ac[NS > 0 ? NS : 1];    // anchor
+};
+
+HAMK_DEV void sincos_incr(double x, double xa, double sa, double ca, double& s, double& c) {
+  const double d = x - xa;
+  const double z = d * d, z2 = z * z, z3 = z2 * z, z4 = z2 * z2;
+  // the leading coefficients of sincos_f64's kernels serve here too (they differ from the Taylor
+  // coefficients by < 4e-15, i.e. < 1e-17 in the result for |delta| < 1/8): 8 fewer fp64
+  // constants = 16 fewer SGPRs in a kernel that already spills SGPRs
+  double ps = 2.75573137070700676789e-06 * z3;
+  ps = fma(-1.98412698298579493134e-04, z2, ps);
+  ps = fma(8.33333333332248946124e-03, z, ps);
+  ps += -1.66666666666666324348e-01;
+  const double sd = fma(d * z, ps, d);                    // sin(delta)
+  double pc = -2.75573143513906633035e-07 * z4;
+  pc = fma(2.48015872894767294178e-05, z3, pc);
+  pc = fma(-1.38888888888741095749e-03, z2, pc);
+  pc = fma(4.16666666666666019037e-02, z, pc);
+  pc += -0.5;
+  const double cm1 = z * pc;                              // cos(delta) - 1
+  s = sa + fma(sa, cm1, ca * sd);
+  c = ca + fma(ca, cm1, -(sa * sd));
+#ifndef HAMK_PROBE_NO_SLOWPATH
+  if (!(fabs(d) < 0.125)) sincos_f64(x, s, c);            // far from the anchor (or NaN): full evaluation
+#endif
+}
+
+template <int MODE, class TC> HAMK_DEV void trig_pair(double x, TC& tc, int k) {
+  if constexpr (MODE == TRIG_FULL) {
+    sincos_f64(x, tc.s[k], tc.c[k]);
+  } else if constexpr (MODE == TRIG_ANCHOR) {
+    sincos_f64(x, tc.s[k], tc.c[k]);
+    tc.ax[k] = x; tc.as[k] = tc.s[k]; tc.ac[k] = tc.c[k];
+  } else if constexpr (MODE == TRIG_INCR) {
+    sincos_incr(x, tc.ax[k], tc.as[k], tc.ac[k], tc.s[k], tc.c[k]);
+  }
+}
+
+template <int MODE, class A, class TC> HAMK_DEV void sincos(const A& x, A& s, A& c, TC& tc, int k) {
+  trig_pair<MODE>(val(x), tc, k);
+  s = chain(x, tc.s[k], tc.c[k], -tc.s[k]);
+  c = chain(x, tc.c[k], -tc.s[k], -tc.c[k]);
+}
+template <int MODE, class A, class TC> HAMK_DEV A sin(const A& x, TC& tc, int k) {
+  trig_pair<MODE>(val(x), tc, k);
+  return chain(x, tc.s[k], tc.c[k], -tc.s[k]);
+}
+template <int MODE, class A, class TC> HAMK_DEV A cos(const A& x, TC& tc, int k) {
+  trig_pair<MODE>(val(x), tc, k);
+  return chain(x, tc.c[k], -tc.s[k], -tc.c[k]);
+}
+// value, first and second derivative of every elementary function at a plain double: the one
+// place the derivative rules live.  The jet overloads below and the generated reverse sweep
+// (hamk_codegen.cpp, MODE_R) both use them.
+HAMK_DEV void d2_recip(double x, double& g0, double& g1, double& g2) { const double r = frcp(x), r2 = r * r; g0 = r; g1 = -r2; g2 = 2.0 * r2 * r; }
+HAMK_DEV void d2_tan(double x, double& g0, double& g1, double& g2) { const double t = ::tan(x), d = fma(t, t, 1.0); g0 = t; g1 = d; g2 = 2.0 * t * d; }
+HAMK_DEV void d2_asin(double x, double& g0, double& g1, double& g2) { const double w = fma(-x, x, 1.0), r = ::rsqrt(w); g0 = ::asin(x); g1 = r; g2 = x * r / w; }
+HAMK_DEV void d2_acos(double x, double& g0, double& g1, double& g2) { const double w = fma(-x, x, 1.0), r = ::rsqrt(w); g0 = ::acos(x); g1 = -r; g2 = -x * r / w; }
+HAMK_DEV void d2_atan(double x, double& g0, double& g1, double& g2) { const double w = 1.0 / fma(x, x, 1.0); g0 = ::atan(x); g1 = w; g2 = -2.0 * x * w * w; }
+HAMK_DEV void d2_sinh(double x, double& g0, double& g1, double& g2) { const double s = ::sinh(x), c = ::cosh(x); g0 = s; g1 = c; g2 = s; }
+HAMK_DEV void d2_cosh(double x, double& g0, double& g1, double& g2) { const double s = ::sinh(x), c = ::cosh(x); g0 = c; g1 = s; g2 = c; }
+HAMK_DEV void d2_tanh(double x, double& g0, double& g1, double& g2) { const double t = ::tanh(x), d = fma(-t, t, 1.0); g0 = t; g1 = d; g2 = -2.0 * t * d; }
+HAMK_DEV void d2_asinh(double x, double& g0, double& g1, double& g2) { const double w = fma(x, x, 1.0), r = ::rsqrt(w); g0 = ::asinh(x); g1 = r; g2 = -x * r / w; }
+HAMK_DEV void d2_acosh(double x, double& g0, double& g1, double& g2) { const double w = fma(x, x, -1.0), r = ::rsqrt(w); g0 = ::acosh(x); g1 = r; g2 = -x * r / w; }
+HAMK_DEV void d2_atanh(double x, double& g0, double& g1, double& g2) { const double w = 1.0 / fma(-x, x, 1.0); g0 = ::atanh(x); g1 = w; g2 = 2.0 * x * w * w; }
+HAMK_DEV void d2_exp(double x, double& g0, double& g1, double& g2) { const double e = ::exp(x); g0 = e; g1 = e; g2 = e; }
+HAMK_DEV void d2_log(double x, double& g0, double& g1, double& g2) { const double r = 1.0 / x; g0 = ::log(x); g1 = r; g2 = -r * r; }
+HAMK_DEV void d2_sqrt(double x, double& g0, double& g1, double& g2) { const double r = ::sqrt(x); g0 = r; g1 = 0.5 / r; g2 = -0.5 * g1 / x; }
+
+// k is a literal after inlining: folds to a multiply chain.  No recursion -- a recursive helper
+// is not inlined and becomes a real device function call (call frame in scratch).
+HAMK_DEV double ipow(double x, int k) {
+  unsigned int e = (k < 0) ? (unsigned int)(-(long long)k) : (unsigned int)k;
+  double r = 1.0, b = x;
+  while (e) { if (e & 1u) r *= b; b *= b; e >>= 1; }
+  return (k < 0) ? frcp(r) : r;
+}
+// x ^ K, integral K: valid for negative x (Examples.hs:154 `x ** 2` with x < 0)
+template <int K> HAMK_DEV void d2_powi(double x, double& g0, double& g1, double& g2) {
+  g0 = ipow(x, K); g1 = K * ipow(x, K - 1); g2 = (double)K * (K - 1) * ipow(x, K - 2);
+}
+// x ** c, constant real c
+HAMK_DEV void d2_powc(double x, double c, double& g0, double& g1, double& g2) {
+  g0 = ::pow(x, c); g1 = c * ::pow(x, c - 1.0); g2 = c * (c - 1.0) * ::pow(x, c - 2.0);
+}
+// two-argument functions: value and all first/second partials
+HAMK_DEV void d2_pow(double a, double b, double& f0, double& fa, double& fb, double& faa, double& fab, double& fbb) {
+  const double z = ::pow(a, b), la = ::log(a), ia = 1.0 / a;     // a ** b, a > 0
+  f0 = z; fa = b * z * ia; fb = z * la; faa = b * (b - 1.0) * z * ia * ia; fab = z * ia * fma(b, la, 1.0); fbb = z * la * la;
+}
+HAMK_DEV void d2_atan2(double y, double x, double& f0, double& fa, double& fb, double& faa, double& fab, double& fbb) {
+  const double i2 = 1.0 / fma(y, y, x * x);
+  f0 = ::atan2(y, x); fa = x * i2; fb = -y * i2; faa = -2.0 * y * x * i2 * i2; fab = (y * y - x * x) * i2 * i2; fbb = -faa;
+}
+
+#define HAMK_UNARY(name)                                                                    \
+  template <class A> HAMK_DEV A name(const A& x) {                                          \
+    double g0, g1, g2; d2_##name(val(x), g0, g1, g2); return chain(x, g0, g1, g2);          \
+  }
+HAMK_UNARY(tan) HAMK_UNARY(asin) HAMK_UNARY(acos) HAMK_UNARY(atan) HAMK_UNARY(sinh) HAMK_UNARY(cosh)
+HAMK_UNARY(tanh) HAMK_UNARY(asinh) HAMK_UNARY(acosh) HAMK_UNARY(atanh) HAMK_UNARY(exp) HAMK_UNARY(log) HAMK_UNARY(sqrt)
+#undef HAMK_UNARY
+
+template <int K, class A> HAMK_DEV A powi(const A& x) {
+  double g0, g1, g2; d2_powi<K>(val(x), g0, g1, g2); return chain(x, g0, g1, g2);
+}
+template <class A> HAMK_DEV A powc(const A& x, double c) {
+  double g0, g1, g2; d2_powc(val(x), c, g0, g1, g2); return chain(x, g0, g1, g2);
+}
+// x ** y, both variable (x > 0)
+template <class A> HAMK_DEV A pow(const A& a, const A& b) {
+  double f0, fa, fb, faa, fab, fbb; d2_pow(val(a), val(b), f0, fa, fb, faa, fab, fbb);
+  return chain2(a, b, f0, fa, fb, faa, fab, fbb);
+}
+template <class A> HAMK_DEV A pow(const A& a, double c) { return powc(a, c); }
+template <class A> HAMK_DEV A pow(double c, const A& b) {      // c ** y = exp(y log c)
+  const double z = ::pow(c, val(b)), lc = ::log(c);
+  return chain(b, z, z * lc, z * lc * lc);
+}
+HAMK_DEV double pow(double a, double b) { return ::pow(a, b); }
+template <class A> HAMK_DEV A atan2(const A& y, const A& x) {
+  double f0, fa, fb, faa, fab, fbb; d2_atan2(val(y), val(x), f0, fa, fb, faa, fab, fbb);
+  return chain2(y, x, f0, fa, fb, faa, fab, fbb);
+}
+template <class A> HAMK_DEV A atan2(const A& y, double x) { return atan2(y, lift<A>(x)); }
+template <class A> HAMK_DEV A atan2(double y, const A& x) { return atan2(lift<A>(y), x); }
+HAMK_DEV double atan2(double y, double x) { return ::atan2(y, x); }
+
+// ===========================================================================
+// Small dense solve K v = p, K symmetric (upper triangle valid), in registers.
+// LDL^T without pivoting; if a pivot is not positive the lane falls back to LU
+// with partial pivoting on the full matrix (what hmatrix `inv` does for every
+// matrix); an exactly zero pivot there sets ST_SINGULAR and yields NaNs, where
+// the reference raises an exception (Hamilton.hs:321,381).
+// ===========================================================================
+template <int N> HAMK_DEV void solve_lu(const double (&K)[N][N], const double (&p)[N], double (&v)[N], int& st) {
+  double a[N][N], b[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    b[i] = p[i];
+#pragma unroll
+    for (int j = 0; j < N; ++j) a[i][j] = (j >= i) ? K[i][j] : K[j][i];
+  }
+  bool singular = false;
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    // bring the largest |a[r][c]|, r >= c, to row c with compare-and-swap (no dynamic indexing)
+#pragma unroll
+    for (int r = c + 1; r < N; ++r) {
+      const bool sw = fabs(a[r][c]) > fabs(a[c][c]);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const double x = a[c][j], y = a[r][j];
+        a[c][j] = sw ? y : x; a[r][j] = sw ? x : y;
+      }
+      const double x = b[c], y = b[r];
+      b[c] = sw ? y : x; b[r] = sw ? x : y;
+    }
+    if (a[c][c] == 0.0) singular = true;
+    const double ip = 1.0 / a[c][c];
+#pragma unroll
+    for (int r = c + 1; r < N; ++r) {
+      const double l = a[r][c] * ip;
+#pragma unroll
+      for (int j = c + 1; j < N; ++j) a[r][j] = fma(-l, a[c][j], a[r][j]);
+      b[r] = fma(-l, b[c], b[r]);
+    }
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    double s = b[i];
+#pragma unroll
+    for (int j = i + 1; j < N; ++j) s = fma(-a[i][j], v[j], s);
+    v[i] = s / a[i][i];
+  }
+  if (singular) {
+    st |= ST_SINGULAR;
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = quiet_nan();
+  }
+}
+
+// POS: every inertia is positive, so K = J^T M J is positive semi-definite by construction and a
+// non-positive pivot can only mean "singular" -- which pivoting cannot repair either: the lane is
+// flagged by a select and the pivoting fallback (a divergent branch per evaluation) is not emitted.
+template <int N, bool POS = false>
+HAMK_DEV void solve_spd(const double (&K)[N][N], const double (&p)[N], double (&v)[N], int& st) {
+  if constexpr (N == 1) {
+    v[0] = p[0] * frcp(K[0][0]);
+    if constexpr (POS) st |= (K[0][0] > 0.0) ? 0 : ST_SINGULAR;
+    else if (!(K[0][0] > 0.0)) solve_lu<N>(K, p, v, st);
+    return;
+  } else if constexpr (N == 2) {
+    // adjugate form: one reciprocal instead of LDL^T's two (positive definite <=> K00 > 0, det > 0)
+    const double det = fma(K[0][0], K[1][1], -(K[0][1] * K[0][1]));
+    const double id = frcp(det);
+    v[0] = fma(K[1][1], p[0], -(K[0][1] * p[1])) * id;
+    v[1] = fma(K[0][0], p[1], -(K[0][1] * p[0])) * id;
+    if constexpr (POS) st |= (K[0][0] > 0.0 && det > 0.0) ? 0 : ST_SINGULAR;
+    else if (!(K[0][0] > 0.0 && det > 0.0)) solve_lu<N>(K, p, v, st);
+    return;
+  }
+  double a[N][N];   // lower triangle: L (unit diagonal implied); diagonal: 1/d_j
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) a[i][j] = K[j][i];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double dj = a[j][j];
+    ok = ok && (dj > 0.0);
+    const double inv = frcp(dj);
+    double col[N];
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) col[i] = a[i][j];
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      const double l = col[i] * inv;
+#pragma unroll
+      for (int k = j + 1; k <= i; ++k) a[i][k] = fma(-l, col[k], a[i][k]);
+      a[i][j] = l;
+    }
+    a[j][j] = inv;
+  }
+  double z[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double s = p[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s = fma(-a[i][k], z[k], s);
+    z[i] = s;
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    double s = z[i] * a[i][i];
+#pragma unroll
+    for (int k = i + 1; k < N; ++k) s = fma(-a[k][i], v[k], s);
+    v[i] = s;
+  }
+  if constexpr (POS) st |= ok ? 0 : ST_SINGULAR;
+  else if (!ok) solve_lu<N>(K, p, v, st);   // rare, lane-divergent
+}
+
+// ===========================================================================
+// The System record's closures on one trajectory (Hamilton.hs:160-169).
+// S (generated): N, M, U_CART, MODE_H, RK4_STAGE_LOOP, RKF_STAGE_LOOP, NTRIG_F, NTRIG_U, inertia(k),
+// coords<A, TRIG>(q, x, trig_cache), potential<A, TRIG>(z, trig_cache).
+// ===========================================================================
+template <class S> HAMK_DEV void seed1(const double (&q)[S::N], Jet1<S::N> (&qa)[S::N]) {
+#pragma unroll
+  for (int j = 0; j < S::N; ++j) {
+    qa[j].v = q[j];
+#pragma unroll
+    for (int i = 0; i < S::N; ++i) qa[j].d[i] = (i == j) ? 1.0 : 0.0;
+  }
+}
+
+// K = J^T M J from first-order jets of x (upper triangle)       Hamilton.hs:380
+template <class S, class A> HAMK_DEV void mass_matrix(const A (&x)[S::M], double (&K)[S::N][S::N]) {
+#pragma unroll
+  for (int a = 0; a < S::N; ++a)
+#pragma unroll
+    for (int b = a; b < S::N; ++b) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < S::M; ++k) acc = fma(S::inertia(k) * x[k].d[a], x[k].d[b], acc);
+      K[a][b] = acc;
+      K[b][a] = acc;
+    }
+}
+
+// grad U(q): potential over generalized coordinates, or (u . f) for mkSystem'
+template <class S> HAMK_DEV void grad_potential(const Jet1<S::N> (&qj)[S::N], const Jet1<S::N> (&xj)[S::M],
+                                                double (&gU)[S::N], double& U) {
+  Jet1<S::N> u;
+  TrigCache<S::NTRIG_U> tu;
+  if constexpr (S::U_CART) u = S::template potential<Jet1<S::N>, TRIG_FULL>(xj, tu);
+  else u = S::template potential<Jet1<S::N>, TRIG_FULL>(qj, tu);
+  U = u.v;
+#pragma unroll
+  for (int i = 0; i < S::N; ++i) gU[i] = u.d[i];
+}
+
+// momenta: p = J^T (M (J qd))                                    Hamilton.hs:262-269
+template <class S> HAMK_DEV void momenta(const double (&q)[S::N], const double (&qd)[S::N], double (&p)[S::N]) {
+  constexpr int N = S::N, M = S::M;
+  Jet1<N> qj[N], xj[M];
+  TrigCache<S::NTRIG_F> tc;
+  seed1<S>(q, qj);
+  S::template coords<Jet1<N>, TRIG_FULL>(qj, xj, tc);
+  double w[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) {
+    double a = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) a = fma(xj[k].d[i], qd[i], a);
+    w[k] = S::inertia(k) * a;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) a = fma(xj[k].d[i], w[k], a);
+    p[i] = a;
+  }
+}
+
+// velocities: qd = (J^T M J)^-1 p                                 Hamilton.hs:316-324
+template <class S> HAMK_DEV void velocities(const double (&q)[S::N], const double (&p)[S::N], double (&qd)[S::N], int& st) {
+  constexpr int N = S::N, M = S::M;
+  Jet1<N> qj[N], xj[M];
+  TrigCache<S::NTRIG_F> tc;
+  seed1<S>(q, qj);
+  S::template coords<Jet1<N>, TRIG_FULL>(qj, xj, tc);
+  double K[N][N];
+  mass_matrix<S>(xj, K);
+  solve_spd<N, S::INERTIA_POS>(K, p, qd, st);
+}
+
+template <class S> HAMK_DEV double potential_value(const double (&q)[S::N]) {
+  TrigCache<S::NTRIG_U> tu;
+  if constexpr (S::U_CART) {
+    double x[S::M];
+    TrigCache<S::NTRIG_F> tc;
+    S::template coords<double, TRIG_FULL>(q, x, tc);
+    return S::template potential<double, TRIG_FULL>(x, tu);
+  } else {
+    return S::template potential<double, TRIG_FULL>(q, tu);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// hamEqs (Hamilton.hs:370-387): (dq, dp) = (K^-1 p, -(dT/dq + grad U)).
+// MODE_H: one sweep of full second-order jets (value, J row, Hessian block per
+//         cartesian coordinate), then contract with qd.  No dependence of the
+//         AD sweep on the solve -> more ILP.  Cheapest for N <= 2.
+// MODE_D: first-order sweep -> K -> qd, then a second sweep along the runtime
+//         direction qd carrying only D_v and D_i D_v (2N+2 components instead
+//         of 1+N+N(N+1)/2); its value/gradient parts are common subexpressions
+//         of the first sweep.  Cheaper for N >= 3.
+// Both use dT/dq_i = -(M J qd) . ((dJ/dq_i) qd), which equals the reference's
+// -(p . K^-1 J^T M (dJ/dq_i) K^-1 p) because K^-1 is symmetric and qd = K^-1 p.
+// ---------------------------------------------------------------------------
+template <class S, bool MODE_H, int TRIG = TRIG_FULL>
+HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (&dq)[S::N], double (&dp)[S::N], int& st,
+                      TrigCache<S::NTRIG_F>& tc) {
+  constexpr int N = S::N, M = S::M;
+  double K[N][N], gU[N], U, v[N], dT[N];
+  if constexpr (MODE_H) {
+    JetH<N> qh[N], xh[M];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      qh[j] = lift<JetH<N>>(q[j]);
+      qh[j].d[j] = 1.0;
+    }
+    S::template coords<JetH<N>, TRIG>(qh, xh, tc);
+    Jet1<N> qj[N], xj[M];
+    seed1<S>(q, qj);
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      xj[k].v = xh[k].v;
+#pragma unroll
+      for (int i = 0; i < N; ++i) xj[k].d[i] = xh[k].d[i];
+    }
+    mass_matrix<S>(xj, K);
+    solve_spd<N, S::INERTIA_POS>(K, p, v, st);
+    grad_potential<S>(qj, xj, gU, U);
+#pragma unroll
+    for (int i = 0; i < N; ++i) dT[i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      double jv = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) jv = fma(xh[k].d[j], v[j], jv);
+      const double uk = S::inertia(k) * jv;                 // (M J qd)_k
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double hv = 0.0;                                    // ((dJ/dq_i) qd)_k
+#pragma unroll
+        for (int j = 0; j < N; ++j) hv = fma(xh[k].h[(i <= j) ? hidx<N>(i, j) : hidx<N>(j, i)], v[j], hv);
+        dT[i] = fma(-uk, hv, dT[i]);
+      }
+    }
+  } else {
+    Jet1<N> qj[N], xj[M];
+    seed1<S>(q, qj);
+    S::template coords<Jet1<N>, TRIG>(qj, xj, tc);
+    mass_matrix<S>(xj, K);
+    solve_spd<N, S::INERTIA_POS>(K, p, v, st);
+    grad_potential<S>(qj, xj, gU, U);
+    if constexpr (S::MODE_R) {
+      // MODE_R: the contraction is a gradient -- one forward (value, tangent along qd) pass and one
+      // reverse pass over the tape (generated, S::dT_reverse), O(tape) instead of O(n * tape)
+      S::dT_reverse(q, v, tc, dT);
+    } else {
+      Jet2<N> q2[N], x2[M];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        q2[j] = lift<Jet2<N>>(q[j]);
+        q2[j].d[j] = 1.0;
+        q2[j].dv = v[j];
+      }
+      S::template coords<Jet2<N>, TRIG_REUSE>(q2, x2, tc);  // primal sincos pairs from the first sweep
+#pragma unroll
+      for (int i = 0; i < N; ++i) dT[i] = 0.0;
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        const double uk = S::inertia(k) * x2[k].dv;           // (M J qd)_k
+#pragma unroll
+        for (int i = 0; i < N; ++i) dT[i] = fma(-uk, x2[k].dd[i], dT[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    dq[i] = v[i];
+    dp[i] = -(dT[i] + gU[i]);
+  }
+}
+
+// TRIG_INCR pays only where sincos is a large share of the right-hand side and the anchors fit
+// in registers; elsewhere the stage evaluations stay TRIG_FULL.
+template <class S> struct StageTrig {
+#ifdef HAMK_NO_INCR
+  static constexpr bool on = false;
+#else
+  static constexpr bool on = (S::NTRIG_F >= 1 && S::NTRIG_F <= 4);
+#endif
+  static constexpr int anchor = on ? TRIG_ANCHOR : TRIG_FULL;
+  static constexpr int incr = on ? TRIG_INCR : TRIG_FULL;
+};
+
+template <class S, int TRIG = TRIG_FULL>
+HAMK_DEV void rhs(const double (&y)[2 * S::N], double (&dy)[2 * S::N], int& st, TrigCache<S::NTRIG_F>& tc) {
+  constexpr int N = S::N;
+  double q[N], p[N], dq[N], dp[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { q[i] = y[i]; p[i] = y[N + i]; }
+  ham_eqs<S, S::MODE_H, TRIG>(q, p, dq, dp, st, tc);
+#pragma unroll
+  for (int i = 0; i < N; ++i) { dy[i] = dq[i]; dy[N + i] = dp[i]; }
+}
+
+// ---- NaN/Inf test on raw bits: immune to -fno-honor-nans folding -------------
+HAMK_DEV bool is_nonfinite_bits(double x) {
+  unsigned int hi = (unsigned int)__double2hiint(x);
+#ifdef HAMK_HOST_EMULATION                                 // tests/host_emulation compiles this header for the CPU
+  asm volatile("" : "+r"(hi));
+#else
+  asm volatile("" : "+v"(hi));
+#endif
+  return (hi & 0x7ff00000u) == 0x7ff00000u;
+}
+
+// ===========================================================================
+// Kernels.  One trajectory per lane; grid covers B.
+// ===========================================================================
+
+// Classic RK4, nsteps steps of dt, state resident in VGPRs for the whole launch.
+template <class S>
+HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, double dt, int nsteps,
+                       int* __restrict__ status) {
+  constexpr int N = S::N, D = 2 * N;
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double y[D];
+#pragma unroll
+  for (int j = 0; j < N; ++j) { y[j] = q[(i64)j * B + i]; y[N + j] = p[(i64)j * B + i]; }
+  int st = 0;
+  TrigCache<S::NTRIG_F> tc;
+  const double h2 = 0.5 * dt, h6 = dt * (1.0 / 6.0), h3 = dt * (1.0 / 3.0);
+  if constexpr (S::RK4_STAGE_LOOP) {
+    // one copy of the right-hand side, executed 4 x nsteps times: keeps the live set to a
+    // single hamEqs (n >= 3 would otherwise pay for four interleaved copies in VGPRs).
+    double k[D], acc[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) { k[j] = 0.0; acc[j] = y[j]; }
+#pragma unroll 1
+    for (int it = 0; it < 4 * nsteps; ++it) {
+      const int sg = it & 3;                                    // wave-uniform: scalar selects
+      const double a = (sg == 0) ? 0.0 : ((sg == 3) ? dt : h2);
+      const double b = (sg == 0 || sg == 3) ? h6 : h3;
+      double yt[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) yt[j] = fma(a, k[j], y[j]);
+      rhs<S>(yt, k, st, tc);
+#pragma unroll
+      for (int j = 0; j < D; ++j) acc[j] = fma(b, k[j], acc[j]);
+      if (sg == 3) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) y[j] = acc[j];
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+      double k[D], yt[D], acc[D];
+      // stage 1 evaluates sincos in full and anchors it; stages 2-4 sit at y + a dt k, a few
+      // hundredths of a radian away, and rotate the anchor pair instead (TRIG_INCR)
+      rhs<S, StageTrig<S>::anchor>(y, k, st, tc);
+#pragma unroll
+      for (int j = 0; j < D; ++j) { acc[j] = fma(h6, k[j], y[j]); yt[j] = fma(h2, k[j], y[j]); }
+      rhs<S, StageTrig<S>::incr>(yt, k, st, tc);
+#pragma unroll
+      for (int j = 0; j < D; ++j) { acc[j] = fma(h3, k[j], acc[j]); yt[j] = fma(h2, k[j], y[j]); }
+      rhs<S, StageTrig<S>::incr>(yt, k, st, tc);
+#pragma unroll
+      for (int j = 0; j < D; ++j) { acc[j] = fma(h3, k[j], acc[j]); yt[j] = fma(dt, k[j], y[j]); }
+      rhs<S, StageTrig<S>::incr>(yt, k, st, tc);
+#pragma unroll
+      for (int j = 0; j < D; ++j) y[j] = fma(h6, k[j], acc[j]);
+    }
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    q[(i64)j * B + i] = y[j];
+    p[(i64)j * B + i] = y[N + j];
+    bad = bad || is_nonfinite_bits(y[j]) || is_nonfinite_bits(y[N + j]);
+  }
+  if (bad) st |= ST_NONFINITE;
+  if (status) status[i] = st;
+}
+
+// hamEqs on the ensemble.
+template <class S>
+HAMK_DEV void hameqs_body(const double* __restrict__ q, const double* __restrict__ p, double* __restrict__ dq,
+                          double* __restrict__ dp, i64 B, int* __restrict__ status) {
+  constexpr int N = S::N;
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double qq[N], pp[N], a[N], b[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) { qq[j] = q[(i64)j * B + i]; pp[j] = p[(i64)j * B + i]; }
+  int st = 0;
+  TrigCache<S::NTRIG_F> tc;
+  ham_eqs<S, S::MODE_H>(qq, pp, a, b, st, tc);
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    dq[(i64)j * B + i] = a[j];
+    dp[(i64)j * B + i] = b[j];
+    bad = bad || is_nonfinite_bits(a[j]) || is_nonfinite_bits(b[j]);
+  }
+  if (bad) st |= ST_NONFINITE;
+  if (status) status[i] = st;
+}
+
+// underlyingPos
+template <class S> HAMK_DEV void coords_body(const double* __restrict__ q, double* __restrict__ x, i64 B) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double qq[S::N], xx[S::M];
+#pragma unroll
+  for (int j = 0; j < S::N; ++j) qq[j] = q[(i64)j * B + i];
+  TrigCache<S::NTRIG_F> tc;
+  S::template coords<double, TRIG_FULL>(qq, xx, tc);
+#pragma unroll
+  for (int k = 0; k < S::M; ++k) x[(i64)k * B + i] = lift<double>(xx[k]);
+}
+
+// toPhase / momenta
+template <class S>
+HAMK_DEV void to_phase_body(const double* __restrict__ q, const double* __restrict__ qd, double* __restrict__ p, i64 B) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double qq[S::N], vv[S::N], pp[S::N];
+#pragma unroll
+  for (int j = 0; j < S::N; ++j) { qq[j] = q[(i64)j * B + i]; vv[j] = qd[(i64)j * B + i]; }
+  momenta<S>(qq, vv, pp);
+#pragma unroll
+  for (int j = 0; j < S::N; ++j) p[(i64)j * B + i] = pp[j];
+}
+
+// fromPhase / velocities
+template <class S>
+HAMK_DEV void from_phase_body(const double* __restrict__ q, const double* __restrict__ p, double* __restrict__ qd,
+                              i64 B, int* __restrict__ status) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double qq[S::N], pp[S::N], vv[S::N];
+#pragma unroll
+  for (int j = 0; j < S::N; ++j) { qq[j] = q[(i64)j * B + i]; pp[j] = p[(i64)j * B + i]; }
+  int st = 0;
+  velocities<S>(qq, pp, vv, st);
+#pragma unroll
+  for (int j = 0; j < S::N; ++j) qd[(i64)j * B + i] = vv[j];
+  if (status) status[i] = st;
+}
+
+// keP / pe / hamiltonian (Hamilton.hs:341-361, :182-186); p may be null when only pe is wanted
+template <class S>
+HAMK_DEV void observe_body(const double* __restrict__ q, const double* __restrict__ p, double* __restrict__ ke,
+                           double* __restrict__ pe, double* __restrict__ h, i64 B, int* __restrict__ status) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double qq[S::N], pp[S::N], vv[S::N];
+#pragma unroll
+  for (int j = 0; j < S::N; ++j) qq[j] = q[(i64)j * B + i];
+  int st = 0;
+  double t = 0.0;
+  if (ke || h) {
+#pragma unroll
+    for (int j = 0; j < S::N; ++j) pp[j] = p[(i64)j * B + i];
+    velocities<S>(qq, pp, vv, st);
+#pragma unroll
+    for (int j = 0; j < S::N; ++j) t = fma(vv[j], pp[j], t);
+    t *= 0.5;
+  }
+  const double u = potential_value<S>(qq);
+  if (ke) ke[i] = t;
+  if (pe) pe[i] = u;
+  if (h) h[i] = t + u;
+  if (status) status[i] = st;
+}
+
+// keC / lagrangian (Hamilton.hs:288-309)
+template <class S>
+HAMK_DEV void observe_config_body(const double* __restrict__ q, const double* __restrict__ qd, double* __restrict__ ke,
+                                  double* __restrict__ lag, i64 B) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double qq[S::N], vv[S::N], pp[S::N];
+#pragma unroll
+  for (int j = 0; j < S::N; ++j) { qq[j] = q[(i64)j * B + i]; vv[j] = qd[(i64)j * B + i]; }
+  momenta<S>(qq, vv, pp);
+  double t = 0.0;
+#pragma unroll
+  for (int j = 0; j < S::N; ++j) t = fma(vv[j], pp[j], t);
+  t *= 0.5;
+  if (ke) ke[i] = t;
+  if (lag) lag[i] = t - potential_value<S>(qq);
+}
+
+// ---------------------------------------------------------------------------
+// evolveHam / stepHam: GSL gsl_odeiv semantics per lane (rkf45.c stepper,
+// cstd.c standard controller a_y = a_dydt = 1, evolve.c evolve_apply, and
+// hmatrix-gsl's gsl-ode.c output loop), restated from the published algorithm.
+// Lanes take different numbers of sub-steps; the loop runs until the wave's
+// slowest lane reaches the output time.  dydt_out of an accepted step is
+// reused as dydt_in of the next (GSL re-evaluates it; same value).
+// qout/pout: [nt][N][B], row 0 = initial state.  nt == 2 and qout == q0 gives
+// stepHam in place (rows are written only for r >= row0).
+// ---------------------------------------------------------------------------
+// 0.9 * r^(-1/ORD) for the step-size controller (cstd.c: r = max |yerr/D|, ORD = 5 on a rejection,
+// 6 on growth), without the general pow (~200 instructions, twice under divergence): a single-
+// precision seed exp2(-log2 r / ORD) from the hardware transcendental units and two Newton steps on
+// y^-ORD = r in fp64 (relative error 2e-7 -> 1e-13 -> rounding).  r is clamped to [2^-100, 2^100]
+// first: outside, the controller's own clamps (factor <= 5, >= 0.2) decide the result anyway.
+template <int ORD> HAMK_DEV double rpow_inv(double r) {
+#ifdef HAMK_PROBE_LIBM_POW
+  return 1.0 / ::pow(r, 1.0 / (double)ORD);
+#endif
+  r = (r < 0x1p-100) ? 0x1p-100 : ((r > 0x1p100) ? 0x1p100 : r);
+  double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)r) * (-1.0f / (float)ORD));
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double y2 = y * y, y4 = y2 * y2;
+    const double yo = (ORD == 5) ? y4 * y : y4 * y2;       // y^ORD
+    y = fma(y * (1.0 / (double)ORD), fma(-r, yo, 1.0), y);
+  }
+  return y;
+}
+
+template <class S>
+HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt, const double* __restrict__ ts, double ts0, double ts1, double h0,
+                         double eps_abs, double eps_rel, int row0, int inplace, int max_sub,
+                         int* __restrict__ status, int* __restrict__ nsub) {
+  constexpr int N = S::N, D = 2 * N;
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double y[D], f0[D];
+#pragma unroll
+  for (int j = 0; j < N; ++j) { y[j] = q0[(i64)j * B + i]; y[N + j] = p0[(i64)j * B + i]; }
+  if (row0 == 0) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) { qout[(i64)j * B + i] = y[j]; pout[(i64)j * B + i] = y[N + j]; }
+  }
+  int st = 0, attempts = 0;
+  // time grid: ts[0..nt), or -- ts == nullptr, nt == 2: stepHam -- the two kernel arguments
+  double t = ts ? ts[0] : ts0, h = h0;
+  TrigCache<S::NTRIG_F> tc;
+  // sincos anchors follow dydt_in/dydt_out: the stage points of an attempt sit within h |f| of
+  // the point where dydt_in was evaluated (after a rejection: of the rejected end point, still
+  // close; TRIG_INCR falls back to the full evaluation when it is not)
+  rhs<S, StageTrig<S>::anchor>(y, f0, st, tc);        // dydt_in at the initial state
+  for (int r = 1; r < nt; ++r) {
+    const double ti = ts ? ts[r] : ts1;
+    while (t < ti && attempts < max_sub) {
+      ++attempts;
+      const double dt = ti - t;
+      double hh = h;
+      bool final_step = false;
+      if ((dt >= 0.0 && hh > dt) || (dt < 0.0 && hh < dt)) { hh = dt; final_step = true; }
+      // --- rkf45.c -----------------------------------------------------------
+      // RKF_STAGE_LOOP: one inlined copy of the right-hand side, run for the six evaluations of an
+      // attempt (k2..k6 and dydt_out) through a wave-uniform stage switch -- far less code for
+      // large systems; otherwise the six evaluations are unrolled (fewer registers for small n).
+      double k2[D], k3[D], k4[D], k5[D], k6[D], yn[D], fn[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) { k2[j] = k3[j] = k4[j] = k5[j] = k6[j] = 0.0; yn[j] = y[j]; fn[j] = 0.0; }
+      if constexpr (S::RKF_STAGE_LOOP) {
+#pragma unroll 1
+      for (int sg = 0; sg < 6; ++sg) {
+        double yt[D], out[D];
+        switch (sg) {
+          case 0:
+#pragma unroll
+            for (int j = 0; j < D; ++j) yt[j] = y[j] + (1.0 / 4.0) * hh * f0[j];
+            break;
+          case 1:
+#pragma unroll
+            for (int j = 0; j < D; ++j) yt[j] = y[j] + hh * ((3.0 / 32.0) * f0[j] + (9.0 / 32.0) * k2[j]);
+            break;
+          case 2:
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+              yt[j] = y[j] + hh * ((1932.0 / 2197.0) * f0[j] + (-7200.0 / 2197.0) * k2[j] + (7296.0 / 2197.0) * k3[j]);
+            break;
+          case 3:
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+              yt[j] = y[j] + hh * ((8341.0 / 4104.0) * f0[j] + (-32832.0 / 4104.0) * k2[j] +
+                                   (29440.0 / 4104.0) * k3[j] + (-845.0 / 4104.0) * k4[j]);
+            break;
+          case 4:
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+              yt[j] = y[j] + hh * ((-6080.0 / 20520.0) * f0[j] + (41040.0 / 20520.0) * k2[j] +
+                                   (-28352.0 / 20520.0) * k3[j] + (9295.0 / 20520.0) * k4[j] +
+                                   (-5643.0 / 20520.0) * k5[j]);
+            break;
+          default:
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+              const double di = (902880.0 / 7618050.0) * f0[j] + (3953664.0 / 7618050.0) * k3[j] +
+                                (3855735.0 / 7618050.0) * k4[j] + (-1371249.0 / 7618050.0) * k5[j] +
+                                (277020.0 / 7618050.0) * k6[j];
+              yn[j] = y[j] + hh * di;
+              yt[j] = yn[j];
+            }
+            break;
+        }
+        rhs<S>(yt, out, st, tc);
+        switch (sg) {
+          case 0:
+#pragma unroll
+            for (int j = 0; j < D; ++j) k2[j] = out[j];
+            break;
+          case 1:
+#pragma unroll
+            for (int j = 0; j < D; ++j) k3[j] = out[j];
+            break;
+          case 2:
+#pragma unroll
+            for (int j = 0; j < D; ++j) k4[j] = out[j];
+            break;
+          case 3:
+#pragma unroll
+            for (int j = 0; j < D; ++j) k5[j] = out[j];
+            break;
+          case 4:
+#pragma unroll
+            for (int j = 0; j < D; ++j) k6[j] = out[j];
+            break;
+          default:
+#pragma unroll
+            for (int j = 0; j < D; ++j) fn[j] = out[j];                  // dydt_out
+            break;
+        }
+      }
+      } else {
+        double yt[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) yt[j] = y[j] + (1.0 / 4.0) * hh * f0[j];
+        rhs<S, StageTrig<S>::incr>(yt, k2, st, tc);
+#pragma unroll
+        for (int j = 0; j < D; ++j) yt[j] = y[j] + hh * ((3.0 / 32.0) * f0[j] + (9.0 / 32.0) * k2[j]);
+        rhs<S, StageTrig<S>::incr>(yt, k3, st, tc);
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+          yt[j] = y[j] + hh * ((1932.0 / 2197.0) * f0[j] + (-7200.0 / 2197.0) * k2[j] + (7296.0 / 2197.0) * k3[j]);
+        rhs<S, StageTrig<S>::incr>(yt, k4, st, tc);
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+          yt[j] = y[j] + hh * ((8341.0 / 4104.0) * f0[j] + (-32832.0 / 4104.0) * k2[j] + (29440.0 / 4104.0) * k3[j] +
+                               (-845.0 / 4104.0) * k4[j]);
+        rhs<S, StageTrig<S>::incr>(yt, k5, st, tc);
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+          yt[j] = y[j] + hh * ((-6080.0 / 20520.0) * f0[j] + (41040.0 / 20520.0) * k2[j] + (-28352.0 / 20520.0) * k3[j] +
+                               (9295.0 / 20520.0) * k4[j] + (-5643.0 / 20520.0) * k5[j]);
+        rhs<S, StageTrig<S>::incr>(yt, k6, st, tc);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const double di = (902880.0 / 7618050.0) * f0[j] + (3953664.0 / 7618050.0) * k3[j] +
+                            (3855735.0 / 7618050.0) * k4[j] + (-1371249.0 / 7618050.0) * k5[j] +
+                            (277020.0 / 7618050.0) * k6[j];
+          yn[j] = y[j] + hh * di;
+        }
+        rhs<S, StageTrig<S>::anchor>(yn, fn, st, tc);      // dydt_out (next attempt's anchor)
+      }
+      // --- cstd.c: std_control_hadjust, ord = 5 ------------------------------
+      double rmax = 2.2250738585072014e-308;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const double yerr = hh * ((1.0 / 360.0) * f0[j] + (-128.0 / 4275.0) * k3[j] + (-2197.0 / 75240.0) * k4[j] +
+                                  (1.0 / 50.0) * k5[j] + (2.0 / 55.0) * k6[j]);
+        const double D0 = eps_rel * (fabs(yn[j]) + fabs(hh * fn[j])) + eps_abs;
+        const double rr = fabs(yerr) / fabs(D0);
+        rmax = (rr > rmax) ? rr : rmax;
+      }
+      const double tnew = final_step ? ti : t + hh;
+      const double h_old = hh;
+      bool reject = false;
+      if (rmax > 1.1) {
+        double rr = 0.9 * rpow_inv<5>(rmax);
+        if (rr < 0.2) rr = 0.2;
+        const double hdec = rr * h_old;
+        if (fabs(hdec) < fabs(h_old) && (tnew + hdec) != tnew) { reject = true; hh = hdec; }
+      } else if (rmax < 0.5) {
+        double rr = 0.9 * rpow_inv<6>(rmax);
+        if (rr > 5.0) rr = 5.0;
+        if (rr < 1.0) rr = 1.0;
+        hh = rr * h_old;
+      }
+      // --- evolve.c: accept or undo -------------------------------------------
+      h = hh;
+      if (!reject) {
+        if (!(tnew > t)) st |= ST_UNDERFLOW;
+        t = tnew;
+#pragma unroll
+        for (int j = 0; j < D; ++j) { y[j] = yn[j]; f0[j] = fn[j]; }
+      }
+    }
+    if (t < ti) st |= ST_MAXSTEPS;
+    if (r >= row0) {
+      double* qo = inplace ? qout : qout + (i64)r * N * B;
+      double* po = inplace ? pout : pout + (i64)r * N * B;
+#pragma unroll
+      for (int j = 0; j < N; ++j) { qo[(i64)j * B + i] = y[j]; po[(i64)j * B + i] = y[N + j]; }
+    }
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < D; ++j) bad = bad || is_nonfinite_bits(y[j]);
+  if (bad) st |= ST_NONFINITE;
+  if (status) status[i] = st;
+  if (nsub) nsub[i] = attempts;
+}
+
+}  // namespace hamk
+
+// Instantiates the extern "C" kernels of one system; the generated translation
+// unit ends with HAMK_INSTANTIATE(HamkSys).
+// NOTE: do not spell the default as __launch_bounds__(256, 1): with an explicit "1 wave per SIMD"
+// hint hipcc/ROCm 7.2 produced a WRONG unrolled RK4 kernel for the 27-opcode test system (error
+// 1e-4 after one step, every lane, status clean; correct with no hint and with hints >= 2).
+#ifdef HAMK_RK4_MIN_WAVES
+#define HAMK_RK4_BOUNDS __launch_bounds__(256, HAMK_RK4_MIN_WAVES)
+#else
+#define HAMK_RK4_BOUNDS __launch_bounds__(256)
+#endif
+#define HAMK_INSTANTIATE(S)                                                                                      \
+  extern "C" __global__ void HAMK_RK4_BOUNDS hamk_rk4_steps_k(double* q, double* p, long long B,                 \
+                                                                      double dt, int nsteps, int* status) {      \
+    hamk::rk4_body<S>(q, p, B, dt, nsteps, status);                                                              \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_hameqs_k(const double* q, const double* p, double* dq,  \
+                                                                   double* dp, long long B, int* status) {       \
+    hamk::hameqs_body<S>(q, p, dq, dp, B, status);                                                               \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_coords_k(const double* q, double* x, long long B) {     \
+    hamk::coords_body<S>(q, x, B);                                                                               \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_to_phase_k(const double* q, const double* qd,           \
+                                                                     double* p, long long B) {                   \
+    hamk::to_phase_body<S>(q, qd, p, B);                                                                         \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_from_phase_k(const double* q, const double* p,          \
+                                                                       double* qd, long long B, int* status) {   \
+    hamk::from_phase_body<S>(q, p, qd, B, status);                                                               \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_observe_k(const double* q, const double* p, double* ke, \
+                                                                    double* pe, double* h, long long B,          \
+                                                                    int* status) {                               \
+    hamk::observe_body<S>(q, p, ke, pe, h, B, status);                                                           \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_observe_config_k(const double* q, const double* qd,     \
+                                                                           double* ke, double* lag,              \
+                                                                           long long B) {                        \
+    hamk::observe_config_body<S>(q, qd, ke, lag, B);                                                             \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_rkf45_k(                                                \
+      const double* q0, const double* p0, double* qout, double* pout, long long B, int nt, const double* ts,     \
+      double ts0, double ts1, double h0, double eps_abs, double eps_rel, int row0, int inplace, int max_sub,     \
+      int* status, int* nsub) {                                                                                  \
+    hamk::rkf45_body<S>(q0, p0, qout, pout, B, nt, ts, ts0, ts1, h0, eps_abs, eps_rel, row0, inplace, max_sub,   \
+                        status, nsub);                                                                           \
+  }
