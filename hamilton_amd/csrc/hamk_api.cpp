@@ -47,9 +47,10 @@ static int fail(int code, const std::string& msg) {
       return fail(HAMK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
   } while (0)
 
-enum KernelId { K_RK4, K_HAMEQS, K_COORDS, K_TO_PHASE, K_FROM_PHASE, K_OBSERVE, K_OBSERVE_CFG, K_RKF45, K__COUNT };
+enum KernelId { K_RK4, K_HAMEQS, K_COORDS, K_TO_PHASE, K_FROM_PHASE, K_OBSERVE, K_OBSERVE_CFG, K_RKF45, K_SCRIBBLE, K__COUNT };
 static const char* kKernelNames[K__COUNT] = {"hamk_rk4_steps_k", "hamk_hameqs_k",  "hamk_coords_k",         "hamk_to_phase_k",
-                                             "hamk_from_phase_k", "hamk_observe_k", "hamk_observe_config_k", "hamk_rkf45_k"};
+                                             "hamk_from_phase_k", "hamk_observe_k", "hamk_observe_config_k", "hamk_rkf45_k",
+                                             "hamk_scribble_k"};
 
 // What a handle owns on ONE device.  A handle used from several devices (one process driving every
 // GPU of a node, or a torch program whose tensors live on cuda:1 while cuda:0 is current) keeps one
@@ -576,7 +577,7 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
   // and both must agree with 64 fixed RK4 steps of T/64 (the kernel checked above) to well within
   // what the controller's tolerance allows.
   if (rc == HAMK_OK && *rk4_ok && *rkf_ok && usable && !flagged) {
-    const int64_t B3 = 256;
+    const int64_t B3 = 4096;                                   // 64 wavefronts: many divergence patterns
     const size_t c3 = (size_t)n * B3;
     const double T = 0.02;
     std::vector<double> q3(c3), p3(c3), ref3(2 * c3), run[2] = {std::vector<double>(2 * c3), std::vector<double>(2 * c3)};
@@ -584,8 +585,10 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
         ns_run[2] = {std::vector<int32_t>((size_t)B3), std::vector<int32_t>((size_t)B3)};
     for (int j = 0; j < n; ++j)
       for (int64_t i = 0; i < B3; ++i) {
-        q3[(size_t)j * B3 + i] = 0.31 + 0.07 * j + 0.004 * (double)i;
-        p3[(size_t)j * B3 + i] = 0.23 - 0.05 * j + 0.003 * (double)i;
+        const double u = std::fmod(0.6180339887498949 * (double)(i + 1) + 0.37 * j, 1.0);     // low-discrepancy in [0, 1)
+        const double w = std::fmod(0.7548776662466927 * (double)(i + 1) + 0.19 * j, 1.0);
+        q3[(size_t)j * B3 + i] = 0.31 + 0.07 * j + 0.29 * u;
+        p3[(size_t)j * B3 + i] = 0.23 - 0.05 * j + 0.29 * w;
       }
     double *e_q = nullptr, *e_p = nullptr; int32_t *e_st = nullptr, *e_ns = nullptr;
     bool alloc_ok = hipMalloc((void**)&e_q, c3 * 8) == hipSuccess && hipMalloc((void**)&e_p, c3 * 8) == hipSuccess &&
@@ -595,7 +598,15 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
     auto download = [&](std::vector<double>& y) { hipMemcpy(y.data(), e_q, c3 * 8, hipMemcpyDeviceToHost); hipMemcpy(y.data() + c3, e_p, c3 * 8, hipMemcpyDeviceToHost); };
     if (alloc_ok) {
       std::vector<double> ref3b(2 * c3);
+      // Between repeated launches a kernel of the module fills every VGPR of every SIMD with launch-dependent
+      // values: a stepping kernel that reads registers it did not write (scripts/probes/sgpr_spill_repro)
+      // agrees with itself back to back and differs once something else has used the registers.
+      auto scribble = [&](unsigned seed) {
+        void* as[] = {&seed};
+        if (hipModuleLaunchKernel(s->cur->fn[K_SCRIBBLE], 2048, 1, 1, 256, 1, 1, 0, s->stream, as, nullptr) != hipSuccess) (void)hipGetLastError();
+      };
       for (int r = 0; r < 2 && rc == HAMK_OK; ++r) {         // the fixed-step kernel, twice as well
+        scribble(0x9e3779b9u * (unsigned)(r + 1));
         upload();
         double ddt = T / 64, no_drift = 0.0; int ns = 64;
         void* a4[] = {&e_q, &e_p, &b3, &ddt, &ns, &no_drift, &e_st};
@@ -609,6 +620,7 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
         g_selfcheck_detail = "two runs of the RK4 kernel on the same input DIFFER";
       }
       for (int r = 0; r < 2 && rc == HAMK_OK; ++r) {
+        scribble(0x85ebca6bu * (unsigned)(r + 3));
         upload();
         double h0 = T / 100, ea = kRefEpsilon, er = kRefEpsilon, t0 = 0.0, t1 = T;
         int nt = 2, row0 = 1, inplace = 1, max_sub = 4096, api = s->gsl_api;

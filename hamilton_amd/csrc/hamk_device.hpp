@@ -1446,6 +1446,117 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
 
 }  // namespace hamk
 
+// Leaves launch-dependent garbage in every VGPR (v2-v255) of the SIMDs it runs on.  The first-use
+// self-check (hamk_api.cpp) runs it between repeated launches of the stepping kernels: a kernel whose
+// result depends on what its predecessor left in the registers -- exactly the defect once met on this
+// toolchain, scripts/probes/sgpr_spill_repro -- agrees with itself when launched back to back and is
+// only caught when something else used the registers in between.
+#ifndef HAMK_HOST_EMULATION
+#define HAMK_SCRIBBLE_BODY \
+  "v_add_u32 v2, 15839, %0\n" "v_add_u32 v3, 23758, %0\n" "v_add_u32 v4, 31677, %0\n" "v_add_u32 v5, 39596, \
+  %0\n" "v_add_u32 v6, 47515, %0\n" "v_add_u32 v7, 55434, %0\n" "v_add_u32 v8, 63353, %0\n" "v_add_u32 v9, \
+  71272, %0\n" "v_add_u32 v10, 79191, %0\n" "v_add_u32 v11, 87110, %0\n" "v_add_u32 v12, 95029, %0\n" "v_add_u32 \
+  v13, 102948, %0\n" "v_add_u32 v14, 110867, %0\n" "v_add_u32 v15, 118786, %0\n" "v_add_u32 v16, 126705, %0\n" \
+  "v_add_u32 v17, 134624, %0\n" "v_add_u32 v18, 142543, %0\n" "v_add_u32 v19, 150462, %0\n" "v_add_u32 v20, \
+  158381, %0\n" "v_add_u32 v21, 166300, %0\n" "v_add_u32 v22, 174219, %0\n" "v_add_u32 v23, 182138, %0\n" \
+  "v_add_u32 v24, 190057, %0\n" "v_add_u32 v25, 197976, %0\n" "v_add_u32 v26, 205895, %0\n" "v_add_u32 v27, \
+  213814, %0\n" "v_add_u32 v28, 221733, %0\n" "v_add_u32 v29, 229652, %0\n" "v_add_u32 v30, 237571, %0\n" \
+  "v_add_u32 v31, 245490, %0\n" "v_add_u32 v32, 253409, %0\n" "v_add_u32 v33, 261328, %0\n" "v_add_u32 v34, \
+  269247, %0\n" "v_add_u32 v35, 277166, %0\n" "v_add_u32 v36, 285085, %0\n" "v_add_u32 v37, 293004, %0\n" \
+  "v_add_u32 v38, 300923, %0\n" "v_add_u32 v39, 308842, %0\n" "v_add_u32 v40, 316761, %0\n" "v_add_u32 v41, \
+  324680, %0\n" "v_add_u32 v42, 332599, %0\n" "v_add_u32 v43, 340518, %0\n" "v_add_u32 v44, 348437, %0\n" \
+  "v_add_u32 v45, 356356, %0\n" "v_add_u32 v46, 364275, %0\n" "v_add_u32 v47, 372194, %0\n" "v_add_u32 v48, \
+  380113, %0\n" "v_add_u32 v49, 388032, %0\n" "v_add_u32 v50, 395951, %0\n" "v_add_u32 v51, 403870, %0\n" \
+  "v_add_u32 v52, 411789, %0\n" "v_add_u32 v53, 419708, %0\n" "v_add_u32 v54, 427627, %0\n" "v_add_u32 v55, \
+  435546, %0\n" "v_add_u32 v56, 443465, %0\n" "v_add_u32 v57, 451384, %0\n" "v_add_u32 v58, 459303, %0\n" \
+  "v_add_u32 v59, 467222, %0\n" "v_add_u32 v60, 475141, %0\n" "v_add_u32 v61, 483060, %0\n" "v_add_u32 v62, \
+  490979, %0\n" "v_add_u32 v63, 498898, %0\n" "v_add_u32 v64, 506817, %0\n" "v_add_u32 v65, 514736, %0\n" \
+  "v_add_u32 v66, 522655, %0\n" "v_add_u32 v67, 530574, %0\n" "v_add_u32 v68, 538493, %0\n" "v_add_u32 v69, \
+  546412, %0\n" "v_add_u32 v70, 554331, %0\n" "v_add_u32 v71, 562250, %0\n" "v_add_u32 v72, 570169, %0\n" \
+  "v_add_u32 v73, 578088, %0\n" "v_add_u32 v74, 586007, %0\n" "v_add_u32 v75, 593926, %0\n" "v_add_u32 v76, \
+  601845, %0\n" "v_add_u32 v77, 609764, %0\n" "v_add_u32 v78, 617683, %0\n" "v_add_u32 v79, 625602, %0\n" \
+  "v_add_u32 v80, 633521, %0\n" "v_add_u32 v81, 641440, %0\n" "v_add_u32 v82, 649359, %0\n" "v_add_u32 v83, \
+  657278, %0\n" "v_add_u32 v84, 665197, %0\n" "v_add_u32 v85, 673116, %0\n" "v_add_u32 v86, 681035, %0\n" \
+  "v_add_u32 v87, 688954, %0\n" "v_add_u32 v88, 696873, %0\n" "v_add_u32 v89, 704792, %0\n" "v_add_u32 v90, \
+  712711, %0\n" "v_add_u32 v91, 720630, %0\n" "v_add_u32 v92, 728549, %0\n" "v_add_u32 v93, 736468, %0\n" \
+  "v_add_u32 v94, 744387, %0\n" "v_add_u32 v95, 752306, %0\n" "v_add_u32 v96, 760225, %0\n" "v_add_u32 v97, \
+  768144, %0\n" "v_add_u32 v98, 776063, %0\n" "v_add_u32 v99, 783982, %0\n" "v_add_u32 v100, 791901, %0\n" \
+  "v_add_u32 v101, 799820, %0\n" "v_add_u32 v102, 807739, %0\n" "v_add_u32 v103, 815658, %0\n" "v_add_u32 v104, \
+  823577, %0\n" "v_add_u32 v105, 831496, %0\n" "v_add_u32 v106, 839415, %0\n" "v_add_u32 v107, 847334, %0\n" \
+  "v_add_u32 v108, 855253, %0\n" "v_add_u32 v109, 863172, %0\n" "v_add_u32 v110, 871091, %0\n" "v_add_u32 v111, \
+  879010, %0\n" "v_add_u32 v112, 886929, %0\n" "v_add_u32 v113, 894848, %0\n" "v_add_u32 v114, 902767, %0\n" \
+  "v_add_u32 v115, 910686, %0\n" "v_add_u32 v116, 918605, %0\n" "v_add_u32 v117, 926524, %0\n" "v_add_u32 v118, \
+  934443, %0\n" "v_add_u32 v119, 942362, %0\n" "v_add_u32 v120, 950281, %0\n" "v_add_u32 v121, 958200, %0\n" \
+  "v_add_u32 v122, 966119, %0\n" "v_add_u32 v123, 974038, %0\n" "v_add_u32 v124, 981957, %0\n" "v_add_u32 v125, \
+  989876, %0\n" "v_add_u32 v126, 997795, %0\n" "v_add_u32 v127, 1005714, %0\n" "v_add_u32 v128, 1013633, %0\n" \
+  "v_add_u32 v129, 1021552, %0\n" "v_add_u32 v130, 1029471, %0\n" "v_add_u32 v131, 1037390, %0\n" "v_add_u32 \
+  v132, 1045309, %0\n" "v_add_u32 v133, 1053228, %0\n" "v_add_u32 v134, 1061147, %0\n" "v_add_u32 v135, 1069066, \
+  %0\n" "v_add_u32 v136, 1076985, %0\n" "v_add_u32 v137, 1084904, %0\n" "v_add_u32 v138, 1092823, %0\n" \
+  "v_add_u32 v139, 1100742, %0\n" "v_add_u32 v140, 1108661, %0\n" "v_add_u32 v141, 1116580, %0\n" "v_add_u32 \
+  v142, 1124499, %0\n" "v_add_u32 v143, 1132418, %0\n" "v_add_u32 v144, 1140337, %0\n" "v_add_u32 v145, 1148256, \
+  %0\n" "v_add_u32 v146, 1156175, %0\n" "v_add_u32 v147, 1164094, %0\n" "v_add_u32 v148, 1172013, %0\n" \
+  "v_add_u32 v149, 1179932, %0\n" "v_add_u32 v150, 1187851, %0\n" "v_add_u32 v151, 1195770, %0\n" "v_add_u32 \
+  v152, 1203689, %0\n" "v_add_u32 v153, 1211608, %0\n" "v_add_u32 v154, 1219527, %0\n" "v_add_u32 v155, 1227446, \
+  %0\n" "v_add_u32 v156, 1235365, %0\n" "v_add_u32 v157, 1243284, %0\n" "v_add_u32 v158, 1251203, %0\n" \
+  "v_add_u32 v159, 1259122, %0\n" "v_add_u32 v160, 1267041, %0\n" "v_add_u32 v161, 1274960, %0\n" "v_add_u32 \
+  v162, 1282879, %0\n" "v_add_u32 v163, 1290798, %0\n" "v_add_u32 v164, 1298717, %0\n" "v_add_u32 v165, 1306636, \
+  %0\n" "v_add_u32 v166, 1314555, %0\n" "v_add_u32 v167, 1322474, %0\n" "v_add_u32 v168, 1330393, %0\n" \
+  "v_add_u32 v169, 1338312, %0\n" "v_add_u32 v170, 1346231, %0\n" "v_add_u32 v171, 1354150, %0\n" "v_add_u32 \
+  v172, 1362069, %0\n" "v_add_u32 v173, 1369988, %0\n" "v_add_u32 v174, 1377907, %0\n" "v_add_u32 v175, 1385826, \
+  %0\n" "v_add_u32 v176, 1393745, %0\n" "v_add_u32 v177, 1401664, %0\n" "v_add_u32 v178, 1409583, %0\n" \
+  "v_add_u32 v179, 1417502, %0\n" "v_add_u32 v180, 1425421, %0\n" "v_add_u32 v181, 1433340, %0\n" "v_add_u32 \
+  v182, 1441259, %0\n" "v_add_u32 v183, 1449178, %0\n" "v_add_u32 v184, 1457097, %0\n" "v_add_u32 v185, 1465016, \
+  %0\n" "v_add_u32 v186, 1472935, %0\n" "v_add_u32 v187, 1480854, %0\n" "v_add_u32 v188, 1488773, %0\n" \
+  "v_add_u32 v189, 1496692, %0\n" "v_add_u32 v190, 1504611, %0\n" "v_add_u32 v191, 1512530, %0\n" "v_add_u32 \
+  v192, 1520449, %0\n" "v_add_u32 v193, 1528368, %0\n" "v_add_u32 v194, 1536287, %0\n" "v_add_u32 v195, 1544206, \
+  %0\n" "v_add_u32 v196, 1552125, %0\n" "v_add_u32 v197, 1560044, %0\n" "v_add_u32 v198, 1567963, %0\n" \
+  "v_add_u32 v199, 1575882, %0\n" "v_add_u32 v200, 1583801, %0\n" "v_add_u32 v201, 1591720, %0\n" "v_add_u32 \
+  v202, 1599639, %0\n" "v_add_u32 v203, 1607558, %0\n" "v_add_u32 v204, 1615477, %0\n" "v_add_u32 v205, 1623396, \
+  %0\n" "v_add_u32 v206, 1631315, %0\n" "v_add_u32 v207, 1639234, %0\n" "v_add_u32 v208, 1647153, %0\n" \
+  "v_add_u32 v209, 1655072, %0\n" "v_add_u32 v210, 1662991, %0\n" "v_add_u32 v211, 1670910, %0\n" "v_add_u32 \
+  v212, 1678829, %0\n" "v_add_u32 v213, 1686748, %0\n" "v_add_u32 v214, 1694667, %0\n" "v_add_u32 v215, 1702586, \
+  %0\n" "v_add_u32 v216, 1710505, %0\n" "v_add_u32 v217, 1718424, %0\n" "v_add_u32 v218, 1726343, %0\n" \
+  "v_add_u32 v219, 1734262, %0\n" "v_add_u32 v220, 1742181, %0\n" "v_add_u32 v221, 1750100, %0\n" "v_add_u32 \
+  v222, 1758019, %0\n" "v_add_u32 v223, 1765938, %0\n" "v_add_u32 v224, 1773857, %0\n" "v_add_u32 v225, 1781776, \
+  %0\n" "v_add_u32 v226, 1789695, %0\n" "v_add_u32 v227, 1797614, %0\n" "v_add_u32 v228, 1805533, %0\n" \
+  "v_add_u32 v229, 1813452, %0\n" "v_add_u32 v230, 1821371, %0\n" "v_add_u32 v231, 1829290, %0\n" "v_add_u32 \
+  v232, 1837209, %0\n" "v_add_u32 v233, 1845128, %0\n" "v_add_u32 v234, 1853047, %0\n" "v_add_u32 v235, 1860966, \
+  %0\n" "v_add_u32 v236, 1868885, %0\n" "v_add_u32 v237, 1876804, %0\n" "v_add_u32 v238, 1884723, %0\n" \
+  "v_add_u32 v239, 1892642, %0\n" "v_add_u32 v240, 1900561, %0\n" "v_add_u32 v241, 1908480, %0\n" "v_add_u32 \
+  v242, 1916399, %0\n" "v_add_u32 v243, 1924318, %0\n" "v_add_u32 v244, 1932237, %0\n" "v_add_u32 v245, 1940156, \
+  %0\n" "v_add_u32 v246, 1948075, %0\n" "v_add_u32 v247, 1955994, %0\n" "v_add_u32 v248, 1963913, %0\n" \
+  "v_add_u32 v249, 1971832, %0\n" "v_add_u32 v250, 1979751, %0\n" "v_add_u32 v251, 1987670, %0\n" "v_add_u32 \
+  v252, 1995589, %0\n" "v_add_u32 v253, 2003508, %0\n" "v_add_u32 v254, 2011427, %0\n" "v_add_u32 v255, 2019346, \
+  %0\n"
+#define HAMK_SCRIBBLE_CLOBBERS \
+  "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", \
+  "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", \
+  "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", \
+  "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", \
+  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", \
+  "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", \
+  "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", \
+  "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", \
+  "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", \
+  "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", \
+  "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", \
+  "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", \
+  "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", \
+  "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", \
+  "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", \
+  "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", \
+  "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", \
+  "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", \
+  "v251", "v252", "v253", "v254", "v255"
+#define HAMK_SCRIBBLE_KERNEL                                                                                       \
+  extern "C" __global__ void __launch_bounds__(256) hamk_scribble_k(unsigned seed) {                               \
+    unsigned x = seed * 2654435761u + threadIdx.x * 40503u + blockIdx.x;                                          \
+    asm volatile(HAMK_SCRIBBLE_BODY : : "v"(x) : HAMK_SCRIBBLE_CLOBBERS);                                         \
+  }
+#else
+#define HAMK_SCRIBBLE_KERNEL extern "C" void hamk_scribble_k(unsigned) {}
+#endif
+
 // Instantiates the extern "C" kernels of one system; the generated translation
 // unit ends with HAMK_INSTANTIATE(HamkSys).
 // NOTE: do not spell the default as __launch_bounds__(256, 1): with an explicit "1 wave per SIMD"
@@ -1457,6 +1568,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
 #define HAMK_RK4_BOUNDS __launch_bounds__(256)
 #endif
 #define HAMK_INSTANTIATE(S)                                                                                      \
+  HAMK_SCRIBBLE_KERNEL                                                                                           \
   extern "C" __global__ void HAMK_RK4_BOUNDS hamk_rk4_steps_k(double* q, double* p, long long B, double dt,      \
                                                               int nsteps, double drift_tol, int* status) {       \
     hamk::rk4_body<S>(q, p, B, dt, nsteps, drift_tol, status);                                                   \

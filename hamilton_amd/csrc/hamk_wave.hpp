@@ -787,6 +787,7 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
 #define HAMK_RK4_MIN_WAVES 2
 #endif
 #define HAMK_INSTANTIATE_WAVE(S)                                                                                 \
+  HAMK_SCRIBBLE_KERNEL                                                                                           \
   extern "C" __global__ void __launch_bounds__(256, HAMK_RK4_MIN_WAVES) hamk_rk4_steps_k(double* q, double* p, long long B, \
                                                           double dt, int nsteps, double drift_tol, int* status) { \
     HAMK_WAVE_SMEM(S);                                                                                           \

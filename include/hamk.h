@@ -185,8 +185,8 @@ int64_t hamk_system_code_object(const hamk_system* s, int32_t which, void* buf, 
  * MachineLICM when that spills fewer SGPRs), its code bytes and its spilled SGPRs.             */
 const char* hamk_system_build_info(const hamk_system* s);
 /* Machine-code bytes of one kernel of the module ("hamk_rk4_steps_k", ...); 0 if unknown.
- * kernel_name == NULL: number of function symbols in the module (8 = every device function
- * was inlined into the 8 kernels).                                                          */
+ * kernel_name == NULL: number of function symbols in the module (9 = every device function
+ * was inlined into the 8 kernels of the path; the ninth is the self-check's scribble kernel).                                                          */
 int64_t hamk_system_kernel_bytes(const hamk_system* s, const char* kernel_name);
 
 /* ---- state functions ------------------------------------------------------ */
