@@ -15,7 +15,7 @@ def fv(xs):
 
 rows = []
 for name in ["pendulum", "doublePendulum", "room", "twoBody", "spring", "bezier", "threeBodyPolar", "chain4", "opcodeZoo",
-             "chain8", "chain12", "chain20", "chain32"]:
+             "chain8", "chain12", "chain16", "chain20", "chain32"]:
     spec = E.get(name); s = api.system_from_spec(spec); o = oracle.OracleSystem(spec)
     B = 2048 if spec.n <= 8 else 256
     q, qd = E.sample_config(spec, 4242, B)
@@ -34,6 +34,14 @@ for name in ["pendulum", "doublePendulum", "room", "twoBody", "spring", "bezier"
     same = np.asarray(s.last_nsub) == sns
     r["stepHam_same_substeps"] = float(same.mean())
     r["stepHam"] = max(rel(st.positions[:, same], sq[:, same]), rel(st.momenta[:, same], sp[:, same]))
+    ts = np.array([0.0, 3 * spec.dt, 7 * spec.dt, 7 * spec.dt, 12 * spec.dt])
+    for gsl in (2, 1):                                   # evolveHam under both bindings of hmatrix-gsl's gsl-ode.c
+        s.gsl_api = gsl; o.gsl_api = gsl
+        rows_ = api.evolveHam(s, api.Phase(q, p), ts); eq_, ep_, ens = o.evolve_ham_batch(q, p, ts)
+        same = np.asarray(s.last_nsub) == ens
+        r[f"evolveHam_api{gsl}_same_substeps"] = float(same.mean())
+        r[f"evolveHam_api{gsl}"] = max(max(rel(rows_[k].positions[:, same], eq_[k][:, same]), rel(rows_[k].momenta[:, same], ep_[k][:, same])) for k in range(1, len(ts)))
+    s.gsl_api = 2; o.gsl_api = 2
     gpath = os.path.join(ROOT, "tests", "golden", f"{name}.json")
     if os.path.exists(gpath):
         pts = json.load(open(gpath))["points"]
