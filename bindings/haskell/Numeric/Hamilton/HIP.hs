@@ -169,10 +169,10 @@ data TapeSt = TapeSt !(Seq.Seq Op) !(M.Map (Int32, Int32, Int32, Word64) Int32)
 
 opConst, opInput, opAdd, opSub, opMul, opDiv, opNeg, opRecip, opSin, opCos, opTan, opAsin, opAcos,
   opAtan, opSinh, opCosh, opTanh, opExp, opLog, opSqrt, opPowC, opPowI, opPow, opAtan2, opAsinh,
-  opAcosh, opAtanh :: Int32
+  opAcosh, opAtanh, opAbs, opSignum :: Int32
 [ opConst, opInput, opAdd, opSub, opMul, opDiv, opNeg, opRecip, opSin, opCos, opTan, opAsin, opAcos
   , opAtan, opSinh, opCosh, opTanh, opExp, opLog, opSqrt, opPowC, opPowI, opPow, opAtan2, opAsinh
-  , opAcosh, opAtanh ] = [0 .. 26]
+  , opAcosh, opAtanh, opAbs, opSignum ] = [0 .. 28]
 
 emit :: IORef TapeSt -> Op -> Int32
 emit ref o@(Op c a b d) = unsafePerformIO $ atomicModifyIORef' ref $ \st@(TapeSt ops memo) ->
@@ -241,8 +241,8 @@ instance Num Traced where
   (-) = bin opSub (-)
   (*) = bin opMul (*)
   negate = neg
-  abs _ = untraceable "abs"
-  signum _ = untraceable "signum"
+  abs = un opAbs abs             -- recorded: derivative signum x, as `ad` differentiates it
+  signum = un opSignum signum
   fromInteger = K . fromInteger
 
 instance Fractional Traced where

@@ -43,6 +43,8 @@ static const char* unary_name(int op) {
     case HAMK_OP_EXP: return "exp";
     case HAMK_OP_LOG: return "log";
     case HAMK_OP_SQRT: return "sqrt";
+    case HAMK_OP_ABS: return "abs";
+    case HAMK_OP_SIGNUM: return "signum";
     default: return nullptr;
   }
 }
@@ -211,6 +213,7 @@ double fold_const(const hamk_op& p, double a, double b) {
     case HAMK_OP_EXP: return std::exp(a);   case HAMK_OP_LOG: return std::log(a);   case HAMK_OP_SQRT: return std::sqrt(a);
     case HAMK_OP_POWC: return std::pow(a, p.c); case HAMK_OP_POWI: return host_ipow(a, p.b);
     case HAMK_OP_POW: return std::pow(a, b);    case HAMK_OP_ATAN2: return std::atan2(a, b);
+    case HAMK_OP_ABS: return std::fabs(a);      case HAMK_OP_SIGNUM: return (double)((a > 0) - (a < 0));
     default: return std::nan("");
   }
 }
@@ -260,7 +263,8 @@ const char* d2_name(int op) {
     case HAMK_OP_ACOS: return "acos"; case HAMK_OP_ATAN: return "atan"; case HAMK_OP_SINH: return "sinh";
     case HAMK_OP_COSH: return "cosh"; case HAMK_OP_TANH: return "tanh"; case HAMK_OP_ASINH: return "asinh";
     case HAMK_OP_ACOSH: return "acosh"; case HAMK_OP_ATANH: return "atanh"; case HAMK_OP_EXP: return "exp";
-    case HAMK_OP_LOG: return "log"; case HAMK_OP_SQRT: return "sqrt"; default: return nullptr;
+    case HAMK_OP_LOG: return "log"; case HAMK_OP_SQRT: return "sqrt"; case HAMK_OP_ABS: return "abs";
+    case HAMK_OP_SIGNUM: return "signum"; default: return nullptr;
   }
 }
 }  // namespace

@@ -590,6 +590,10 @@ HAMK_DEV void d2_tanh(double x, double& g0, double& g1, double& g2) { const doub
 HAMK_DEV void d2_asinh(double x, double& g0, double& g1, double& g2) { const double w = fma(x, x, 1.0), r = ::rsqrt(w); g0 = ::asinh(x); g1 = r; g2 = -x * r / w; }
 HAMK_DEV void d2_acosh(double x, double& g0, double& g1, double& g2) { const double w = fma(x, x, -1.0), r = ::rsqrt(w); g0 = ::acosh(x); g1 = r; g2 = -x * r / w; }
 HAMK_DEV void d2_atanh(double x, double& g0, double& g1, double& g2) { const double w = 1.0 / fma(-x, x, 1.0); g0 = ::atanh(x); g1 = w; g2 = 2.0 * x * w * w; }
+// |x| and signum x (Num methods): derivative of |x| is signum x, every higher derivative 0 (at x = 0: signum 0 = 0, as `ad` has it)
+HAMK_DEV double signum_f64(double x) { return (x > 0.0) ? 1.0 : ((x < 0.0) ? -1.0 : 0.0); }
+HAMK_DEV void d2_abs(double x, double& g0, double& g1, double& g2) { g0 = fabs(x); g1 = signum_f64(x); g2 = 0.0; }
+HAMK_DEV void d2_signum(double x, double& g0, double& g1, double& g2) { g0 = signum_f64(x); g1 = 0.0; g2 = 0.0; }
 HAMK_DEV void d2_exp(double x, double& g0, double& g1, double& g2) { const double e = ::exp(x); g0 = e; g1 = e; g2 = e; }
 HAMK_DEV void d2_log(double x, double& g0, double& g1, double& g2) { const double r = 1.0 / x; g0 = ::log(x); g1 = r; g2 = -r * r; }
 HAMK_DEV void d2_sqrt(double x, double& g0, double& g1, double& g2) { const double r = ::sqrt(x); g0 = r; g1 = 0.5 / r; g2 = -0.5 * g1 / x; }
@@ -626,6 +630,7 @@ HAMK_DEV void d2_atan2(double y, double x, double& f0, double& fa, double& fb, d
   }
 HAMK_UNARY(tan) HAMK_UNARY(asin) HAMK_UNARY(acos) HAMK_UNARY(atan) HAMK_UNARY(sinh) HAMK_UNARY(cosh)
 HAMK_UNARY(tanh) HAMK_UNARY(asinh) HAMK_UNARY(acosh) HAMK_UNARY(atanh) HAMK_UNARY(exp) HAMK_UNARY(log) HAMK_UNARY(sqrt)
+HAMK_UNARY(abs) HAMK_UNARY(signum)
 #undef HAMK_UNARY
 
 template <int K, class A> HAMK_DEV A powi(const A& x) {

@@ -374,3 +374,25 @@ def opcode_zoo() -> SystemSpec:
 
 
 REGISTRY["opcodeZoo"] = opcode_zoo
+
+
+def abs_zoo() -> SystemSpec:
+    """Not a physical example: a System 3 2 whose coordinate map and potential use the two Num methods
+    the reference's own systems never call -- `abs` and `signum` (opcodes 27, 28; derivative of |x| is
+    signum x, as `ad` differentiates it).  The sampling box stays away from the kinks at 0."""
+    def f(q, o):
+        a, b = q
+        return [a + 0.2 * abs(b), b + 0.1 * abs(a) * a, abs(a - b) + 0.3 * o.sin(a)]
+
+    def u(q, o):
+        a, b = q
+        return abs(a) * abs(b) + 0.3 * o.signum(b) * b ** 2 + abs(o.cos(a + b))
+
+    return SystemSpec(
+        name="absZoo", m=3, n=2, inertia=(1.0, 2.0, 1.5), f=f, u=u, u_space=U_GENERALIZED,
+        q0=(0.5, -0.6), qd0=(0.2, -0.3),
+        q_box=((0.3, 0.9), (-1.0, -0.35)), qd_box=((-0.5, 0.5), (-0.5, 0.5)),
+        cite="build-defined (hamk_opcode 27, 28)")
+
+
+REGISTRY["absZoo"] = abs_zoo

@@ -24,6 +24,7 @@ OP_CONST, OP_INPUT, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_RECIP = range(8)
 OP_SIN, OP_COS, OP_TAN, OP_ASIN, OP_ACOS, OP_ATAN = range(8, 14)
 OP_SINH, OP_COSH, OP_TANH, OP_EXP, OP_LOG, OP_SQRT = range(14, 20)
 OP_POWC, OP_POWI, OP_POW, OP_ATAN2, OP_ASINH, OP_ACOSH, OP_ATANH = range(20, 27)
+OP_ABS, OP_SIGNUM = 27, 28
 
 OP_NAMES = {
     OP_CONST: "const", OP_INPUT: "input", OP_ADD: "add", OP_SUB: "sub", OP_MUL: "mul",
@@ -31,7 +32,7 @@ OP_NAMES = {
     OP_TAN: "tan", OP_ASIN: "asin", OP_ACOS: "acos", OP_ATAN: "atan", OP_SINH: "sinh",
     OP_COSH: "cosh", OP_TANH: "tanh", OP_EXP: "exp", OP_LOG: "log", OP_SQRT: "sqrt",
     OP_POWC: "powc", OP_POWI: "powi", OP_POW: "pow", OP_ATAN2: "atan2",
-    OP_ASINH: "asinh", OP_ACOSH: "acosh", OP_ATANH: "atanh",
+    OP_ASINH: "asinh", OP_ACOSH: "acosh", OP_ATANH: "atanh", OP_ABS: "abs", OP_SIGNUM: "signum",
 }
 
 
@@ -165,6 +166,8 @@ _EVAL = {
     OP_ASINH: lambda v, xs, a, b, c: math.asinh(v[a]),
     OP_ACOSH: lambda v, xs, a, b, c: math.acosh(v[a]),
     OP_ATANH: lambda v, xs, a, b, c: math.atanh(v[a]),
+    OP_ABS: lambda v, xs, a, b, c: abs(v[a]),
+    OP_SIGNUM: lambda v, xs, a, b, c: float((v[a] > 0) - (v[a] < 0)),
 }
 
 
@@ -329,8 +332,11 @@ class Var:
     __float__ = _no_ord
 
     def __abs__(self):
-        raise TypeError("abs/signum of a traced value: |x| is not differentiable at 0 and the tape has no opcode for it "
-                        "(the reference's systems do not use it); write sqrt(x * x) if a smooth-enough |x| is meant")
+        """Num.abs: recorded (derivative signum x, as `ad` differentiates it; not differentiable at 0)."""
+        c = self._cv()
+        if c is not None:
+            return self.tape.const(abs(c))
+        return Var(self.tape, self.tape.emit(OP_ABS, self.idx))
 
     def __repr__(self):
         return f"Var(v{self.idx})"
@@ -364,6 +370,7 @@ exp = _unary(OP_EXP, math.exp)
 log = _unary(OP_LOG, math.log)
 sqrt = _unary(OP_SQRT, math.sqrt)
 recip = _unary(OP_RECIP, lambda v: 1.0 / v)
+signum = _unary(OP_SIGNUM, lambda v: float((v > 0) - (v < 0)))
 
 
 def powi(x, k: int):

@@ -206,6 +206,9 @@ HAMILTON_UNARY(exp, HAMK_OP_EXP)
 HAMILTON_UNARY(log, HAMK_OP_LOG)
 HAMILTON_UNARY(sqrt, HAMK_OP_SQRT)
 #undef HAMILTON_UNARY
+// Num's abs and signum (derivative of |x|: signum x, as `ad` has it)
+inline Var abs(const Var& x) { return detail::unary(HAMK_OP_ABS, x, [](double v) { return std::fabs(v); }); }
+inline Var signum(const Var& x) { return detail::unary(HAMK_OP_SIGNUM, x, [](double v) { return (double)((v > 0) - (v < 0)); }); }
 
 // x ^ k (Haskell `^` / `^^`)
 inline Var powi(const Var& x, int k) {

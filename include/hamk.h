@@ -98,7 +98,8 @@ extern "C" {
 /* ---- expression tape ----------------------------------------------------
  * Op i defines value i; operands a,b are indices of EARLIER values (SSA).
  * The set covers the Num/Fractional/Floating/RealFloat methods a traced
- * Haskell function can emit without comparisons.                            */
+ * Haskell function can emit without comparisons (abs and signum included: they
+ * are Num methods; what cannot be recorded is a BRANCH on a value).                            */
 enum hamk_opcode {
   HAMK_OP_CONST = 0,  /* c                                  */
   HAMK_OP_INPUT = 1,  /* input[a]                           */
@@ -127,6 +128,8 @@ enum hamk_opcode {
   HAMK_OP_ASINH = 24,
   HAMK_OP_ACOSH = 25,
   HAMK_OP_ATANH = 26,
+  HAMK_OP_ABS    = 27, /* |v[a]|     (Num.abs; derivative signum, second derivative 0: not differentiable at 0) */
+  HAMK_OP_SIGNUM = 28, /* signum v[a] (Num.signum: -1, 0, +1; derivatives 0)                                   */
   HAMK_OP__COUNT
 };
 

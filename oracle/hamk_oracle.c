@@ -54,7 +54,7 @@
 typedef struct { int32_t op, a, b, _pad; double c; } orc_op;
 enum { O_CONST = 0, O_INPUT, O_ADD, O_SUB, O_MUL, O_DIV, O_NEG, O_RECIP, O_SIN, O_COS, O_TAN,
        O_ASIN, O_ACOS, O_ATAN, O_SINH, O_COSH, O_TANH, O_EXP, O_LOG, O_SQRT, O_POWC, O_POWI,
-       O_POW, O_ATAN2, O_ASINH, O_ACOSH, O_ATANH, O__COUNT };
+       O_POW, O_ATAN2, O_ASINH, O_ACOSH, O_ATANH, O_ABS, O_SIGNUM, O__COUNT };
 
 typedef struct orc_system {
   int m, n, u_space;
@@ -165,6 +165,8 @@ static void tape_eval(int n, const orc_op* ops, int nops, const hd* in, hd* val)
       case O_ASINH: { double w = a->v * a->v + 1, r = 1 / sqrt(w); hd_unary(n, y, a, asinh(a->v), r, -a->v * r / w); } break;
       case O_ACOSH: { double w = a->v * a->v - 1, r = 1 / sqrt(w); hd_unary(n, y, a, acosh(a->v), r, -a->v * r / w); } break;
       case O_ATANH: { double w = 1 - a->v * a->v; hd_unary(n, y, a, atanh(a->v), 1 / w, 2 * a->v / (w * w)); } break;
+      case O_ABS: { double sg = (a->v > 0) - (a->v < 0); hd_unary(n, y, a, fabs(a->v), sg, 0.0); } break;        /* ad: abs' = signum */
+      case O_SIGNUM: { double sg = (a->v > 0) - (a->v < 0); hd_unary(n, y, a, sg, 0.0, 0.0); } break;
       case O_EXP: { double e = exp(a->v); hd_unary(n, y, a, e, e, e); } break;
       case O_LOG: { double r = 1.0 / a->v; hd_unary(n, y, a, log(a->v), r, -r * r); } break;
       case O_SQRT: { double r = sqrt(a->v); hd_unary(n, y, a, r, 0.5 / r, -0.25 / (r * a->v)); } break;

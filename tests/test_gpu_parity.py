@@ -93,6 +93,24 @@ def test_hameqs_vs_oracle_ensemble(api, systems, name):
     assert relerr(api.underlyingPos(s, q), o.coords_batch(q)) < T1
 
 
+def test_abs_and_signum_opcodes(api, oracle_lib):
+    """Opcodes 27 / 28 (Num.abs, Num.signum; no reference system uses them) on the GPU vs the oracle."""
+    spec = E.get("absZoo")
+    s, o = api.system_from_spec(spec), oracle_lib.OracleSystem(spec)
+    q, qd = E.sample_config(spec, 7, 777)
+    p = api.momenta(s, api.Config(q, qd))
+    assert relerr(p, o.to_phase_batch(q, qd)) < T1
+    dq, dp = api.hamEqs(s, api.Phase(q, p))
+    odq, odp, _ = o.hameqs_batch(q, p)
+    assert relerr(dq, odq) < 1e-11 and relerr(dp, odp) < 1e-11 and not np.any(s.last_status)
+    ph = api.rk4Steps(spec.dt, 5, s, api.Phase(q, p))
+    oq, op = o.rk4_steps_batch(q, p, spec.dt, 5)
+    assert relerr(ph.positions, oq) < 1e-12 and relerr(ph.momenta, op) < 1e-12
+    st = api.stepHam(0.02, s, api.Phase(q, p))
+    sq, sp, sns = o.step_ham_batch(q, p, 0.02)
+    assert np.array_equal(np.asarray(s.last_nsub), sns) and relerr(st.positions, sq) < 1e-11
+
+
 # ---------------------------------------------------------------- T2/T3: RK4
 @pytest.mark.parametrize("name", REFERENCE_SYSTEMS + ["threeBodyPolar"])
 def test_rk4_vs_oracle(api, systems, name):
@@ -447,7 +465,7 @@ def test_all_codegen_variants_agree(api, oracle_lib, name, monkeypatch):
     """MODE_H (full second-order jets), MODE_D (two sweeps, directional jets, trig cache) and MODE_R
     (second sweep in reverse mode: generated adjoint code), each with the unrolled and the
     stage-loop RK4 body, against the oracle: every derivative rule of every jet type and of the
-    reverse sweep is exercised by opcodeZoo (all 27 tape opcodes)."""
+    reverse sweep is exercised by opcodeZoo (tape opcodes 0-26; abs / signum: test_abs_and_signum_opcodes)."""
     spec = E.get(name)
     o = oracle_lib.OracleSystem(spec)
     B = 257

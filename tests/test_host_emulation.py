@@ -231,6 +231,23 @@ def test_fixed_step_loop_over_many_steps_on_host(emulate, oracle_lib, name, loop
     assert np.array_equal(q3, q2) and np.array_equal(p3, p2)
 
 
+def test_abs_and_signum_opcodes_on_host(emulate, oracle_lib):
+    """Opcodes 27 / 28 (Num.abs, Num.signum) through every AD strategy of the device code against the
+    oracle, and the oracle's own derivatives of them against central differences (away from the kinks)."""
+    spec = E.get("absZoo")
+    o = oracle_lib.OracleSystem(spec)
+    q = np.array([0.55, -0.7])
+    g, h = o.grad_pe(q), 1e-6
+    num = np.array([(o.pe(q + h * e) - o.pe(q - h * e)) / (2 * h) for e in np.eye(2)])
+    assert np.max(np.abs(g - num)) < 1e-8
+    J = o.jacobian(q)
+    numJ = np.stack([(o.coords(q + h * e) - o.coords(q - h * e)) / (2 * h) for e in np.eye(2)], axis=1)
+    assert np.max(np.abs(J - numJ)) < 1e-8
+    for mode in ("H", "D", "R"):
+        L, _ = emulate(spec, {"HAMK_AD_MODE": mode})
+        check_against_oracle(L, spec, o, B=32, steps=3, dt_ham=0.02)
+
+
 @pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS)
 def test_device_code_on_host_matches_oracle(emulate, oracle_lib, name):
     spec = E.get(name)

@@ -86,3 +86,14 @@ def test_sampler_is_shard_invariant():
     np.testing.assert_array_equal(q[:, 400:500], q2)
     np.testing.assert_array_equal(qd[:, 400:500], qd2)
     assert np.all(q >= -math.pi) and np.all(q < math.pi) and abs(q.mean()) < 0.2
+
+
+def test_abs_and_signum_are_recorded():
+    """Num's abs / signum are tape opcodes (27, 28): recorded, folded on constants, evaluated; what a
+    traced function still cannot do is BRANCH on a value."""
+    t = T.trace(lambda q: [abs(q[0]) * T.signum(q[1]) + abs(-2.5), T.signum(q[0] * 0 + 3.0)], 2, 2)
+    ops = [o[0] for o in t.ops]
+    assert T.OP_ABS in ops and T.OP_SIGNUM in ops
+    assert t.evaluate([-1.5, -0.2]) == [-1.5 + 2.5, 1.0] and t.evaluate([0.7, 4.0]) == [0.7 + 2.5, 1.0]
+    with pytest.raises(TypeError):
+        T.trace(lambda q: [q[0] if q[0] > 0 else -q[0]], 1, 1)
