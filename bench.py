@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the all-cores baseline leg")
     ap.add_argument("--no-isa", action="store_true", help="skip the instruction count of the stepping loop (roofline.fp64)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path "
+                         "(barrier, max-over-ranks, final all_gather) on a 1-GPU box")
     ap.add_argument("--drift-tol", type=float, default=1e-3,
                     help="per-launch energy check of the timed launches (HAMK_ST_DRIFT); 0 = plain hamk_rk4_steps")
     a = ap.parse_args()
@@ -180,8 +183,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
