@@ -22,15 +22,18 @@
 //     K^-1 or the m x n x n Hessian tensor;
 //   * classic RK4 (BASELINE.json north_star) and GSL-semantics adaptive RKF45
 //     (stepHam/evolveHam, Hamilton.hs:390-462) stepping loops around it;
-//   * an fp64 sincos written for this path (sincos_f64) and its anchored
-//     incremental form for Runge-Kutta stage points (sincos_incr).
+//   * an fp64 sincos written for this path (sincos_f64), and what the stepping
+//     kernels make of it: a 512-pair table in LDS (sincos_lut: 22 instructions per
+//     full-accuracy evaluation) and rotations about the RK4 step's midpoint
+//     (rotate_pair: 20-23 instructions, no memory traffic) -- see StageTrig.
 // Systems with more than 16 coordinates use the wave-cooperative kernels of
 // hamk_wave.hpp instead (same generated f/U code, one AD direction per lane).
 //
 // Memory: ensemble state is SoA fp64, q[j*B + i]; a wave reads 64 consecutive
 // doubles (512 B) per component -- fully coalesced.  Algorithmic HBM traffic is
 // 32 n bytes per trajectory per launch (read + write one Phase); everything
-// else lives in VGPRs.  The kernels are FP64-VALU bound.
+// else lives in VGPRs, except the read-only sincos table of the stepping kernels
+// (8 KiB of LDS per block).  The kernels are FP64-VALU bound.
 //
 // Compiled per system by hiprtc (hamk_api.cpp) with
 //   -O3 -ffp-contract=fast -fno-honor-nans -fno-signed-zeros
