@@ -151,6 +151,33 @@ def cpu_baseline_leg(spec, s, dt, target_seconds):
     return base, parity
 
 
+def c1_leg(spec, s):
+    """BASELINE config 1 ("plumbing"): ONE trajectory, 1000 x stepHam 0.01 from the reference's initial
+    state (Examples.hs:250-267), through the host-pointer path of the C ABI and through the CPU oracle."""
+    from oracle import oracle
+    o = oracle.OracleSystem(spec)
+    q, p = np.array(spec.q0, dtype=np.float64), np.zeros(spec.n)
+    ph = api.toPhase(s, api.Config(q, np.array(spec.qd0, dtype=np.float64)))
+    q, p = np.asarray(ph.positions, dtype=np.float64), np.asarray(ph.momenta, dtype=np.float64)
+    oq, op = q.copy(), p.copy()
+    for _ in range(20):                                           # warm: pinned arena, module, self-check
+        api.stepHam(0.01, s, api.Phase(q, p))
+    t0 = time.perf_counter()
+    gq, gp = q, p
+    for _ in range(1000):
+        ph = api.stepHam(0.01, s, api.Phase(gq, gp))
+        gq, gp = ph.positions, ph.momenta
+    t_gpu = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(1000):
+        oq, op = o.step_ham(0.01, oq, op)
+    t_cpu = time.perf_counter() - t0
+    return {"workload": "doublePendulum, 1 trajectory, 1000 x stepHam 0.01 (BASELINE.json configs[0])",
+            "gpu_us_per_call": t_gpu * 1e3, "cpu_oracle_us_per_call": t_cpu * 1e3,
+            "max_abs_dphase_after_1000_calls": float(max(np.max(np.abs(gq - oq)), np.max(np.abs(gp - op)))),
+            "note": "host-pointer call through the Python mirror of the C ABI (pinned arena, one launch + one sync per call)"}
+
+
 def stepham_bench(a, s, spec, dt, state, dist, dev, rank, world):
     """Secondary: stepHam(dt) calls/s over the ensemble (GSL-semantics adaptive RKF45 per lane)."""
     ph = state
@@ -344,6 +371,8 @@ def main():
             base, parity = cpu_baseline_leg(spec, s, dt, a.cpu_seconds)
             out["cpu_baseline"] = base
             out["parity"] = parity
+            if a.system == "doublePendulum":
+                out["config1"] = c1_leg(spec, s)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
