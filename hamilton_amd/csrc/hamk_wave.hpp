@@ -1,9 +1,9 @@
 // hamk_wave.hpp -- wave-cooperative kernels for systems with many generalized coordinates
-// (9 <= n <= 32; BASELINE.json config 5, the N-link chain), where one trajectory no longer fits
+// (17 <= n <= 64 by default; BASELINE.json config 5, the N-link chain), where one trajectory no longer fits
 // the registers of one lane (second-order jets of 2N outputs in N directions).
 //
-// Mapping: one trajectory per group of NP = 16 or 32 lanes (G = 64/NP trajectories per
-// wavefront); LANE i OF THE GROUP CARRIES AD DIRECTION e_i.  Every lane runs the same
+// Mapping: one trajectory per group of NP = 16, 32 or 64 lanes (G = 64/NP trajectories per
+// wavefront; n > 32: the whole wavefront, sixteen 16x16 MFMA blocks of which the ten on or above the diagonal are kept); LANE i OF THE GROUP CARRIES AD DIRECTION e_i.  Every lane runs the same
 // generated f/U code -- uniform control flow, the SIMT-friendly way to run forward mode --
 // at the one-direction jets Jet1<1> / Jet2<1>, with its own seed:
 //
@@ -35,7 +35,7 @@ namespace hamk {
 namespace wave {
 
 template <int N> struct Geo {
-  static constexpr int NP = (N <= 16) ? 16 : 32;       // lanes per trajectory
+  static constexpr int NP = (N <= 16) ? 16 : (N <= 32) ? 32 : 64;   // lanes per trajectory
   static constexpr int G = 64 / NP;                    // trajectories per wavefront
   static constexpr int WAVES = 4;                      // wavefronts per 256-thread block
 };
@@ -788,7 +788,7 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
 #endif
 #define HAMK_INSTANTIATE_WAVE(S)                                                                                 \
   HAMK_SCRIBBLE_KERNEL                                                                                           \
-  extern "C" __global__ void __launch_bounds__(256, HAMK_RK4_MIN_WAVES) hamk_rk4_steps_k(double* q, double* p, long long B, \
+  extern "C" __global__ void __launch_bounds__(256, (S::N > 32) ? 1 : HAMK_RK4_MIN_WAVES) hamk_rk4_steps_k(double* q, double* p, long long B, \
                                                           double dt, int nsteps, double drift_tol, int* status) { \
     HAMK_WAVE_SMEM(S);                                                                                           \
     hamk::wave::rk4_body<S>(smem, q, p, B, dt, nsteps, drift_tol, status);                                       \

@@ -69,10 +69,10 @@ def test_malformed_tapes_are_rejected(hamk_lib):
 
 
 def test_sizes_beyond_the_kernels_are_refused(hamk_lib):
-    """n <= 32 (m <= 64 on the wave path): larger systems get HAMK_ERR_UNSUPPORTED and a message, not
+    """n <= 64 (m <= 128 on the wave path): larger systems get HAMK_ERR_UNSUPPORTED and a message, not
     a compile that never ends."""
     from hamilton_amd import _abi, api
-    spec = E.chain(33)
+    spec = E.chain(65)
     with pytest.raises(api.HamkError) as e:
         api.system_from_spec(spec)
     assert e.value.code == _abi.HAMK_ERR_UNSUPPORTED and "supported sizes" in str(e.value)

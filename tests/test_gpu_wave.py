@@ -24,7 +24,8 @@ def relerr(a, b):
 
 
 CASES = [("spring", True), ("threeBodyPolar", True), ("chain4", True), ("opcodeZoo", True),
-         ("chain8", True), ("chain16", True), ("chain32", False)]
+         ("chain8", True), ("chain16", True), ("chain32", False),
+         ("chain33", False), ("chain48", False), ("chain64", False)]      # n > 32: one trajectory per wavefront
 
 
 @pytest.mark.parametrize("name,force", CASES)
@@ -76,7 +77,7 @@ def test_wave_path_matches_golden_and_lane_path(api, monkeypatch):
     assert relerr(dp_w, want_dp) < 1e-11 and relerr(dp_w, dp_l) < 1e-11 and relerr(dq_w, dq_l) < 1e-11
 
 
-@pytest.mark.parametrize("name,force", [("spring", True), ("threeBodyPolar", True), ("chain8", True), ("chain20", False)])
+@pytest.mark.parametrize("name,force", [("spring", True), ("threeBodyPolar", True), ("chain8", True), ("chain20", False), ("chain40", False)])
 def test_wave_adaptive_stepper_vs_oracle(api, oracle_lib, monkeypatch, name, force):
     """stepHam / evolveHam on the wave path: GSL-semantics RKF45 with group-uniform control."""
     spec = E.get(name)

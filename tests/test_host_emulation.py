@@ -464,11 +464,14 @@ def emulate_wave(hamk_lib, tmp_path_factory):
 
 
 @pytest.mark.parametrize("name,force,B", [("spring", True, 9), ("opcodeZoo", True, 6), ("threeBodyPolar", True, 5),
-                                          ("chain8", True, 5), ("chain17", False, 3), ("chain18", False, 2), ("chain32", False, 2)])
+                                          ("chain8", True, 5), ("chain17", False, 3), ("chain18", False, 2), ("chain32", False, 2),
+                                          ("chain33", False, 1),
+                                          pytest.param("chain64", False, 1, marks=pytest.mark.skipif(
+                                              not os.environ.get("HAMK_TEST_SLOW"), reason="68 s of emulated lanes; set HAMK_TEST_SLOW=1 (the GPU suite runs chain64 against the oracle)"))])
 def test_wave_kernels_on_host_match_oracle(emulate_wave, oracle_lib, name, force, B):
     """Lane = AD direction, K = J^T M J through the (emulated) matrix-core instruction, two-pivot LDL^T
     by LDS column broadcast with the forward substitution riding along, four-wide back substitution,
-    group-uniform RKF45 control -- against the oracle, incl. group sizes 16 and 32, padded lanes,
+    group-uniform RKF45 control -- against the oracle, incl. group sizes 16, 32 and 64 (one trajectory per wavefront), padded lanes,
     odd N (single last pivot), N mod 4 != 0 (scalar head of the back substitution), M mod 4 != 0
     (zero-padded MFMA rows), unequal inertias, and ensembles that do not fill the last block."""
     spec = E.get(name)
