@@ -992,6 +992,11 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   // spills (chain16: 4.5e8 vs 7.3e7 steps/s); beyond that one trajectory no longer fits a lane
   s->desc.wave = (n > 16);
   if (const char* e = std::getenv("HAMK_WAVE")) s->desc.wave = (e[0] == '1');      // experiments / tests
+  // LDL^T in panels of 16 with the trailing blocks on the matrix cores (hamk_wave.hpp factor_blocked): measured on
+  // MI355X chain32 5.06e7 -> 5.66e7, chain64 4.6e6 -> 7.6e6 RK4 steps/s (profiles/r02_wave_blocked.jsonl); a single panel
+  // (n <= 16, forced wave path) has nothing to block
+  s->desc.wave_blocked = n > 16;
+  if (const char* e = std::getenv("HAMK_WAVE_BLOCKED")) s->desc.wave_blocked = (e[0] == '1') && n > 16;      // experiments
   s->desc.rk4_stage_loop = (n >= 7);
   if (const char* e = std::getenv("HAMK_RK4_LOOP")) s->desc.rk4_stage_loop = (e[0] == '1');
   if (const char* e = std::getenv("HAMK_RK4_WAVES")) s->desc.rk4_min_waves = std::atoi(e);

@@ -401,6 +401,7 @@ std::string generate_source(const SystemDesc& d) {
   o << "// generated by libhamk (hamk_codegen.cpp) from the expression tape of one System " << d.m << " " << d.n << "\n";
   if (d.rk4_min_waves > 1) o << "#define HAMK_RK4_MIN_WAVES " << d.rk4_min_waves << "\n";
   o << "#define HAMK_USE_LUT " << d.use_lut << "\n";
+  if (d.wave && d.wave_blocked) o << "#define HAMK_WAVE_BLOCKED 1\n";
   // (sin, cos)(i 2pi/512), correctly rounded from 80-bit: the constant data behind sincos_lut's LDS table
   o << "#ifdef HAMK_HOST_EMULATION\nstatic const double hamk_trig_lut_init[1024] = {\n#else\n__device__ const double hamk_trig_lut_init[1024] = {\n#endif\n";
   for (int i = 0; i < 512; ++i) {

@@ -17,6 +17,7 @@ struct SystemDesc {
   int rk4_min_waves = 1;        // __launch_bounds__ second argument of the RK4 kernel (waves per SIMD)
   int use_lut = 2;              // stepping kernels: sincos through the LDS table (hamk_device.hpp StageTrig: 0, 1, 2)
   bool wave = false;            // wave-cooperative kernels (hamk_wave.hpp) instead of one trajectory per lane
+  bool wave_blocked = false;    // wave kernels: LDL^T in panels of 16 with the trailing blocks updated on the matrix cores
   std::vector<double> inertia;
   std::vector<hamk_op> f_ops;
   std::vector<int32_t> f_outs;

@@ -48,7 +48,11 @@ template <class S> struct Lds {
   // contiguous.  The first 4*NP doubles double as the staging rows of sweep 1.
   static constexpr int TILE = NP * (NP + 1) / 2;
   HAMK_DEV static constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
-  static constexpr int PER_TRAJ = TILE + 4 * NP + 2 * NT;   // + 2*NP scratch row (sincos exchange, pivot column + z) + two all-gather buffers + sincos pairs
+#ifndef HAMK_WAVE_BLOCKED
+#define HAMK_WAVE_BLOCKED 0
+#endif
+  static constexpr int NPIV = HAMK_WAVE_BLOCKED ? NP : 0;   // the pivots d_j of the blocked factorisation
+  static constexpr int PER_TRAJ = TILE + 4 * NP + 2 * NT + NPIV;   // + 2*NP scratch row (sincos exchange, pivot column + z) + two all-gather buffers + sincos pairs
 };
 
 // sincos pairs of the trajectory's current point, resident in LDS (same member syntax as
@@ -248,6 +252,7 @@ template <class S> struct Ctx {
   HAMK_DEV TrigLds trig() const {
     TrigLds t; t.s = smem + off + Lds<S>::TILE + 4 * NP; t.c = t.s + Lds<S>::NT; t.ax = t.as = t.ac = nullptr; return t;
   }
+  HAMK_DEV double* piv() const { return smem + off + Lds<S>::TILE + 4 * NP + 2 * Lds<S>::NT; }   // [NP] d_j (blocked factorisation)
   int g4;            // 4 * (first lane of the group within the wavefront)
   HAMK_DEV int grp4() const { return g4; }
 #ifdef HAMK_HOST_EMULATION
@@ -275,6 +280,112 @@ template <class S> HAMK_DEV void cooperative_trig(const Ctx<S>& c, double qi) {
     static_assert(S::NTRIG_F <= NP, "more sincos sites than lanes in a group");
     lds_sync();
   }
+}
+
+// LDL^T in panels of 16 pivots, left-looking: before panel b is factorised, block column b of what is
+// left of K (rows >= 16 b) receives the contribution of all earlier panels at once,
+//   K[16 ib + i][16 b + j] -= sum_c L[16 ib + i][c] d_c L[16 b + j][c],   c < 16 b,
+// on the matrix cores, operands read from the packed triangle where the panels left L (one 8-byte read
+// per lane per four columns -- the same operand layout as the accumulation of K in SinkK), the block
+// read from and written back to its place in the triangle.  Inside a panel the column broadcast of
+// `factor` below runs unchanged, but its trailing update stops at the panel's edge: a lane reads
+// (16 - 1 - j mod 16) values per pivot instead of (N - 1 - j), and carries 16 entries of its row in
+// registers instead of N.  Broadcast reads per factorisation at N = 32: 240 wide reads -> 112, plus
+// 32 narrow ones for the one off-diagonal block.
+template <class S>
+HAMK_DEV void factor_blocked(const Ctx<S>& c, double& dinv, int& st, double& z) {
+  constexpr int N = S::N, NP = Ctx<S>::NP, G = 64 / NP, PER = Lds<S>::PER_TRAJ, NBR = (N + 15) / 16;
+  auto tri = [](int i, int j) { return i * (i + 1) / 2 + j; };
+  const int li = c.li;
+  const int kq = c.lw >> 4, l16 = c.lw & 15;
+  bool ok = true;
+  dinv = 0.0;
+  double dmine = 1.0;
+  double* Lrow = c.tile() + li * (li + 1) / 2;
+  double* cA = c.rowbuf();
+  double* cB = c.rowbuf() + NP;
+  double* cZ = c.gb();
+#pragma unroll
+  for (int pb = 0; pb < NBR; ++pb) {
+    const int J0 = 16 * pb, J1 = (16 * pb + 16 < N) ? 16 * pb + 16 : N;     // this panel's pivots [J0, J1)
+    if (pb > 0) {
+      HAMK_LOCKSTEP();
+      c.piv()[li] = dmine;                                   // every lane its own slot; final for lanes < J0
+      lds_sync();                                            // L of the earlier panels and their pivots are in LDS
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const double* T = c.smem + c.offw + g * PER;         // trajectory g of the wavefront: all 64 lanes serve it
+        const double* D = T + Lds<S>::TILE + 4 * NP + 2 * Lds<S>::NT;
+        double xb[4 * (NBR > 1 ? NBR - 1 : 1)], xd[4 * (NBR > 1 ? NBR - 1 : 1)];
+#pragma unroll
+        for (int cm = 0; cm < 4 * pb; ++cm) {                // columns 4 cm + kq of the earlier panels
+          xb[cm] = T[tri(J0 + l16, 4 * cm + kq)];
+          xd[cm] = D[4 * cm + kq];
+        }
+#pragma unroll
+        for (int ib = pb; ib < NBR; ++ib) {
+          mfma_d4 acc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ib + 4 * r + kq, col = J0 + l16;
+            const int hi = (ib != pb || row > col) ? row : col, lo = (ib != pb || row > col) ? col : row;
+            acc[r] = T[hi * (hi + 1) / 2 + lo];
+          }
+#pragma unroll
+          for (int cm = 0; cm < 4 * pb; ++cm) {
+            const double xa = (ib == pb) ? xb[cm] : T[tri(16 * ib + l16, 4 * cm + kq)];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-(xa * xd[cm]), xb[cm], acc, 0, 0, 0);
+          }
+          double* Tw = c.smem + c.offw + g * PER;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ib + 4 * r + kq, col = J0 + l16;
+            const int hi = (ib != pb || row > col) ? row : col, lo = (ib != pb || row > col) ? col : row;
+            Tw[hi * (hi + 1) / 2 + lo] = acc[r];
+          }
+        }
+      }
+      lds_sync();
+    }
+    double row[16];                                          // this lane's entries in the panel's columns (entries beyond li: never used)
+#pragma unroll
+    for (int b = 0; b < 16; ++b) row[b] = (J0 + b < N) ? Lrow[J0 + b] : 0.0;
+#pragma unroll
+    for (int j = J0; j + 1 < J1; j += 2) {
+      HAMK_LOCKSTEP();
+      cA[li] = row[j - J0];
+      cB[li] = row[j + 1 - J0];
+      cZ[li] = z;
+      lds_sync();
+      const double a = cA[j], b = cA[j + 1], cc = cB[j + 1], zj = cZ[j], zj1 = cZ[j + 1];
+      const double det = fma(a, cc, -(b * b));
+      ok = ok && (a > 0.0) && (det > 0.0);
+      const double inv_a = frcp(a), inv_det = frcp(det);
+      const double inv_c = a * inv_det;
+      const double l = b * inv_a;
+      const double zj1p = fma(-l, zj, zj1);
+      const double l0 = (li > j) ? row[j - J0] * inv_a : 0.0;
+      const double l1 = (li > j + 1) ? fma(-l0, b, row[j + 1 - J0]) * inv_c : 0.0;
+      if (li == j) { dinv = inv_a; dmine = a; }
+      if (li == j + 1) { dinv = inv_c; dmine = det * inv_a; }
+      z = fma(-l1, zj1p, fma(-l0, zj, z));
+      const double al = fma(-l1, l, l0);
+#pragma unroll
+      for (int k = j + 2; k < J1; ++k) row[k - J0] = fma(-al, cA[k], fma(-l1, cB[k], row[k - J0]));
+      Lrow[(li > j) ? j : li] = l0;
+      Lrow[(li > j + 1) ? j + 1 : li] = l1;
+    }
+    if (((J1 - J0) & 1) != 0) {                              // last pivot of an odd N: nothing below it
+      HAMK_LOCKSTEP();
+      cA[li] = row[J1 - 1 - J0];
+      lds_sync();
+      const double dj = cA[J1 - 1];
+      ok = ok && (dj > 0.0);
+      if (li == J1 - 1) { dinv = frcp(dj); dmine = dj; }
+    }
+  }
+  if (!ok && li < N) st |= ST_SINGULAR;
+  lds_sync();
 }
 
 // Sweep 1 (with K accumulated in the sink) + LDL^T, with the forward substitution of one right-hand
@@ -308,6 +419,10 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
     sink.store(c.smem, c.offw, c.lw);                       // accumulators -> K in the packed triangles
   }
   lds_sync();
+#if HAMK_WAVE_BLOCKED
+  factor_blocked<S>(c, dinv, st, z);
+  return;
+#endif
 #pragma unroll
   for (int b = 0; b < N; ++b) row[b] = c.tile()[li * (li + 1) / 2 + b];   // each lane takes its row (entries b > li: never used)
   // LDL^T, right-looking, TWO pivots per LDS round trip: the serial chain (write column, read it

@@ -24,6 +24,9 @@ def jobs():
         out.append((n, {"HAMK_WAVE": "1"}, False))
     for n in ("chain8", "chain16"):
         out.append((n, {"HAMK_WAVE": "0"}, False))
+    for n in ("chain17", "chain18", "chain20", "chain32", "chain33", "chain40", "chain48", "chain64"):
+        out.append((n, {"HAMK_WAVE_BLOCKED": "1"}, True))       # LDL^T in panels (hamk_wave.hpp factor_blocked)
+        out.append((n, {"HAMK_WAVE_BLOCKED": "0"}, True))
     for n in ("opcodeZoo", "doublePendulum", "spring", "threeBodyPolar"):
         for mode in "HDR":
             for loop in (None, "1"):

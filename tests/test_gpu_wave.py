@@ -63,6 +63,29 @@ def test_wave_path_vs_oracle(api, oracle_lib, monkeypatch, name, force):
         assert not np.any(s.last_status)
 
 
+def test_flat_and_panel_factorisation_agree(api, oracle_lib, monkeypatch):
+    """n > 16: LDL^T in panels of 16 with the trailing blocks on the matrix cores (default) against the flat
+    column-broadcast factorisation it replaced (HAMK_WAVE_BLOCKED=0) and the oracle."""
+    spec = E.get("chain32")
+    panel = api.system_from_spec(spec)
+    assert "#define HAMK_WAVE_BLOCKED 1" in panel.source
+    monkeypatch.setenv("HAMK_WAVE_BLOCKED", "0")
+    flat = api.system_from_spec(spec)
+    assert "#define HAMK_WAVE_BLOCKED 1" not in flat.source
+    o = oracle_lib.OracleSystem(spec)
+    B = 70
+    q, _ = E.sample_config(spec, 3, B)
+    qd = 0.3 * np.cos(np.arange(spec.n * B).reshape(spec.n, B) * 0.7)
+    p = o.to_phase_batch(q, qd)
+    odq, odp, _ = o.hameqs_batch(q, p)
+    for s in (panel, flat):
+        dq, dp = api.hamEqs(s, api.Phase(q, p))
+        assert relerr(dq, odq) < 1e-10 and relerr(dp, odp) < 1e-10
+    a = api.rk4Steps(spec.dt, 20, panel, api.Phase(q, p))
+    b = api.rk4Steps(spec.dt, 20, flat, api.Phase(q, p))
+    assert relerr(a.positions, b.positions) < 1e-10 and relerr(a.momenta, b.momenta) < 1e-10
+
+
 def test_wave_path_matches_golden_and_lane_path(api, monkeypatch):
     spec = E.get("threeBodyPolar")
     lane = api.system_from_spec(spec)

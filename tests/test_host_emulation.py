@@ -472,8 +472,18 @@ def test_wave_kernels_on_host_match_oracle(emulate_wave, oracle_lib, name, force
     """Lane = AD direction, K = J^T M J through the (emulated) matrix-core instruction, two-pivot LDL^T
     by LDS column broadcast with the forward substitution riding along, four-wide back substitution,
     group-uniform RKF45 control -- against the oracle, incl. group sizes 16, 32 and 64 (one trajectory per wavefront), padded lanes,
-    odd N (single last pivot), N mod 4 != 0 (scalar head of the back substitution), M mod 4 != 0
+    panels of 16 pivots with the trailing blocks updated by MFMA (two panels at n <= 32, up to four beyond; a second
+    panel of ONE pivot at n = 17), odd N (single last pivot), N mod 4 != 0 (scalar head of the back substitution), M mod 4 != 0
     (zero-padded MFMA rows), unequal inertias, and ensembles that do not fill the last block."""
     spec = E.get(name)
     L = emulate_wave(spec, force)
     check_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=B, steps=2, tol=1e-10)
+
+
+def test_flat_factorisation_on_host(emulate_wave, oracle_lib, monkeypatch):
+    """n > 16 factorises in panels of 16 by default (trailing blocks on the matrix cores: chain17/18/32/33
+    above); the flat column-broadcast LDL^T it replaced stays selectable (HAMK_WAVE_BLOCKED=0) and correct."""
+    monkeypatch.setenv("HAMK_WAVE_BLOCKED", "0")
+    spec = E.get("chain18")
+    L = emulate_wave(spec, False)
+    check_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=2, steps=2, tol=1e-10)
