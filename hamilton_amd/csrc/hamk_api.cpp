@@ -999,6 +999,10 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   if (const char* e = std::getenv("HAMK_WAVE_BLOCKED")) s->desc.wave_blocked = (e[0] == '1') && n > 16;      // experiments
   s->desc.rk4_stage_loop = (n >= 7);
   if (const char* e = std::getenv("HAMK_RK4_LOOP")) s->desc.rk4_stage_loop = (e[0] == '1');
+  // n > 32 (one trajectory per wavefront): the RK4 kernel capped at 256 VGPRs -- two wavefronts per SIMD, ~160
+  // spilled registers -- beats one wavefront with everything in registers: chain48 1.05e7 -> 1.45e7, chain64
+  // 7.6e6 -> 9.5e6 RK4 steps/s on MI355X (profiles/r02_wave_blocked.jsonl)
+  if (s->desc.wave && n > 32) s->desc.rk4_min_waves = 2;
   if (const char* e = std::getenv("HAMK_RK4_WAVES")) s->desc.rk4_min_waves = std::atoi(e);
   {
     // sincos in the stepping kernels (hamk_device.hpp StageTrig).  Every evaluation through the LDS table is

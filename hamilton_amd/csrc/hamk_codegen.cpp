@@ -399,7 +399,7 @@ static void emit_reverse(std::ostringstream& o, const SystemDesc& d) {
 std::string generate_source(const SystemDesc& d) {
   std::ostringstream o;
   o << "// generated by libhamk (hamk_codegen.cpp) from the expression tape of one System " << d.m << " " << d.n << "\n";
-  if (d.rk4_min_waves > 1) o << "#define HAMK_RK4_MIN_WAVES " << d.rk4_min_waves << "\n";
+  if (d.rk4_min_waves > 1) o << "#define HAMK_RK4_MIN_WAVES " << d.rk4_min_waves << "\n#define HAMK_RK4_MIN_WAVES_BIG " << d.rk4_min_waves << "\n";
   o << "#define HAMK_USE_LUT " << d.use_lut << "\n";
   if (d.wave && d.wave_blocked) o << "#define HAMK_WAVE_BLOCKED 1\n";
   // (sin, cos)(i 2pi/512), correctly rounded from 80-bit: the constant data behind sincos_lut's LDS table

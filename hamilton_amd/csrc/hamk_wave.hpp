@@ -15,6 +15,8 @@
 //   solve    LDL^T with rows distributed over lanes: per pivot, every lane drops its entry of the
 //            pivot column into an LDS buffer and reads what it needs back as broadcast loads; the
 //            forward substitution rides along; back substitution reads L^T from the packed triangle.
+//            For n > 16 in panels of 16 pivots, the trailing blocks updated on the matrix cores
+//            (factor_blocked): the broadcast stops at the panel's edge.
 //   sweep 2  Jet2<1> along the common runtime direction qd with own e_i: lane i accumulates
 //            dT/dq_i = -sum_k m_k (J qd)_k ((dJ/dq_i) qd)_k directly in the sink -- the m x n x n
 //            Hessian tensor of the reference (Hamilton.hs:222, 512 KiB per point at N = 32)
@@ -901,9 +903,12 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
 #ifndef HAMK_RK4_MIN_WAVES
 #define HAMK_RK4_MIN_WAVES 2
 #endif
+#ifndef HAMK_RK4_MIN_WAVES_BIG                             // n > 32 (one trajectory per wavefront)
+#define HAMK_RK4_MIN_WAVES_BIG 1
+#endif
 #define HAMK_INSTANTIATE_WAVE(S)                                                                                 \
   HAMK_SCRIBBLE_KERNEL                                                                                           \
-  extern "C" __global__ void __launch_bounds__(256, (S::N > 32) ? 1 : HAMK_RK4_MIN_WAVES) hamk_rk4_steps_k(double* q, double* p, long long B, \
+  extern "C" __global__ void __launch_bounds__(256, (S::N > 32) ? HAMK_RK4_MIN_WAVES_BIG : HAMK_RK4_MIN_WAVES) hamk_rk4_steps_k(double* q, double* p, long long B, \
                                                           double dt, int nsteps, double drift_tol, int* status) { \
     HAMK_WAVE_SMEM(S);                                                                                           \
     hamk::wave::rk4_body<S>(smem, q, p, B, dt, nsteps, drift_tol, status);                                       \

@@ -27,6 +27,8 @@ def jobs():
     for n in ("chain17", "chain18", "chain20", "chain32", "chain33", "chain40", "chain48", "chain64"):
         out.append((n, {"HAMK_WAVE_BLOCKED": "1"}, True))       # LDL^T in panels (hamk_wave.hpp factor_blocked)
         out.append((n, {"HAMK_WAVE_BLOCKED": "0"}, True))
+    for n in ("chain33", "chain40", "chain48", "chain64"):
+        out.append((n, {"HAMK_RK4_WAVES": "2"}, False))          # n > 32 at two wavefronts per SIMD (256 VGPRs, spills)
     for n in ("opcodeZoo", "doublePendulum", "spring", "threeBodyPolar"):
         for mode in "HDR":
             for loop in (None, "1"):
