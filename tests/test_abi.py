@@ -78,6 +78,20 @@ def test_sizes_beyond_the_kernels_are_refused(hamk_lib):
     assert e.value.code == _abi.HAMK_ERR_UNSUPPORTED and "supported sizes" in str(e.value)
 
 
+def test_defaults_of_the_wave_kernels(hamk_lib, monkeypatch):
+    """What the library chooses for n > 16 (each choice measured on MI355X): LDL^T in panels
+    of 16 with MFMA trailing updates; beyond n = 32 the RK4 kernel capped for two wavefronts per SIMD; a forced
+    wave build of a small system (one panel) keeps the flat factorisation."""
+    from hamilton_amd import api
+    mid = api.system_from_spec(E.get("chain20")).source
+    assert "hamk_wave.hpp" in mid and "#define HAMK_WAVE_BLOCKED 1" in mid and "HAMK_RK4_MIN_WAVES_BIG" not in mid
+    big = api.system_from_spec(E.get("chain33")).source
+    assert "#define HAMK_WAVE_BLOCKED 1" in big and "#define HAMK_RK4_MIN_WAVES_BIG 2" in big
+    monkeypatch.setenv("HAMK_WAVE", "1")
+    small = api.system_from_spec(E.get("chain8")).source
+    assert "hamk_wave.hpp" in small and "HAMK_WAVE_BLOCKED" not in small
+
+
 def test_calls_fail_loudly_without_a_gpu(hamk_lib):
     """There is no CPU fallback: on a box without a GPU a compute call returns an error code."""
     from hamilton_amd import api
