@@ -2,7 +2,7 @@
 bench.py and the sweep scripts will ask for, into a cache directory that travels with the repository
 snapshot (`.hamk_cache/`, git-ignored): a fresh GPU box then spends its minutes measuring, not
 compiling.  Use on the GPU side with HAMK_CACHE_DIR=$PWD/.hamk_cache.
-  python scripts/warm_cache.py [-j 8]"""
+  python scripts/warm_cache.py [-j 8] [--tests-only]"""
 import multiprocessing as mp
 import os
 import sys
@@ -44,8 +44,12 @@ def jobs():
     return out
 
 
+TESTS_ONLY = "--tests-only" in sys.argv         # tests/conftest.py: no instruction-count probe builds (bench.py's)
+
+
 def build(job):
     name, env, isa = job
+    isa = isa and not TESTS_ONLY
     os.environ["HAMK_CACHE_DIR"] = CACHE
     os.environ.update(env)
     from hamilton_amd import api, examples
