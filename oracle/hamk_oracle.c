@@ -277,6 +277,11 @@ static int lu_inverse(int n, const double* A, double* Ainv) {
   return info;
 }
 
+/* hmatrix `inv` on its own (Hamilton.hs:321, :381), exported so the CPU suite can hold it against the
+ * LAPACK dgesv that hmatrix really binds (numpy.linalg.inv calls the same routine):
+ * tests/test_oracle_thirdparty.py.  A, Ainv row-major n x n; returns LAPACK's info > 0 as 1. */
+int orc_inverse(int n, const double* A, double* Ainv) { return lu_inverse(n, A, Ainv); }
+
 /* jmj = trj <> mm <> j   (Hamilton.hs:380, :324) */
 static void mass_matrix(const orc_system* s, const double* J, double* K) {
   int n = s->n, m = s->m;
