@@ -39,6 +39,7 @@ module Numeric.Hamilton.HIP
   , hamEqsBatch
   , hamiltonianBatch
   , stepHamBatch
+  , iterateStepHamBatch
   , rk4StepsBatch
   , evolveHamEnsemble
     -- * ensembles resident in HBM, several GPUs from one process
@@ -48,6 +49,7 @@ module Numeric.Hamilton.HIP
   , downloadEnsemble
   , rk4StepsDevice
   , stepHamDevice
+  , iterateStepHamDevice
   , synchronize
   , gatherEnsembles
     -- * which GSL binding of hmatrix-gsl 'stepHam' / 'evolveHam' reproduce (hamk.h)
@@ -116,6 +118,9 @@ foreign import ccall safe "hamk_rk4_steps"
   c_rk4_steps :: Ptr HamkSystem -> Int64 -> Ptr Double -> Ptr Double -> Double -> Int32 -> Ptr Int32 -> Int32 -> IO CInt
 foreign import ccall safe "hamk_step_ham_batch"
   c_step_ham :: Ptr HamkSystem -> Int64 -> Ptr Double -> Ptr Double -> Double -> Ptr Int32 -> Ptr Int32 -> Int32 -> IO CInt
+foreign import ccall safe "hamk_step_ham_iterate"
+  c_step_ham_iterate :: Ptr HamkSystem -> Int64 -> Ptr Double -> Ptr Double -> Double -> Int32 -> Int32 -> Ptr Double -> Ptr Double
+                     -> Ptr Int32 -> Ptr Int32 -> Int32 -> IO CInt
 foreign import ccall safe "hamk_evolve_ham_batch"
   c_evolve_ham :: Ptr HamkSystem -> Int64 -> Ptr Double -> Ptr Double -> Int32 -> Ptr Double -> Ptr Double -> Ptr Double
                -> Double -> Double -> Double -> Ptr Int32 -> Ptr Int32 -> Int32 -> IO CInt
@@ -401,6 +406,12 @@ stepHamBatch :: forall m n. KnownNat n => Double -> HipSystem m n -> Ensemble n 
 stepHamBatch r (HipSystem h) e = withForeignPtr h $ \s ->
   inPlace e (\b pq pp -> c_step_ham s b pq pp r nullPtr nullPtr memHost) "stepHam"
 
+-- | @iterate (stepHam r s)@ (README.md:150; the demo's frame loop, app/Examples.hs:429): @k@ consecutive
+--   'stepHam' calls in ONE launch, bit-identical to @k@ separate calls.
+iterateStepHamBatch :: forall m n. KnownNat n => Double -> Int -> HipSystem m n -> Ensemble n -> IO (Ensemble n)
+iterateStepHamBatch r k (HipSystem h) e = withForeignPtr h $ \s ->
+  inPlace e (\b pq pp -> c_step_ham_iterate s b pq pp r (fromIntegral k) 0 nullPtr nullPtr nullPtr nullPtr memHost) "iterateStepHam"
+
 -- | Classic fixed-step RK4 (no counterpart in the reference; SURVEY.md F1).
 rk4StepsBatch :: forall m n. KnownNat n => Double -> Int -> HipSystem m n -> Ensemble n -> IO (Ensemble n)
 rk4StepsBatch dt k (HipSystem h) e = withForeignPtr h $ \s ->
@@ -470,6 +481,12 @@ stepHamDevice :: forall m n. KnownNat n => Double -> HipSystem m n -> DeviceEnse
 stepHamDevice r (HipSystem h) (DeviceEnsemble b dq dp) =
   withForeignPtr h $ \s -> withForeignPtr dq $ \pq -> withForeignPtr dp $ \pp ->
     c_step_ham s (fromIntegral b) pq pp r nullPtr nullPtr memDevice >>= check "stepHam"
+
+-- | @k@ consecutive 'stepHam' calls for every member, in place in HBM, one launch.
+iterateStepHamDevice :: forall m n. KnownNat n => Double -> Int -> HipSystem m n -> DeviceEnsemble n -> IO ()
+iterateStepHamDevice r k (HipSystem h) (DeviceEnsemble b dq dp) =
+  withForeignPtr h $ \s -> withForeignPtr dq $ \pq -> withForeignPtr dp $ \pp ->
+    c_step_ham_iterate s (fromIntegral b) pq pp r (fromIntegral k) 0 nullPtr nullPtr nullPtr nullPtr memDevice >>= check "iterateStepHam"
 
 synchronize :: HipSystem m n -> IO ()
 synchronize (HipSystem h) = withForeignPtr h $ \s -> c_synchronize s >>= check "synchronize"

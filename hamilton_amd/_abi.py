@@ -64,6 +64,7 @@ SIGNATURES = {
                                             ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(_f64)]),
     "hamk_checkpoint_read": (ctypes.c_int, [ctypes.c_char_p, _i32, _i64, _dp, _dp, _i32]),
     "hamk_step_ham_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _f64, _ip, _ip, _i32]),
+    "hamk_step_ham_iterate": (ctypes.c_int, [_h, _i64, _dp, _dp, _f64, _i32, _i32, _dp, _dp, _ip, _ip, _i32]),
     "hamk_evolve_ham_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _i32, ctypes.POINTER(ctypes.c_double), _dp, _dp,
                                              _f64, _f64, _f64, _ip, _ip, _i32]),
     "hamk_last_error": (ctypes.c_char_p, []),

@@ -394,6 +394,32 @@ def stepHam(r: float, s: System, ph: Phase, inplace: bool = False) -> Phase:
     return Phase(_shape_out(q, qa.single), _shape_out(p, qa.single))
 
 
+def iterateStepHam(r: float, ncalls: int, s: System, ph: Phase, every: int = 0, inplace: bool = False):
+    """`iterate (stepHam r s)` (README.md:150; the demo's frame loop, app/Examples.hs:429) -- `ncalls` consecutive
+    stepHam r in ONE launch (hamk_step_ham_iterate): bit-identical to calling stepHam `ncalls` times, without
+    the launch and synchronisation per call.  Returns the final Phase, or (final Phase, frames) when
+    every > 0: frames = the Phase after every `every`-th call, arrays shaped [ncalls // every, n(, B)]."""
+    qa, pa = _pair(ph.positions, "positions", ph.momenta, "momenta", s.n)
+    if inplace:
+        _in_place(qa, ph.positions, "positions"); _in_place(pa, ph.momenta, "momenta")
+    q, p = (qa.a, pa.a) if inplace else (qa.clone(), pa.clone())
+    st, ns = qa.like(None, "i4"), qa.like(None, "i4")
+    rows = (int(ncalls) // int(every)) if every > 0 else 0
+    fq = qa.like(s.n, lead=(rows,)) if rows else None
+    fp = qa.like(s.n, lead=(rows,)) if rows else None
+    with s._on(qa):
+        _abi.check(_abi.lib().hamk_step_ham_iterate(s._h, qa.B, _ptr(q), _ptr(p), float(r), int(ncalls), int(every) if rows else 0,
+                                                    _ptr(fq), _ptr(fp), _ptr(st), _ptr(ns), qa.mem))
+    s.last_nsub = ns
+    s._after(st, qa.single, "iterateStepHam")
+    out = Phase(_shape_out(q, qa.single), _shape_out(p, qa.single))
+    if every > 0:
+        if rows == 0:
+            return out, Phase(np.empty((0, s.n)), np.empty((0, s.n)))
+        return out, Phase(_shape_out(fq, qa.single), _shape_out(fp, qa.single))
+    return out
+
+
 def evolveHam(s: System, p0: Phase, ts, h0: float = 0.0, eps_abs: float = 0.0, eps_rel: float = 0.0) -> List[Phase]:
     """evolveHam (Hamilton.hs:433-462): the state at each of the >= 2 times; element 0 is p0."""
     ts = np.ascontiguousarray(np.asarray(ts, dtype=np.float64))

@@ -448,6 +448,8 @@ static size_t chosen_kernel_bytes(const hamk_system* s, int k) {
 }
 
 static int launch(hamk_system* s, KernelId k, int64_t B, void** args);
+// the flags argument of hamk_rkf45_k (hamk_device.hpp rkf45_body)
+static int rkf_flags(int row0, int inplace, int gsl_api) { return (row0 & 1) | ((inplace & 3) << 8) | ((gsl_api & 3) << 16); }
 static int build_code(hamk_system* s);
 static int load_modules(hamk_system* s);
 
@@ -574,9 +576,10 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
       }
       hipMemcpy(d_q, q.data(), cnt * 8, hipMemcpyHostToDevice); hipMemcpy(d_p, p.data(), cnt * 8, hipMemcpyHostToDevice);
       double h0 = dt, ea = 1e30, er = 1e30, t0 = 0.0, t1 = dt;
-      int nt = 2, row0 = 1, inplace = 1, max_sub = 8, api = s->gsl_api;
+      int nt = 2, flags = rkf_flags(1, 1, s->gsl_api), max_sub = 8;
       const double *cq = d_q, *cp = d_p, *cts = nullptr; int32_t* st = d_st; int32_t* ns = nullptr;
-      void* args[] = {&cq, &cp, &d_q, &d_p, &b, &nt, &cts, &t0, &t1, &h0, &ea, &er, &row0, &inplace, &max_sub, &api, &st, &ns};
+      int ncalls = 1, it_every = 0;
+      void* args[] = {&cq, &cp, &d_q, &d_p, &b, &nt, &cts, &t0, &t1, &h0, &ea, &er, &flags, &max_sub, &st, &ns, &ncalls, &it_every};
       rc = launch(s, K_RKF45, B, args);
       if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RKF45 kernel failed");
       hipMemcpy(got.data(), d_q, cnt * 8, hipMemcpyDeviceToHost); hipMemcpy(got.data() + cnt, d_p, cnt * 8, hipMemcpyDeviceToHost);
@@ -637,9 +640,10 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
         scribble(0x85ebca6bu * (unsigned)(r + 3));
         upload();
         double h0 = T / 100, ea = kRefEpsilon, er = kRefEpsilon, t0 = 0.0, t1 = T;
-        int nt = 2, row0 = 1, inplace = 1, max_sub = 4096, api = s->gsl_api;
+        int nt = 2, flags = rkf_flags(1, 1, s->gsl_api), max_sub = 4096;
         const double *cq = e_q, *cp = e_p, *cts = nullptr;
-        void* a5[] = {&cq, &cp, &e_q, &e_p, &b3, &nt, &cts, &t0, &t1, &h0, &ea, &er, &row0, &inplace, &max_sub, &api, &e_st, &e_ns};
+        int ncalls = 1, it_every = 0;
+        void* a5[] = {&cq, &cp, &e_q, &e_p, &b3, &nt, &cts, &t0, &t1, &h0, &ea, &er, &flags, &max_sub, &e_st, &e_ns, &ncalls, &it_every};
         rc = launch(s, K_RKF45, B3, a5);
         if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RKF45 kernel failed");
         download(run[r]);
@@ -1303,34 +1307,46 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
   TRY(st.out(status, (size_t)B, &dst));
   TRY(st.out(nsub, (size_t)B, &dns));
   long long b = B;
-  int nt_ = nt, row0 = 0, inplace = 0, max_sub = max_substeps(), api = s->gsl_api;
-  void* args[] = {&xq, &xp, &xqo, &xpo, &b, &nt_, &dts, &ts0, &ts1, &h0, &eps_abs, &eps_rel, &row0, &inplace, &max_sub, &api, &dst, &dns};
+  int nt_ = nt, flags = rkf_flags(0, 0, s->gsl_api), max_sub = max_substeps();
+  int ncalls = 1, it_every = 0;
+  void* args[] = {&xq, &xp, &xqo, &xpo, &b, &nt_, &dts, &ts0, &ts1, &h0, &eps_abs, &eps_rel, &flags, &max_sub, &dst, &dns, &ncalls, &it_every};
+  TRY(launch(s, K_RKF45, B, args));
+  return st.finish();
+}
+
+int hamk_step_ham_iterate(hamk_system* s, int64_t B, double* q, double* p, double dt, int32_t ncalls, int32_t out_every,
+                          double* qout, double* pout, int32_t* status, int32_t* nsub, int32_t mem) {
+  TRY(check_call(s, B, mem));
+  if (!q || !p) return fail(HAMK_ERR_INVALID, "null q / p");
+  if (ncalls < 0 || out_every < 0) return fail(HAMK_ERR_INVALID, "negative ncalls / out_every");
+  if (out_every > 0 && (!qout || !pout)) return fail(HAMK_ERR_INVALID, "out_every > 0 needs qout / pout");
+  if (B == 0 || ncalls == 0) return HAMK_OK;
+  TRY(bind_device(s));
+  double ts0 = 0.0, ts1 = dt;                               // evolveHam over (0, r), Hamilton.hs:401
+  double h0 = dt / 100.0, eps_abs = kRefEps, eps_rel = kRefEps;
+  Stager st(s, mem);
+  const size_t cnt = (size_t)s->desc.n * B;
+  const size_t rows = out_every > 0 ? (size_t)(ncalls / out_every) : 0;
+  double *xq, *xp, *xqo = nullptr, *xpo = nullptr; int32_t *dst, *dns;
+  TRY(st.inout(q, cnt, &xq));
+  TRY(st.inout(p, cnt, &xp));
+  if (rows > 0) { TRY(st.out(qout, cnt * rows, &xqo)); TRY(st.out(pout, cnt * rows, &xpo)); }
+  TRY(st.out(status, (size_t)B, &dst));
+  TRY(st.out(nsub, (size_t)B, &dns));
+  long long b = B;
+  // in place on (q, p); the kernel's qout/pout receive the frames (hamk_device.hpp rkf45_body, flags)
+  int nt_ = 2, flags = rkf_flags(1, 2, s->gsl_api), max_sub = max_substeps();
+  int nc = ncalls, every = rows > 0 ? out_every : 0;
+  const double* dts = nullptr;
+  const double *cq = xq, *cp = xp;
+  void* args[] = {&cq, &cp, &xqo, &xpo, &b, &nt_, &dts, &ts0, &ts1, &h0, &eps_abs, &eps_rel, &flags, &max_sub, &dst, &dns, &nc, &every};
   TRY(launch(s, K_RKF45, B, args));
   return st.finish();
 }
 
 int hamk_step_ham_batch(hamk_system* s, int64_t B, double* q, double* p, double dt, int32_t* status, int32_t* nsub,
                         int32_t mem) {
-  TRY(check_call(s, B, mem));
-  if (!q || !p) return fail(HAMK_ERR_INVALID, "null q / p");
-  if (B == 0) return HAMK_OK;
-  TRY(bind_device(s));
-  double ts0 = 0.0, ts1 = dt;                               // evolveHam over (0, r), Hamilton.hs:401
-  double h0 = dt / 100.0, eps_abs = kRefEps, eps_rel = kRefEps;
-  Stager st(s, mem);
-  const size_t cnt = (size_t)s->desc.n * B;
-  double *xq, *xp; int32_t *dst, *dns;
-  TRY(st.inout(q, cnt, &xq));
-  TRY(st.inout(p, cnt, &xp));
-  TRY(st.out(status, (size_t)B, &dst));
-  TRY(st.out(nsub, (size_t)B, &dns));
-  long long b = B;
-  int nt_ = 2, row0 = 1, inplace = 1, max_sub = max_substeps(), api = s->gsl_api;
-  const double* dts = nullptr;
-  const double *cq = xq, *cp = xp;
-  void* args[] = {&cq, &cp, &xq, &xp, &b, &nt_, &dts, &ts0, &ts1, &h0, &eps_abs, &eps_rel, &row0, &inplace, &max_sub, &api, &dst, &dns};
-  TRY(launch(s, K_RKF45, B, args));
-  return st.finish();
+  return hamk_step_ham_iterate(s, B, q, p, dt, 1, 0, nullptr, nullptr, status, nsub, mem);
 }
 
 

@@ -48,6 +48,9 @@
 #endif
 
 #define HAMK_DEV __device__ __forceinline__
+#ifndef HAMK_K_REASSOC
+#define HAMK_K_REASSOC 0
+#endif
 
 namespace hamk {
 
@@ -793,6 +796,22 @@ template <class S> HAMK_DEV void seed1(const double (&q)[S::N], Jet1<S::N> (&qa)
 
 // K = J^T M J from first-order jets of x (upper triangle)       Hamilton.hs:380
 template <class S, class A> HAMK_DEV void mass_matrix(const A (&x)[S::M], double (&K)[S::N][S::N]) {
+#if HAMK_K_REASSOC
+  // K[a][b] = sum_k m_k J[k][a] J[k][b] with the sum free to be re-associated (this block only): where the
+  // Jacobian repeats entries down a column -- a chain's dx_k/dq_j is the same value for every k >= j -- the
+  // compiler turns "the same product added (M - max(a, b)) times" into one product times a constant
+#pragma clang fp reassociate(on)
+#pragma unroll
+  for (int a = 0; a < S::N; ++a)
+#pragma unroll
+    for (int b = a; b < S::N; ++b) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < S::M; ++k) acc += (S::inertia(k) * x[k].d[a]) * x[k].d[b];
+      K[a][b] = acc;
+      K[b][a] = acc;
+    }
+#else
 #pragma unroll
   for (int a = 0; a < S::N; ++a)
 #pragma unroll
@@ -803,6 +822,7 @@ template <class S, class A> HAMK_DEV void mass_matrix(const A (&x)[S::M], double
       K[a][b] = acc;
       K[b][a] = acc;
     }
+#endif
 }
 
 // grad U(q): potential over generalized coordinates, or (u . f) for mkSystem'
@@ -1259,10 +1279,34 @@ template <int ORD> HAMK_DEV double rpow_inv(double r) {
   return y;
 }
 
+// A wave-uniform value the compiler would keep in scalar registers for the whole kernel, moved to a vector register:
+// the adaptive stepper is short of SGPRs (its argument block alone is 31 of the 102, and every fp64 literal of the
+// Butcher tableau is an SGPR pair on gfx9), never of VGPRs -- and SGPR spilling is what the one miscompiled kernel of
+// DESIGN.md section 6b had in excess.
+HAMK_DEV double park_in_vgpr(double x) {
+#ifndef HAMK_HOST_EMULATION
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
+HAMK_DEV int park_in_vgpr(int x) {
+#ifndef HAMK_HOST_EMULATION
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
+#define HAMK_RKF_FLAGS(row0, inplace, gsl_api) (((row0) & 1) | (((inplace) & 3) << 8) | (((gsl_api) & 3) << 16))
 template <class S>
 HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt, const double* __restrict__ ts, double ts0, double ts1, double h0,
-                         double eps_abs, double eps_rel, int row0, int inplace, int max_sub, int gsl_api,
-                         int* __restrict__ status, int* __restrict__ nsub) {
+                         double eps_abs, double eps_rel, int flags, int max_sub,
+                         int* __restrict__ status, int* __restrict__ nsub, int ncalls, int it_every) {
+  // flags (one kernel argument instead of three: the argument block of this kernel is what its SGPR budget is short of):
+  //   bit 0      row0: first row of qout/pout that is written (0: evolveHam, row 0 = initial state; 1: stepHam)
+  //   bits 8-9   0: rows go to qout/pout + r N B (evolveHam); 1: the final state overwrites qout/pout (stepHam in place);
+  //              2: iterate -- the final state overwrites q0/p0, qout/pout receive every it_every-th state
+  //   bits 16-17 which binding of gsl-ode.c (1 | 2)
+  const int row0 = flags & 1, inplace = (flags >> 8) & 3, gsl_api = (flags >> 16) & 3;
+  ts0 = park_in_vgpr(ts0); ts1 = park_in_vgpr(ts1); h0 = park_in_vgpr(h0); eps_abs = park_in_vgpr(eps_abs); eps_rel = park_in_vgpr(eps_rel);
   constexpr int N = S::N, D = 2 * N;
   if constexpr (StageTrig<S>::lut) lut_load();
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1285,10 +1329,22 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
   // the point where dydt_in was evaluated (after a rejection: of the rejected end point, still
   // close; TRIG_INCR falls back to the full evaluation when it is not)
   rhs<S, StageTrig<S>::anchor>(y, f0, st, tc);        // dydt_in at the initial state
+  // ncalls > 1 (hamk_step_ham_iterate): `iterate (stepHam dt)` (README.md:150, Examples.hs:429) in ONE launch.
+  // Every call is a fresh evolveHam over (0, dt), Hamilton.hs:400-402: t back to the grid's start, h back to
+  // h0 = dt/100 (:447), the sub-step budget and a GSL_FAILURE of the previous call forgotten.  dydt_in of the
+  // new call is f at the state the last call returned -- the dydt_out this lane already holds (the right-hand
+  // side is a pure function of the state): same bits as a separate launch, one evaluation saved per call.
+  it_every = park_in_vgpr(it_every);
+  int until_frame = it_every;
+  int calls_left = park_in_vgpr(ncalls);                  // (loop bookkeeping in vector registers: see park_in_vgpr)
+#pragma unroll 1
+  for (bool first = true; calls_left > 0; --calls_left, first = false) {
+  int budget = max_sub;
+  if (!first) { t = ts ? ts[0] : ts0; h = h0; failed = false; }
   for (int r = 1; r < nt; ++r) {
     const double ti = ts ? ts[r] : ts1;
-    while (sgn * (ti - t) > 0.0 && attempts < max_sub && !failed) {
-      ++attempts;
+    while (sgn * (ti - t) > 0.0 && budget > 0 && !failed) {
+      ++attempts; --budget;
       const double dt = ti - t;
       double hh = h;
       bool final_step = false;
@@ -1437,12 +1493,19 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
       }
     }
     if (sgn * (ti - t) > 0.0 && !failed) st |= ST_MAXSTEPS;
-    if (r >= row0) {
-      double* qo = inplace ? qout : qout + (i64)r * N * B;
-      double* po = inplace ? pout : pout + (i64)r * N * B;
+    if (r >= row0 && calls_left == 1) {
+      double* qo = (inplace == 2) ? const_cast<double*>(q0) : (inplace ? qout : qout + (i64)r * N * B);
+      double* po = (inplace == 2) ? const_cast<double*>(p0) : (inplace ? pout : pout + (i64)r * N * B);
 #pragma unroll
       for (int j = 0; j < N; ++j) { qo[(i64)j * B + i] = y[j]; po[(i64)j * B + i] = y[N + j]; }
     }
+  }
+  if (it_every > 0 && --until_frame == 0) {               // every it_every-th state of the iteration: [ncalls / it_every][N][B]
+    until_frame = it_every;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { qout[(i64)j * B + i] = y[j]; pout[(i64)j * B + i] = y[N + j]; }
+    qout += (i64)N * B; pout += (i64)N * B;
+  }
   }
   bool bad = false;
 #pragma unroll
@@ -1608,8 +1671,8 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
   }                                                                                                              \
   extern "C" __global__ void __launch_bounds__(256) hamk_rkf45_k(                                                \
       const double* q0, const double* p0, double* qout, double* pout, long long B, int nt, const double* ts,     \
-      double ts0, double ts1, double h0, double eps_abs, double eps_rel, int row0, int inplace, int max_sub,     \
-      int gsl_api, int* status, int* nsub) {                                                                     \
-    hamk::rkf45_body<S>(q0, p0, qout, pout, B, nt, ts, ts0, ts1, h0, eps_abs, eps_rel, row0, inplace, max_sub,   \
-                        gsl_api, status, nsub);                                                                  \
+      double ts0, double ts1, double h0, double eps_abs, double eps_rel, int flags, int max_sub,                 \
+      int* status, int* nsub, int ncalls, int it_every) {                                                        \
+    hamk::rkf45_body<S>(q0, p0, qout, pout, B, nt, ts, ts0, ts1, h0, eps_abs, eps_rel, flags, max_sub,           \
+                        status, nsub, ncalls, it_every);                                                         \
   }

@@ -779,8 +779,9 @@ template <class S> HAMK_DEV void coords_body(double* smem, const double* q, doub
 template <class S>
 HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt,
                          const double* ts, double ts0, double ts1, double h0, double eps_abs, double eps_rel,
-                         int row0, int inplace, int max_sub, int gsl_api, int* status, int* nsub) {
+                         int flags, int max_sub, int* status, int* nsub, int ncalls, int it_every) {
   constexpr int N = S::N, NP = Geo<N>::NP;
+  const int row0 = flags & 1, inplace = (flags >> 8) & 3, gsl_api = (flags >> 16) & 3;      // see hamk::rkf45_body
   const bool api2 = gsl_api != 1;
   const double sgn = (!api2 || h0 > 0.0) ? 1.0 : -1.0;    // odeiv2 driver.c: direction = sign of the initial step
   bool failed = false;                                    // odeiv2: GSL_FAILURE (uniform within a group)
@@ -793,10 +794,15 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
   double t = ts ? ts[0] : ts0, h = h0;
   double fq, fp;
   ham_eqs<S>(w.c, yq, yp, fq, fp, st);                    // dydt_in at the initial state
+  // ncalls > 1: `iterate (stepHam dt)` in one launch -- see hamk::rkf45_body
+#pragma unroll 1
+  for (int call = 0; call < ncalls; ++call) {
+  int budget = max_sub;
+  if (call > 0) { t = ts ? ts[0] : ts0; h = h0; failed = false; }
   for (int r = 1; r < nt; ++r) {
     const double ti = ts ? ts[r] : ts1;
     for (;;) {
-      const bool active = (sgn * (ti - t) > 0.0) && (attempts < max_sub) && !failed;
+      const bool active = (sgn * (ti - t) > 0.0) && (budget > 0) && !failed;
       if (!__any(active)) break;                           // wave-uniform exit
       const double dt = ti - t;
       double hh = h;
@@ -868,7 +874,7 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
         hh = rr * h_old;
       }
       if (active) {                                        // evolve.c: accept or undo
-        ++attempts;
+        ++attempts; --budget;
         if (fail_now) { failed = true; st |= ST_UNDERFLOW; }
         // the suggested step: always written back by gsl_odeiv; by gsl_odeiv2 not on a final step
         if (reject || fail_now || !api2 || !final_step) h = hh;
@@ -879,11 +885,16 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
       }
     }
     if (sgn * (ti - t) > 0.0 && !failed) st |= ST_MAXSTEPS;
-    if (r >= row0 && w.live) {
-      double* qo = inplace ? qout : qout + (i64)r * N * B;
-      double* po = inplace ? pout : pout + (i64)r * N * B;
+    if (r >= row0 && w.live && call == ncalls - 1) {
+      double* qo = (inplace == 2) ? const_cast<double*>(q0) : (inplace ? qout : qout + (i64)r * N * B);
+      double* po = (inplace == 2) ? const_cast<double*>(p0) : (inplace ? pout : pout + (i64)r * N * B);
       qo[(i64)j * B + w.t] = yq; po[(i64)j * B + w.t] = yp;
     }
+  }
+  if (it_every > 0 && (call + 1) % it_every == 0 && w.live) {
+    const i64 row = (i64)((call + 1) / it_every - 1);
+    qout[(row * N + j) * B + w.t] = yq; pout[(row * N + j) * B + w.t] = yp;
+  }
   }
   if ((is_nonfinite_bits(yq) || is_nonfinite_bits(yp)) && mine) st |= ST_NONFINITE;
   if (!mine) st = 0;
@@ -946,9 +957,9 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
   }                                                                                                              \
   extern "C" __global__ void __launch_bounds__(256) hamk_rkf45_k(                                                \
       const double* q0, const double* p0, double* qout, double* pout, long long B, int nt, const double* ts,     \
-      double ts0, double ts1, double h0, double eps_abs, double eps_rel, int row0, int inplace, int max_sub,     \
-      int gsl_api, int* status, int* nsub) {                                                                     \
+      double ts0, double ts1, double h0, double eps_abs, double eps_rel, int flags, int max_sub,                 \
+      int* status, int* nsub, int ncalls, int it_every) {                                                        \
     HAMK_WAVE_SMEM(S);                                                                                           \
-    hamk::wave::rkf45_body<S>(smem, q0, p0, qout, pout, B, nt, ts, ts0, ts1, h0, eps_abs, eps_rel, row0,         \
-                              inplace, max_sub, gsl_api, status, nsub);                                          \
+    hamk::wave::rkf45_body<S>(smem, q0, p0, qout, pout, B, nt, ts, ts0, ts1, h0, eps_abs, eps_rel, flags,        \
+                              max_sub, status, nsub, ncalls, it_every);                                          \
   }

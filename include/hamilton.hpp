@@ -383,6 +383,26 @@ inline Phase stepHam(double r, System& s, const Phase& ph) {                    
   check(hamk_step_ham_batch(s.handle(), ph.B, out.positions.data(), out.momenta.data(), r, s.last_status.data(), nullptr, HAMK_MEM_HOST));
   return out;
 }
+// `iterate (stepHam r s)` (README.md:150, app/Examples.hs:429): ncalls consecutive stepHam r in one launch, bit-identical to
+// ncalls calls of stepHam; frames (optional) receives the Phase after every `every`-th call.
+inline Phase iterateStepHam(double r, int ncalls, System& s, const Phase& ph, int every = 0, std::vector<Phase>* frames = nullptr) {
+  Phase out = ph;
+  s.last_status.assign((size_t)ph.B, 0);
+  const size_t cnt = (size_t)s.n() * ph.B;
+  const size_t rows = (every > 0 && frames) ? (size_t)(ncalls / every) : 0;
+  std::vector<double> fq(cnt * rows), fp(cnt * rows);
+  check(hamk_step_ham_iterate(s.handle(), ph.B, out.positions.data(), out.momenta.data(), r, ncalls, rows ? every : 0,
+                              rows ? fq.data() : nullptr, rows ? fp.data() : nullptr, s.last_status.data(), nullptr, HAMK_MEM_HOST));
+  if (frames) {
+    frames->assign(rows, Phase{});
+    for (size_t k = 0; k < rows; ++k) {
+      (*frames)[k].n = ph.n; (*frames)[k].B = ph.B;
+      (*frames)[k].positions.assign(fq.begin() + k * cnt, fq.begin() + (k + 1) * cnt);
+      (*frames)[k].momenta.assign(fp.begin() + k * cnt, fp.begin() + (k + 1) * cnt);
+    }
+  }
+  return out;
+}
 inline std::vector<Phase> evolveHam(System& s, const Phase& p0, const std::vector<double>& ts) {           // :433-462
   if (ts.size() < 2) throw std::invalid_argument("evolveHam needs at least two solution times (2 <= s)");
   const size_t cnt = (size_t)s.n() * p0.B;
@@ -471,6 +491,10 @@ inline void rk4Steps(double dt, int nsteps, System& s, DevicePhase& d) {      //
 }
 inline void stepHam(double r, System& s, DevicePhase& d) {                     // :390-402, in place, asynchronous
   check(hamk_step_ham_batch(s.handle(), d.B, d.positions.as<double>(), d.momenta.as<double>(), r, d.status.as<int32_t>(), nullptr, HAMK_MEM_DEVICE));
+}
+inline void iterateStepHam(double r, int ncalls, System& s, DevicePhase& d) {  // README.md:150; in place, asynchronous, one launch
+  check(hamk_step_ham_iterate(s.handle(), d.B, d.positions.as<double>(), d.momenta.as<double>(), r, ncalls, 0, nullptr, nullptr,
+                              d.status.as<int32_t>(), nullptr, HAMK_MEM_DEVICE));
 }
 // ... with the launch checking its own energy invariant: HAMK_ST_DRIFT in d.status where
 // |H_exit - H_entry| > drift_tol * max(1, |H_entry|)   (hamk_rk4_steps_checked)

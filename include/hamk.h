@@ -17,6 +17,7 @@
  *   keP :341-349, hamiltonian :353-361                  hamk_observe_batch
  *   hamEqs :370-387                                     hamk_hameqs_batch
  *   stepHam :390-402                                    hamk_step_ham_batch   (adaptive RKF45, GSL semantics)
+ *   iterate (stepHam dt)  README.md:150, Examples.hs:429 hamk_step_ham_iterate (ncalls calls, one launch)
  *   evolveHam :433-462, evolveHam' :409-429             hamk_evolve_ham_batch (adaptive RKF45, GSL semantics)
  *   odeSolveV's GSL binding (:445, hmatrix-gsl)         hamk_system_set_gsl_api (gsl_odeiv2 driver | old gsl_odeiv)
  *   (no counterpart; named by BASELINE.json north_star) hamk_rk4_steps        (classic fixed-step RK4)
@@ -240,6 +241,19 @@ int hamk_rk4_steps_checked(hamk_system* s, int64_t B, double* q, double* p,
  * :445-448.  nsub (optional, [B]) receives accepted+rejected sub-step counts. */
 int hamk_step_ham_batch(hamk_system* s, int64_t B, double* q, double* p, double dt,
                         int32_t* status, int32_t* nsub, int32_t mem);
+
+/* `iterate (stepHam dt)` (README.md:150; the demo's frame loop, app/Examples.hs:429): ncalls consecutive
+ * stepHam dt in ONE launch, IN PLACE.  Every call is what a separate hamk_step_ham_batch would do -- a fresh
+ * evolveHam over (0, dt): t = 0, h0 = dt/100 (Hamilton.hs:400-402, :447), its own sub-step budget -- and the
+ * result is bit-identical to ncalls separate calls; what is saved is ncalls - 1 launches and stream
+ * synchronisations (one trajectory is launch-latency bound: BASELINE config 1) and one right-hand side per
+ * call (dydt_in of a call is the dydt_out the previous one already holds).
+ * out_every > 0: the state after every out_every-th call goes to qout/pout, [ncalls / out_every][n][B]
+ * (the frames an animation shows); out_every == 0: qout/pout may be NULL.  status: OR over the calls;
+ * nsub: sub-steps summed over the calls.                                                                 */
+int hamk_step_ham_iterate(hamk_system* s, int64_t B, double* q, double* p, double dt, int32_t ncalls,
+                          int32_t out_every, double* qout, double* pout,
+                          int32_t* status, int32_t* nsub, int32_t mem);
 
 /* evolveHam: states at each of the nt >= 2 requested times ts[] (host array);
  * qout/pout are [nt][n][B]; row 0 is the initial state (Hamilton.hs:443-462).

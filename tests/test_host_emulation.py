@@ -487,3 +487,40 @@ def test_flat_factorisation_on_host(emulate_wave, oracle_lib, monkeypatch):
     spec = E.get("chain18")
     L = emulate_wave(spec, False)
     check_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=2, steps=2, tol=1e-10)
+
+
+@pytest.mark.parametrize("name,env", [("doublePendulum", None), ("spring", None), ("threeBodyPolar", None),
+                                       ("doublePendulum", {"HAMK_RKF_LOOP": "1", "HAMK_TRIG_LUT": "0"})])
+def test_iterate_stepham_is_the_calls_one_by_one(emulate, oracle_lib, name, env):
+    """hamk_step_ham_iterate's kernel path: `iterate (stepHam dt)` (README.md:150) inside one kernel invocation is
+    BIT-identical to the same number of separate stepHam invocations -- every call restarts from h0 = dt/100 with its
+    own budget (Hamilton.hs:400-402, :447), dydt_in of a call is the dydt_out the previous one ended with -- the
+    sub-step totals add up, the every-k-th frames are the states the separate calls pass through, and the whole
+    sequence agrees with the oracle's stepHam applied as often."""
+    spec = E.get(name)
+    o = oracle_lib.OracleSystem(spec)
+    L, _ = emulate(spec, env)
+    B, ncalls, every = 24, 9, 3
+    dt = 2 * spec.dt
+    q, qd = E.sample_config(spec, 5, B)
+    p = o.to_phase_batch(q, qd)
+    q1, p1 = q.copy(), p.copy()
+    st, ns = np.zeros(B, np.int32), np.zeros(B, np.int32)
+    tot = np.zeros(B, np.int64)
+    frames_q, frames_p = [], []
+    for k in range(ncalls):
+        L.emu_step_ham(P(q1), P(p1), LL(B), ctypes.c_double(dt), I(st), I(ns))
+        tot += ns
+        if (k + 1) % every == 0:
+            frames_q.append(q1.copy()); frames_p.append(p1.copy())
+    q2, p2 = q.copy(), p.copy()
+    fq, fp = np.zeros((ncalls // every, spec.n, B)), np.zeros((ncalls // every, spec.n, B))
+    st2, ns2 = np.zeros(B, np.int32), np.zeros(B, np.int32)
+    L.emu_step_ham_iterate(P(q2), P(p2), LL(B), ctypes.c_double(dt), ncalls, every, P(fq), P(fp), I(st2), I(ns2))
+    assert np.array_equal(q1, q2) and np.array_equal(p1, p2)
+    assert np.array_equal(tot, ns2.astype(np.int64))
+    assert np.array_equal(np.stack(frames_q), fq) and np.array_equal(np.stack(frames_p), fp)
+    oq, op = q.copy(), p.copy()
+    for _ in range(ncalls):
+        oq, op, _ = o.step_ham_batch(oq, op, dt)
+    assert relerr(q2, oq) < 1e-9 and relerr(p2, op) < 1e-9
