@@ -262,26 +262,96 @@ def c1_leg(spec, s):
 
 
 def stepham_bench(a, s, spec, dt, state, dist, dev, rank, world):
-    """Secondary: stepHam(dt) calls/s over the ensemble (GSL-semantics adaptive RKF45 per lane)."""
+    """Secondary: the reference's OWN stepper over the ensemble -- stepHam(dt) calls/s (GSL-semantics adaptive RKF45 per
+    lane, Hamilton.hs:390-402, :443-448).  One bench step = one launch = one stepHam(dt) of every trajectory."""
     ph = state
     for _ in range(a.warmup):
         ph = api.stepHam(dt, s, ph, inplace=True)
     torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nsub_sum = torch.zeros(ph.positions.shape[1], dtype=torch.int64, device=dev)
+    wave_max_sum = 0.0
+    lanes = s.lanes_per_trajectory
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(a.steps):
         ph = api.stepHam(dt, s, ph, inplace=True)
+    ev1.record()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    kernel_s = ev0.elapsed_time(ev1) * 1e-3 / max(1, a.steps)
+    # divergence: a wavefront runs until its slowest member is done (outside the timed region: one more call, counted)
+    probe = api.stepHam(dt, s, api.Phase(ph.positions.clone(), ph.momenta.clone()))
+    del probe
     nsub = s.last_nsub.to(torch.float64)
+    per_wave = 64 // lanes
+    Bw = (nsub.numel() // per_wave) * per_wave
+    wmax = nsub[:Bw].reshape(-1, per_wave).amax(1)
     if rank == 0:
         B = a.batch
-        print(json.dumps({"metric": "stepHam calls/sec (ensemble, adaptive RKF45 GSL semantics)",
-                          "value": world * B * a.steps / el, "unit": "trajectory-stepHam/s", "n_gpus": world,
-                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
-                          "higher_is_better": True, "dtype": "f64", "data": "synthetic",
-                          "config": {"workload": f"{a.system} stepHam dt={dt}", "trajectories_per_gpu": B},
-                          "mean_substeps": float(nsub.mean()), "max_substeps": float(nsub.max()),
-                          "rhs_evals_per_s": world * B * a.steps * float(nsub.mean()) * 6 / el}), flush=True)
+        n = spec.n
+        calls_per_s = world * B * a.steps / el
+        attempts_per_s = calls_per_s * float(nsub.mean())
+        out = {"metric": "stepHam calls/sec (ensemble, adaptive RKF45 GSL semantics)",
+               "value": calls_per_s, "unit": "trajectory-stepHam/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+               "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic (per-index splitmix64 initial conditions, seed 20241008)",
+               "config": {"workload": f"{a.system} (System {spec.m} {spec.n}) ensemble, stepHam dt={dt}", "trajectories_per_gpu": B,
+                          "kernel_path": "wave-cooperative" if lanes > 1 else "one trajectory per lane", "gsl_api": s.gsl_api},
+               "mean_substeps": float(nsub.mean()), "max_substeps": float(nsub.max()),
+               "rhs_evals_per_s": attempts_per_s * 6,
+               "divergence": {"mean_substeps_per_lane": float(nsub.mean()), "mean_of_wave_max_substeps": float(wmax.mean()),
+                              "lane_utilisation": float(nsub[:Bw].mean() / wmax.mean()),
+                              "note": "a wavefront executes max-over-its-lanes attempts; utilisation = mean / mean-of-wave-max"}}
+        alg = 32.0 * n * B                                   # a launch reads and writes one Phase per trajectory
+        fp64 = {"peak_tflops": FP64_PEAK_TFLOPS, "lanes_per_trajectory": lanes}
+        if not a.no_isa:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                import isa_stats
+                isa = isa_stats.rkf45_attempt_stats(spec, s)
+            except Exception as e:                           # noqa: BLE001
+                isa, fp64["isa_error"] = None, repr(e)
+            if isa:
+                wave_attempts_per_s = float(wmax.sum()) * a.steps / (kernel_s * a.steps)      # per GPU
+                fp64.update(isa)
+                fp64["wave_attempts_per_s"] = wave_attempts_per_s
+                fp64["valu_issue_frac"] = wave_attempts_per_s * isa["valu_per_wave_attempt"] * 4.0 / (N_SIMD * NOMINAL_HZ)
+                fp64["achieved_tflops_useful"] = B * float(nsub.mean()) / kernel_s * isa["valu_f64_per_wave_attempt"] * 2 / 1e12
+                fp64["note"] = ("valu_issue_frac counts what the wavefronts EXECUTE (wave-max attempts); achieved_tflops_useful counts "
+                                "fp64 instructions x 2 on the attempts the lanes needed (an upper bound: not every fp64 instruction is an FMA)")
+        out["roofline"] = {"bound": "hbm", "achieved": alg / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": alg / kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "hamk_rkf45_k", "kernel_ms": kernel_s * 1e3,
+                           "algorithmic_bytes_per_launch": alg, "physically_binding": "fp64-valu (divergent trip counts)", "fp64": fp64}
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import oracle
+            o = oracle.OracleSystem(spec)
+            o.gsl_api = s.gsl_api
+            cores = oracle.max_threads()
+            S = 64 * cores
+            q, qd = examples.sample_config(spec, 0, S)
+            p = o.to_phase_batch(q, qd)
+            t0 = time.perf_counter()
+            o.step_ham_batch(q, p, dt)
+            probe_t = time.perf_counter() - t0
+            S = int(min(1 << 20, max(64, S * min(64.0, a.cpu_seconds / max(probe_t, 1e-6)))))
+            q, qd = examples.sample_config(spec, 0, S)
+            p = o.to_phase_batch(q, qd)
+            t0 = time.perf_counter()
+            oq, op, ons = o.step_ham_batch(q, p, dt)
+            elc = time.perf_counter() - t0
+            g = api.stepHam(dt, s, api.Phase(torch.from_numpy(q).cuda(), torch.from_numpy(p).cuda()))
+            gns = s.last_nsub.cpu().numpy()
+            same = gns == ons
+            dq = np.maximum(np.abs(g.positions.cpu().numpy() - oq).max(0), np.abs(g.momenta.cpu().numpy() - op).max(0))
+            out["cpu_baseline"] = {"value": S / elc, "unit": "trajectory-stepHam/s", "cores": cores, "kind": "port",
+                                   "sample": f"{S} trajectories x one stepHam({dt}) of the same seeded ensemble, oracle (OpenMP, {cores} threads), {elc:.1f} s",
+                                   "reference_haskell": probe_reference_toolchain()}
+            out["parity"] = {"identical_substep_counts_frac": float(same.mean()), "max_abs_dphase_all_lanes": float(dq.max()),
+                             "max_abs_dphase_lanes_with_identical_counts": float(dq[same].max()) if same.any() else None,
+                             "trajectories": S, "reference": "oracle (CPU restatement of GSL rkf45 + standard controller; reference toolchain absent)"}
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

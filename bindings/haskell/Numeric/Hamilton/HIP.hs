@@ -33,6 +33,11 @@ module Numeric.Hamilton.HIP
   ( HipSystem
   , traceSystem
   , traceSystem'
+    -- * the library's choices as an explicit record (hamk.h @hamk_options@; 0 = HAMK_AUTO)
+  , Options (..)
+  , defaultOptions
+  , traceSystemWith
+  , traceSystemWith'
   , Ensemble (..)
   , toPhaseBatch
   , fromPhaseBatch
@@ -99,9 +104,30 @@ instance Storable Op where
   poke p (Op o a b c) = pokeByteOff p 0 o >> pokeByteOff p 4 a >> pokeByteOff p 8 b
                      >> pokeByteOff p 12 (0 :: Int32) >> pokeByteOff p 16 c
 
-foreign import ccall safe "hamk_system_create"
-  c_system_create :: Int32 -> Int32 -> Ptr Double -> Ptr Op -> Int32 -> Ptr Int32
-                  -> Ptr Op -> Int32 -> Int32 -> Int32 -> Ptr (Ptr HamkSystem) -> IO CInt
+foreign import ccall safe "hamk_system_create_ex"
+  c_system_create_ex :: Int32 -> Int32 -> Ptr Double -> Ptr Op -> Int32 -> Ptr Int32
+                     -> Ptr Op -> Int32 -> Int32 -> Int32 -> Ptr Options -> Ptr (Ptr HamkSystem) -> IO CInt
+
+-- | @hamk_options@ (include/hamk.h): everything the library otherwise decides for itself when it specialises its
+--   kernels for a system.  0 (@HAMK_AUTO@) leaves a choice to the library; the numeric values are the header's
+--   (@HAMK_MAP_*@, @HAMK_AD_*@, @HAMK_BODY_*@, @HAMK_TRIG_*@, @HAMK_ON@ = 1 / @HAMK_OFF@ = 2).
+data Options = Options
+  { optMapping, optAdMode, optRk4Body, optRkfBody, optTrig, optGslApi, optSelfCheck, optBuild
+  , optWaveBlocked, optRk4MinWaves, optKReassoc, optRk4Park, optMaxSubsteps, optCache :: Int32 }
+
+defaultOptions :: Options
+defaultOptions = Options 0 0 0 0 0 0 0 0 0 0 0 0 0 0
+
+instance Storable Options where
+  sizeOf _ = 128                                   -- uint32 size, 14 choices, lanes_per_trajectory (output), reserved[16]
+  alignment _ = 4
+  peek p = Options <$> f 4 <*> f 8 <*> f 12 <*> f 16 <*> f 20 <*> f 24 <*> f 28 <*> f 32 <*> f 36 <*> f 40 <*> f 44
+                   <*> f 48 <*> f 52 <*> f 56
+    where f = peekByteOff p
+  poke p (Options a b c d e g h i j k l m' n' o') = do
+    mapM_ (\off -> pokeByteOff p off (0 :: Int32)) [0, 4 .. 124]
+    pokeByteOff p 0 (128 :: Word32)
+    mapM_ (\(off, v) -> pokeByteOff p off v) (zip [4, 8 ..] [a, b, c, d, e, g, h, i, j, k, l, m', n', o'])
 foreign import ccall "&hamk_system_destroy"
   p_system_destroy :: FunPtr (Ptr HamkSystem -> IO ())
 foreign import ccall safe "hamk_to_phase_batch"
@@ -318,15 +344,15 @@ canonical ops outs = (reverse rev, map (newId M.!) outs)
           in (M.insert node next' seen', Op c a' b' d : acc', next' + 1)
 
 create :: forall m n. (KnownNat m, KnownNat n)
-       => Int32 -> [Double] -> ([Traced] -> [Traced]) -> ([Traced] -> Traced) -> IO (HipSystem m n)
-create uSpace inertia f u = do
+       => Options -> Int32 -> [Double] -> ([Traced] -> [Traced]) -> ([Traced] -> Traced) -> IO (HipSystem m n)
+create opts uSpace inertia f u = do
   let m = fromIntegral (natVal (Proxy @m)); n = fromIntegral (natVal (Proxy @n))
   (fOps, fOuts) <- record n f
   (uOps, [uOut]) <- record (if uSpace == 1 then m else n) (pure . u)
   withArrayLen inertia $ \_ pI -> withArrayLen fOps $ \nf pF -> withArray fOuts $ \pFO ->
-    withArrayLen uOps $ \nu pU -> alloca $ \pH -> do
-      c_system_create (fromIntegral m) (fromIntegral n) pI pF (fromIntegral nf) pFO
-                      pU (fromIntegral nu) uOut uSpace pH >>= check "mkSystem"
+    withArrayLen uOps $ \nu pU -> alloca $ \pH -> with opts $ \pO -> do
+      c_system_create_ex (fromIntegral m) (fromIntegral n) pI pF (fromIntegral nf) pFO
+                         pU (fromIntegral nu) uOut uSpace pO pH >>= check "mkSystem"
       HipSystem <$> (peek pH >>= newForeignPtr p_system_destroy)
 
 -- | 'mkSystem' (Hamilton.hs:201-225): potential over generalized coordinates.
@@ -335,7 +361,16 @@ traceSystem :: forall m n. (KnownNat m, KnownNat n)
             -> (forall a. RealFloat a => V.Vector n a -> V.Vector m a)
             -> (forall a. RealFloat a => V.Vector n a -> a)
             -> IO (HipSystem m n)
-traceSystem w f u = create 0 (V.toList w) (V.toList . f . unsafeSized) (u . unsafeSized)
+traceSystem = traceSystemWith defaultOptions
+
+-- | 'traceSystem' with the library's choices fixed by the caller.
+traceSystemWith :: forall m n. (KnownNat m, KnownNat n)
+                => Options
+                -> V.Vector m Double
+                -> (forall a. RealFloat a => V.Vector n a -> V.Vector m a)
+                -> (forall a. RealFloat a => V.Vector n a -> a)
+                -> IO (HipSystem m n)
+traceSystemWith o w f u = create o 0 (V.toList w) (V.toList . f . unsafeSized) (u . unsafeSized)
 
 -- | 'mkSystem'' (Hamilton.hs:238-254): potential over the underlying cartesian coordinates.
 traceSystem' :: forall m n. (KnownNat m, KnownNat n)
@@ -343,7 +378,16 @@ traceSystem' :: forall m n. (KnownNat m, KnownNat n)
              -> (forall a. RealFloat a => V.Vector n a -> V.Vector m a)
              -> (forall a. RealFloat a => V.Vector m a -> a)
              -> IO (HipSystem m n)
-traceSystem' w f u = create 1 (V.toList w) (V.toList . f . unsafeSized) (u . unsafeSized)
+traceSystem' = traceSystemWith' defaultOptions
+
+-- | "traceSystem'" with the library's choices fixed by the caller.
+traceSystemWith' :: forall m n. (KnownNat m, KnownNat n)
+                 => Options
+                 -> V.Vector m Double
+                 -> (forall a. RealFloat a => V.Vector n a -> V.Vector m a)
+                 -> (forall a. RealFloat a => V.Vector m a -> a)
+                 -> IO (HipSystem m n)
+traceSystemWith' o w f u = create o 1 (V.toList w) (V.toList . f . unsafeSized) (u . unsafeSized)
 
 unsafeSized :: forall k a. KnownNat k => [a] -> V.Vector k a
 unsafeSized xs = case V.fromList xs of

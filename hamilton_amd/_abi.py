@@ -35,11 +35,46 @@ _ip = ctypes.c_void_p          # int32_t*
 _h = ctypes.c_void_p           # hamk_system*
 _i32, _i64, _f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 
+AUTO, ON, OFF = 0, 1, 2
+MAP_LANE, MAP_WAVE, MAP_QUAD = 1, 2, 3
+AD_H, AD_D, AD_R = 1, 2, 3
+BODY_UNROLLED, BODY_STAGE_LOOP = 1, 2
+TRIG_DIRECT, TRIG_TABLE, TRIG_TABLE_ROTATE = 1, 2, 3
+BUILD_DEFAULT, BUILD_NOLICM = 1, 2
+
+
+class HamkOptions(ctypes.Structure):
+    """`hamk_options` of include/hamk.h: what the library otherwise decides for itself (0 = HAMK_AUTO)."""
+    _fields_ = [("size", ctypes.c_uint32), ("mapping", ctypes.c_int32), ("ad_mode", ctypes.c_int32),
+                ("rk4_body", ctypes.c_int32), ("rkf_body", ctypes.c_int32), ("trig", ctypes.c_int32),
+                ("gsl_api", ctypes.c_int32), ("self_check", ctypes.c_int32), ("build", ctypes.c_int32),
+                ("wave_blocked", ctypes.c_int32), ("rk4_min_waves", ctypes.c_int32), ("k_reassoc", ctypes.c_int32),
+                ("rk4_park", ctypes.c_int32), ("max_substeps", ctypes.c_int32), ("cache", ctypes.c_int32),
+                ("lanes_per_trajectory", ctypes.c_int32), ("reserved", ctypes.c_int32 * 16)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.size = ctypes.sizeof(HamkOptions)
+        for k, v in kw.items():
+            if k not in dict(self._fields_) or k in ("size", "reserved"):
+                raise TypeError(f"hamk_options has no field {k!r}")
+            setattr(self, k, int(v))
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k not in ("size", "reserved")}
+
+
 # name -> (restype, argtypes); mirrors include/hamk.h declaration by declaration
 SIGNATURES = {
     "hamk_system_create": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(HamkOp), _i32, ctypes.POINTER(ctypes.c_int32),
                                           ctypes.POINTER(HamkOp), _i32, _i32, _i32, ctypes.POINTER(_h)]),
+    "hamk_system_create_ex": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(ctypes.c_double),
+                                             ctypes.POINTER(HamkOp), _i32, ctypes.POINTER(ctypes.c_int32),
+                                             ctypes.POINTER(HamkOp), _i32, _i32, _i32, ctypes.POINTER(HamkOptions), ctypes.POINTER(_h)]),
+    "hamk_options_init": (None, [ctypes.POINTER(HamkOptions)]),
+    "hamk_system_get_options": (ctypes.c_int, [_h, _i64, ctypes.POINTER(HamkOptions)]),
+    "hamk_system_describe_batch": (ctypes.c_int, [_h, _i64]),
     "hamk_system_destroy": (None, [_h]),
     "hamk_system_dims": (ctypes.c_int, [_h, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "hamk_set_stream": (ctypes.c_int, [_h, ctypes.c_void_p]),
@@ -99,8 +134,20 @@ def _default_cache_dir():
     if "HAMK_CACHE_DIR" in os.environ:
         return
     d = os.path.join(os.path.dirname(_HERE), ".hamk_cache")
-    if os.path.isdir(d):
+    try:
+        st = os.lstat(d)
+    except OSError:
+        return
+    import stat
+    # the same test libhamk applies (hamk_api.cpp private_dir): a real directory of ours nobody else can touch.  A tree
+    # unpacked by another user or with group/other bits fails it -- and libhamk has no fallback once HAMK_CACHE_DIR names
+    # a rejected directory: then leave it unset, so the per-user cache ($XDG_CACHE_HOME/hamk, ~/.cache/hamk) applies.
+    if stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0:
         os.environ["HAMK_CACHE_DIR"] = d
+    else:
+        import warnings
+        warnings.warn(f"{d} is not an owner-only directory of this user: the in-tree code-object cache is ignored "
+                      "(chmod 700 it, or set HAMK_CACHE_DIR)", RuntimeWarning, stacklevel=2)
 
 
 def lib():

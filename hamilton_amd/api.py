@@ -165,7 +165,10 @@ Cfg, Phs = Config, Phase
 class System:
     """Opaque `System m n` (Hamilton.hs:160-169): owns a libhamk handle."""
 
-    def __init__(self, m: int, n: int, inertia, tape_f: T.Tape, tape_u: T.Tape, u_space: int):
+    def __init__(self, m: int, n: int, inertia, tape_f: T.Tape, tape_u: T.Tape, u_space: int, options=None):
+        """options: a `hamilton_amd._abi.HamkOptions` or a dict of its fields (hamk.h `hamk_options`; unset = the
+        library's own choice) -- which lanes serve a trajectory, AD strategy, stepping bodies, sincos policy, GSL
+        binding, self-check ...  Environment variables remain as test overrides of whatever is left to the library."""
         self.m, self.n = int(m), int(n)
         self.u_space = u_space
         self.tape_f, self.tape_u = tape_f, tape_u
@@ -176,8 +179,10 @@ class System:
         u_ops, u_n, _ = tape_u.as_ctypes()
         w = (ctypes.c_double * self.m)(*[float(v) for v in inertia])
         h = ctypes.c_void_p()
-        _abi.check(L.hamk_system_create(self.m, self.n, w, f_ops, f_n, f_outs, u_ops, u_n, tape_u.outs[0],
-                                        u_space, ctypes.byref(h)))
+        if isinstance(options, dict):
+            options = _abi.HamkOptions(**options)
+        _abi.check(L.hamk_system_create_ex(self.m, self.n, w, f_ops, f_n, f_outs, u_ops, u_n, tape_u.outs[0],
+                                           u_space, ctypes.byref(options) if options is not None else None, ctypes.byref(h)))
         self._h = h
 
     def __del__(self):
@@ -187,6 +192,27 @@ class System:
                 self._h = None
         except Exception:
             pass
+
+    def options(self, B: int = -1) -> dict:
+        """What a launch over B trajectories uses (B < 0: a large ensemble), every choice resolved
+        (hamk_system_get_options): mapping, ad_mode, bodies, trig, ..., lanes_per_trajectory."""
+        o = _abi.HamkOptions()
+        _abi.check(_abi.lib().hamk_system_get_options(self._h, int(B), ctypes.byref(o)))
+        return o.as_dict()
+
+    def describe_batch(self, B: int = -1):
+        """`source`, `build_info`, `code_size`, `code_object`, `kernel_bytes` below describe the specialisation a launch
+        over B trajectories uses (default: the one built at creation = the large-ensemble one)."""
+        _abi.check(_abi.lib().hamk_system_describe_batch(self._h, int(B)))
+        return self
+
+    @property
+    def lanes_per_trajectory(self) -> int:
+        """1 (lane kernels), 4 (quad), 16 / 32 / 64 (wave-cooperative) -- of the specialisation being described."""
+        src = self.source
+        if "HAMK_INSTANTIATE_WAVE" in src:
+            return 16 if self.n <= 16 else (32 if self.n <= 32 else 64)
+        return 4 if "HAMK_INSTANTIATE_QUAD" in src else 1
 
     @property
     def source(self) -> str:
@@ -253,26 +279,26 @@ class System:
                 raise SingularSystem(f"{what}: mass matrix J^T M J is singular")
 
 
-def mkSystem(inertia, f: Callable, u: Callable, n: int) -> System:
+def mkSystem(inertia, f: Callable, u: Callable, n: int, options=None) -> System:
     """mkSystem (Hamilton.hs:201-225): potential over GENERALIZED coordinates.
 
     `f(q)` maps a list of n values to m values, `u(q)` to a scalar; both written
     against hamilton_amd's traced arithmetic (the `RealFloat a` of the reference).
     m = len(inertia); n cannot be read off a Python function and is explicit."""
     m = len(inertia)
-    return System(m, n, inertia, T.trace(f, n, m), T.trace(u, n, None), U_GENERALIZED)
+    return System(m, n, inertia, T.trace(f, n, m), T.trace(u, n, None), U_GENERALIZED, options)
 
 
-def mkSystem_(inertia, f: Callable, u: Callable, n: int) -> System:
+def mkSystem_(inertia, f: Callable, u: Callable, n: int, options=None) -> System:
     """mkSystem' (Hamilton.hs:238-254): potential over the underlying CARTESIAN coordinates."""
     m = len(inertia)
-    return System(m, n, inertia, T.trace(f, n, m), T.trace(u, m, None), U_CARTESIAN)
+    return System(m, n, inertia, T.trace(f, n, m), T.trace(u, m, None), U_CARTESIAN, options)
 
 
-def system_from_spec(spec) -> System:
+def system_from_spec(spec, options=None) -> System:
     """Build a System from a hamilton_amd.examples.SystemSpec."""
     tf, tu = spec.trace()
-    return System(spec.m, spec.n, spec.inertia, tf, tu, spec.u_space)
+    return System(spec.m, spec.n, spec.inertia, tf, tu, spec.u_space, options)
 
 
 # ---------------------------------------------------------------------------------------

@@ -32,6 +32,9 @@ static const char kDeviceHeader[] =
 static const char kWaveHeader[] =
 #include "hamk_wave_src.inc"
     ;
+static const char kQuadHeader[] =
+#include "hamk_quad_src.inc"
+    ;
 
 static thread_local std::string g_last_error;
 
@@ -47,10 +50,44 @@ static int fail(int code, const std::string& msg) {
       return fail(HAMK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
   } while (0)
 
+#define TRY0(expr) do { int rc0_ = (expr); if (rc0_ != HAMK_OK) return rc0_; } while (0)
+
 enum KernelId { K_RK4, K_HAMEQS, K_COORDS, K_TO_PHASE, K_FROM_PHASE, K_OBSERVE, K_OBSERVE_CFG, K_RKF45, K_SCRIBBLE, K__COUNT };
 static const char* kKernelNames[K__COUNT] = {"hamk_rk4_steps_k", "hamk_hameqs_k",  "hamk_coords_k",         "hamk_to_phase_k",
                                              "hamk_from_phase_k", "hamk_observe_k", "hamk_observe_config_k", "hamk_rkf45_k",
                                              "hamk_scribble_k"};
+
+// One specialisation of the device library for a system: which lanes serve a trajectory (hamk.h HAMK_MAP_*) and the
+// choices that go with it.  A handle builds the one its options name -- or, with mapping = HAMK_AUTO, the one a large
+// ensemble uses -- when it is created, and the others the first time a launch asks for them.
+struct Variant {
+  int mapping = HAMK_MAP_LANE;
+  SystemDesc desc;
+  std::string source;
+  std::vector<char> code;      // gfx950 code object (default options)
+  std::vector<char> code2;     // the same source built without MachineLICM; empty unless some kernel is taken from it
+  bool use2[K__COUNT] = {};    // kernel k comes from code2 (it spills no / fewer SGPRs there)
+  std::string build_log;
+  std::string build_info;      // per kernel: which build it comes from, bytes, spilled SGPRs
+  int generation = 0;          // bumped whenever `code` is rebuilt (the self-check's recovery path)
+  int self_check_rebuilds = 0;
+  bool forced_rk4_body = false, forced_rkf_body = false;
+  bool has[K__COUNT] = {};     // the kernels this module provides (the quad module: four of the eight)
+};
+constexpr int kMaxMap = 4;     // HAMK_MAP_* ids are 1..3
+
+// The modules of one Variant on one device.
+struct DevModule {
+  hipModule_t module = nullptr;
+  hipModule_t module2 = nullptr;
+  hipFunction_t fn[K__COUNT] = {};
+  bool self_checked = false;
+  int code_generation = -1;     // Variant::generation the loaded modules were built from
+  void unload() {
+    if (module) { hipModuleUnload(module); module = nullptr; }
+    if (module2) { hipModuleUnload(module2); module2 = nullptr; }
+  }
+};
 
 // What a handle owns on ONE device.  A handle used from several devices (one process driving every
 // GPU of a node, or a torch program whose tensors live on cuda:1 while cuda:0 is current) keeps one
@@ -58,9 +95,10 @@ static const char* kKernelNames[K__COUNT] = {"hamk_rk4_steps_k", "hamk_hameqs_k"
 // alternate between devices.
 struct DevState {
   int device = -1;
-  hipModule_t module = nullptr;
-  hipModule_t module2 = nullptr;
-  hipFunction_t fn[K__COUNT] = {};
+  DevModule mod[kMaxMap];
+  // the stream this handle launches on ON THIS DEVICE (hamk_set_stream binds it to the device that is current
+  // at the time: a stream belongs to one device, and a handle may be used from several)
+  hipStream_t stream = nullptr;
   // grow-only device staging for HAMK_MEM_HOST calls (slot i serves the i-th staged array of a
   // call): the reference's own usage pattern is one small stepHam per frame (Examples.hs:429),
   // where a hipMalloc/hipFree pair per array per call would dominate
@@ -79,14 +117,8 @@ struct DevState {
   double* d_ts = nullptr;
   size_t d_ts_cap = 0;
   std::vector<double> h_ts;
-  bool self_checked = false;
-  int code_generation = -1;     // hamk_system::generation the loaded modules were built from
-  void unload() {
-    if (module) { hipModuleUnload(module); module = nullptr; }
-    if (module2) { hipModuleUnload(module2); module2 = nullptr; }
-  }
   void release() {
-    unload();
+    for (DevModule& m : mod) m.unload();
     if (d_ts) { hipFree(d_ts); d_ts = nullptr; d_ts_cap = 0; }
     for (void*& b : stage_buf) if (b) { hipFree(b); b = nullptr; }
     stage_cap.assign(stage_cap.size(), 0);
@@ -95,20 +127,19 @@ struct DevState {
 };
 
 struct hamk_system {
-  SystemDesc desc;
-  std::string source;
-  std::vector<char> code;      // gfx950 code object (default options)
-  std::vector<char> code2;     // the same source built without MachineLICM; empty unless some kernel is taken from it
-  bool use2[K__COUNT] = {};    // kernel k comes from code2 (it spills no / fewer SGPRs there)
-  std::string build_log;
-  std::string build_info;      // per kernel: which build it comes from, bytes, spilled SGPRs
-  int generation = 0;          // bumped whenever `code` is rebuilt (the self-check's recovery path)
+  SystemDesc base;             // m, n, inertia, tapes: what every specialisation shares
+  hamk_options opt;            // as the caller gave them (HAMK_AUTO where the choice is the library's)
+  Variant* var[kMaxMap] = {};  // by mapping id; built on demand
+  Variant* curv = nullptr;     // the specialisation the call in progress uses
+  Variant* info = nullptr;     // the one the introspection entry points describe (hamk_system_describe_batch)
   // lazily bound to the calling thread's current device, one DevState per device ever used
   std::vector<DevState*> devs;
   DevState* cur = nullptr;
-  hipStream_t stream = nullptr;
   int gsl_api = 2;             // which binding of hmatrix-gsl's gsl-ode.c stepHam/evolveHam follow (hamk.h)
-  int self_check_rebuilds = 0;
+  int max_substeps = 1 << 24;
+  bool self_check_on = true, cache_on = true;
+  int quad_eligible = -1;      // -1: not analysed yet
+  DevModule& mod() { return cur->mod[curv->mapping]; }
 };
 
 // ---------------------------------------------------------------------------
@@ -219,10 +250,10 @@ static std::string cache_dir() {
 
 struct CacheKey { std::string path; unsigned char sha[32]; };
 
-static CacheKey cache_key(const hamk_system* s, const std::vector<const char*>& opts) {
+static CacheKey cache_key(const Variant* s, const std::vector<const char*>& opts, bool cache_on) {
   CacheKey k;
   std::memset(k.sha, 0, sizeof k.sha);
-  const std::string dir = cache_dir();
+  const std::string dir = cache_on ? cache_dir() : std::string();
   if (dir.empty()) return k;
   int major = 0, minor = 0;
   hiprtcVersion(&major, &minor);
@@ -232,6 +263,7 @@ static CacheKey cache_key(const hamk_system* s, const std::vector<const char*>& 
   feed(s->source.data(), s->source.size());
   feed(kDeviceHeader, sizeof kDeviceHeader);
   feed(kWaveHeader, sizeof kWaveHeader);
+  feed(kQuadHeader, sizeof kQuadHeader);
   for (const char* o : opts) feed(o, std::strlen(o) + 1);
   feed(&major, sizeof major);
   feed(&minor, sizeof minor);
@@ -277,19 +309,26 @@ static void cache_store(const CacheKey& k, const std::vector<char>& code) {   //
   if (!out || std::rename(tmp.c_str(), k.path.c_str()) != 0) std::remove(tmp.c_str());
 }
 
-static int compile_module(hamk_system* s, bool no_machine_licm, std::vector<char>& code) {
+static int compile_module(Variant* s, bool cache_on, bool no_machine_licm, std::vector<char>& code) {
   hiprtcProgram prog = nullptr;
-  const char* hdr_src[] = {kDeviceHeader, kWaveHeader};
-  const char* hdr_name[] = {"hamk_device.hpp", "hamk_wave.hpp"};
-  hiprtcResult r = hiprtcCreateProgram(&prog, s->source.c_str(), "hamk_system.hip", 2, hdr_src, hdr_name);
+  const char* hdr_src[] = {kDeviceHeader, kWaveHeader, kQuadHeader};
+  const char* hdr_name[] = {"hamk_device.hpp", "hamk_wave.hpp", "hamk_quad.hpp"};
+  hiprtcResult r = hiprtcCreateProgram(&prog, s->source.c_str(), "hamk_system.hip", 3, hdr_src, hdr_name);
   if (r != HIPRTC_SUCCESS) return fail(HAMK_ERR_COMPILE, std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r));
   std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast",
                                    "-fno-honor-nans", "-fno-signed-zeros"};
-  if (s->desc.wave) {
+  if (s->desc.wave || s->desc.mapping == HAMK_MAP_QUAD) {
     // CodeGenPrepare's address sinking is quadratic in the thousands of LDS accesses of the
     // straight-line wave kernels (chain32: 170 s of a 200 s build); it is an optimisation pass only
     opts.push_back("-mllvm");
     opts.push_back("-disable-cgp");
+  }
+  if (s->desc.mapping == HAMK_MAP_QUAD) {
+    // the factorisation is written as loops over literal bounds that MUST unroll completely (rows of K are registers, not
+    // memory): ~10^4 FMAs at n = 32, beyond the default cap on `#pragma unroll` (16 K instructions of estimated size) --
+    // with the cap in force the inner loops stay rolled and K is indexed dynamically, i.e. lives in scratch
+    opts.push_back("-mllvm");
+    opts.push_back("-pragma-unroll-threshold=4194304");
   }
   if (no_machine_licm) {
     opts.push_back("-mllvm");
@@ -308,7 +347,7 @@ static int compile_module(hamk_system* s, bool no_machine_licm, std::vector<char
     }
     for (auto& t : extra_tok) opts.push_back(t.c_str());
   }
-  const CacheKey ckey = cache_key(s, opts);
+  const CacheKey ckey = cache_key(s, opts, cache_on);
   if (!ckey.path.empty() && cache_load(ckey, code)) {
     s->build_log = "cache hit: " + ckey.path;
     hiprtcDestroyProgram(&prog);
@@ -395,7 +434,7 @@ static int sgpr_spill_count(const std::vector<char>& elf, const char* kernel) {
   return -1;
 }
 
-static void describe_build(hamk_system* s);
+static void describe_build(Variant* s);
 
 // Build the code object(s) of s->source.  Kernels that spill SGPRs under the default options are
 // taken from a second build without MachineLICM when that build spills fewer: the hoisting of the
@@ -403,21 +442,20 @@ static void describe_build(hamk_system* s);
 // literal is an SGPR pair on gfx9), re-materialising them in place costs a few SALU moves, and the
 // one kernel found giving run-to-run different results is correct again
 // without its 101 spilled SGPRs.  Spill-free kernels keep the default build (the headline RK4
-// kernel is 3 % faster with the hoisting).  HAMK_NOLICM=0 / 1 forces one build for experiments.
-static int build_code(hamk_system* s) {
+// kernel is 3 % faster with the hoisting).  force (hamk_options::build / HAMK_NOLICM): 0 the default build only,
+// 1 the build without MachineLICM only, -1 per kernel.
+static int build_code(Variant* s, bool cache_on, int force) {
   s->code2.clear();
   for (bool& u : s->use2) u = false;
-  int rc = compile_module(s, false, s->code);
+  int rc = compile_module(s, cache_on, false, s->code);
   if (rc != HAMK_OK) return rc;
-  int force = -1;
-  if (const char* e = std::getenv("HAMK_NOLICM")) force = (e[0] == '1') ? 1 : (e[0] == '0' ? 0 : -1);
   if (force == 0) { describe_build(s); return HAMK_OK; }
   int spills[K__COUNT];
   bool any = false;
   for (int k = 0; k < K__COUNT; ++k) { spills[k] = sgpr_spill_count(s->code, kKernelNames[k]); any = any || spills[k] > 0; }
   if (!any && force != 1) { describe_build(s); return HAMK_OK; }
   std::vector<char> alt;
-  rc = compile_module(s, true, alt);
+  rc = compile_module(s, cache_on, true, alt);
   if (rc != HAMK_OK) return rc;
   bool used = false;
   for (int k = 0; k < K__COUNT; ++k) {
@@ -430,7 +468,7 @@ static int build_code(hamk_system* s) {
   return HAMK_OK;
 }
 
-static void describe_build(hamk_system* s) {
+static void describe_build(Variant* s) {
   std::string t;
   for (int k = 0; k < K__COUNT; ++k) {
     const std::vector<char>& c = s->use2[k] ? s->code2 : s->code;
@@ -443,14 +481,20 @@ static void describe_build(hamk_system* s) {
   s->build_info = t;
 }
 
-static size_t chosen_kernel_bytes(const hamk_system* s, int k) {
+static size_t chosen_kernel_bytes(const Variant* s, int k) {
   return kernel_code_bytes(s->use2[k] ? s->code2 : s->code, kKernelNames[k]);
+}
+
+static int build_force(const hamk_system* s) {                      // hamk_options::build, else HAMK_NOLICM (tests), else per kernel
+  if (s->opt.build == HAMK_BUILD_DEFAULT) return 0;
+  if (s->opt.build == HAMK_BUILD_NOLICM) return 1;
+  if (const char* e = std::getenv("HAMK_NOLICM")) return (e[0] == '1') ? 1 : (e[0] == '0' ? 0 : -1);
+  return -1;
 }
 
 static int launch(hamk_system* s, KernelId k, int64_t B, void** args);
 // the flags argument of hamk_rkf45_k (hamk_device.hpp rkf45_body)
 static int rkf_flags(int row0, int inplace, int gsl_api) { return (row0 & 1) | ((inplace & 3) << 8) | ((gsl_api & 3) << 16); }
-static int build_code(hamk_system* s);
 static int load_modules(hamk_system* s);
 
 // ---------------------------------------------------------------------------
@@ -466,7 +510,7 @@ static const double kRefEpsilon = 1.49012e-08;   // Hamilton.hs:448
 static thread_local std::string g_selfcheck_detail;
 static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
   g_selfcheck_detail.clear();
-  const int n = s->desc.n;
+  const int n = s->base.n;
   const int64_t B = 64;
   const size_t cnt = (size_t)n * B;
   std::vector<double> q(cnt), p(cnt), k(2 * cnt), acc(2 * cnt), yt(2 * cnt);
@@ -494,7 +538,7 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
     void* args[] = {&cq, &cp, &d_dq, &d_dp, &b, &st};
     int rc = launch(s, K_HAMEQS, B, args);
     if (rc != HAMK_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(s->cur->stream));
     HIP_TRY(hipMemcpy(out.data(), d_dq, cnt * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out.data() + cnt, d_dp, cnt * 8, hipMemcpyDeviceToHost));
     std::vector<int32_t> hst((size_t)B);
@@ -545,13 +589,14 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
       double ddt = dt, no_drift = 0.0; int ns = 1; int32_t* st = d_st;
       void* args[] = {&d_q, &d_p, &b, &ddt, &ns, &no_drift, &st};
       rc = launch(s, K_RK4, B, args);
-      if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RK4 kernel failed");
+      if (rc == HAMK_OK && hipStreamSynchronize(s->cur->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RK4 kernel failed");
       hipMemcpy(got.data(), d_q, cnt * 8, hipMemcpyDeviceToHost); hipMemcpy(got.data() + cnt, d_p, cnt * 8, hipMemcpyDeviceToHost);
       *rk4_ok = close_enough(got, ref, &usable, "one RK4 step");
     }
   }
   // ---- RKF45: one accepted sub-step (h = dt, huge tolerances, t: 0 -> dt) ---------------------
-  if (rc == HAMK_OK && usable) {
+  const bool has_rkf = s->curv->has[K_RKF45];              // (the quad module leaves the adaptive stepper to the wave module)
+  if (rc == HAMK_OK && usable && has_rkf) {
     static const double A[5][5] = {{1.0 / 4, 0, 0, 0, 0},
                                    {3.0 / 32, 9.0 / 32, 0, 0, 0},
                                    {1932.0 / 2197, -7200.0 / 2197, 7296.0 / 2197, 0, 0},
@@ -581,7 +626,7 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
       int ncalls = 1, it_every = 0;
       void* args[] = {&cq, &cp, &d_q, &d_p, &b, &nt, &cts, &t0, &t1, &h0, &ea, &er, &flags, &max_sub, &st, &ns, &ncalls, &it_every};
       rc = launch(s, K_RKF45, B, args);
-      if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RKF45 kernel failed");
+      if (rc == HAMK_OK && hipStreamSynchronize(s->cur->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RKF45 kernel failed");
       hipMemcpy(got.data(), d_q, cnt * 8, hipMemcpyDeviceToHost); hipMemcpy(got.data() + cnt, d_p, cnt * 8, hipMemcpyDeviceToHost);
       *rkf_ok = close_enough(got, ref, &usable, "one accepted RKF45 sub-step");
     }
@@ -620,7 +665,7 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
       // agrees with itself back to back and differs once something else has used the registers.
       auto scribble = [&](unsigned seed) {
         void* as[] = {&seed};
-        if (hipModuleLaunchKernel(s->cur->fn[K_SCRIBBLE], 2048, 1, 1, 256, 1, 1, 0, s->stream, as, nullptr) != hipSuccess) (void)hipGetLastError();
+        if (hipModuleLaunchKernel(s->mod().fn[K_SCRIBBLE], 2048, 1, 1, 256, 1, 1, 0, s->cur->stream, as, nullptr) != hipSuccess) (void)hipGetLastError();
       };
       for (int r = 0; r < 2 && rc == HAMK_OK; ++r) {         // the fixed-step kernel, twice as well
         scribble(0x9e3779b9u * (unsigned)(r + 1));
@@ -628,7 +673,7 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
         double ddt = T / 64, no_drift = 0.0; int ns = 64;
         void* a4[] = {&e_q, &e_p, &b3, &ddt, &ns, &no_drift, &e_st};
         rc = launch(s, K_RK4, B3, a4);
-        if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RK4 kernel failed");
+        if (rc == HAMK_OK && hipStreamSynchronize(s->cur->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RK4 kernel failed");
         download(r == 0 ? ref3 : ref3b);
       }
       hipMemcpy(st_ref.data(), e_st, B3 * 4, hipMemcpyDeviceToHost);
@@ -636,7 +681,7 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
         *rk4_ok = false;
         g_selfcheck_detail = "two runs of the RK4 kernel on the same input DIFFER";
       }
-      for (int r = 0; r < 2 && rc == HAMK_OK; ++r) {
+      for (int r = 0; r < 2 && rc == HAMK_OK && has_rkf; ++r) {
         scribble(0x85ebca6bu * (unsigned)(r + 3));
         upload();
         double h0 = T / 100, ea = kRefEpsilon, er = kRefEpsilon, t0 = 0.0, t1 = T;
@@ -645,12 +690,12 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
         int ncalls = 1, it_every = 0;
         void* a5[] = {&cq, &cp, &e_q, &e_p, &b3, &nt, &cts, &t0, &t1, &h0, &ea, &er, &flags, &max_sub, &e_st, &e_ns, &ncalls, &it_every};
         rc = launch(s, K_RKF45, B3, a5);
-        if (rc == HAMK_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RKF45 kernel failed");
+        if (rc == HAMK_OK && hipStreamSynchronize(s->cur->stream) != hipSuccess) rc = fail(HAMK_ERR_HIP, "self-check: RKF45 kernel failed");
         download(run[r]);
         hipMemcpy(st_run[r].data(), e_st, B3 * 4, hipMemcpyDeviceToHost);
         hipMemcpy(ns_run[r].data(), e_ns, B3 * 4, hipMemcpyDeviceToHost);
       }
-      if (rc == HAMK_OK) {
+      if (rc == HAMK_OK && has_rkf) {
         bool same = std::memcmp(run[0].data(), run[1].data(), 2 * c3 * 8) == 0 && ns_run[0] == ns_run[1] && st_run[0] == st_run[1];
         double worst = 0.0;
         for (int64_t i = 0; i < B3; ++i) {
@@ -676,52 +721,55 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
     (void)hipGetLastError();
   }
   if (const char* e = std::getenv("HAMK_SELFCHECK_FAULT")) {        // test hook: pretend the unrolled body is wrong
-    if (std::strstr(e, "rk4") && !s->desc.rk4_stage_loop) *rk4_ok = false;
-    if (std::strstr(e, "rkf") && !s->desc.rkf_stage_loop) *rkf_ok = false;
+    if (std::strstr(e, "rk4") && !s->curv->desc.rk4_stage_loop) *rk4_ok = false;
+    if (std::strstr(e, "rkf") && !s->curv->desc.rkf_stage_loop) *rkf_ok = false;
   }
   return rc;
 }
 
 static int self_check(hamk_system* s) {
-  if (const char* e = std::getenv("HAMK_SELFCHECK")) if (e[0] == '0') return HAMK_OK;
-  if (s->cur->self_checked) return HAMK_OK;
+  if (!s->self_check_on) return HAMK_OK;
+  Variant* v = s->curv;
+  if (s->mod().self_checked) return HAMK_OK;
   for (int attempt = 0; attempt < 2; ++attempt) {
     bool rk4_ok = true, rkf_ok = true;
     int rc = self_check_once(s, &rk4_ok, &rkf_ok);
     if (rc != HAMK_OK) return rc;
-    if (rk4_ok && rkf_ok) { s->cur->self_checked = true; return HAMK_OK; }
-    const bool can_retry = attempt == 0 && !s->desc.wave && ((!rk4_ok && !s->desc.rk4_stage_loop) || (!rkf_ok && !s->desc.rkf_stage_loop));
+    if (rk4_ok && rkf_ok) { s->mod().self_checked = true; return HAMK_OK; }
+    const bool can_retry = attempt == 0 && v->mapping == HAMK_MAP_LANE &&
+                           ((!rk4_ok && !v->desc.rk4_stage_loop) || (!rkf_ok && !v->desc.rkf_stage_loop));
     if (!can_retry)
       return fail(HAMK_ERR_COMPILE, std::string("self-check failed: the fused ") + (!rk4_ok ? "RK4" : "RKF45") +
                                         " kernel disagrees with the hamEqs kernel (miscompiled module?)" +
                                         (g_selfcheck_detail.empty() ? "" : " [" + g_selfcheck_detail + "]"));
-    if (!rk4_ok) s->desc.rk4_stage_loop = true;            // rebuild with the stage-loop bodies
-    if (!rkf_ok) s->desc.rkf_stage_loop = true;
-    s->source = generate_source(s->desc);
-    rc = build_code(s);
+    if (!rk4_ok) v->desc.rk4_stage_loop = true;            // rebuild with the stage-loop bodies
+    if (!rkf_ok) v->desc.rkf_stage_loop = true;
+    v->source = generate_source(v->desc);
+    rc = build_code(v, s->cache_on, build_force(s));
     if (rc != HAMK_OK) return rc;
-    s->generation++;                                       // other devices reload (and re-check) lazily
-    for (DevState* d : s->devs) if (d != s->cur) d->self_checked = false;
+    v->generation++;                                       // other devices reload (and re-check) lazily
+    for (DevState* d : s->devs) if (d != s->cur) d->mod[v->mapping].self_checked = false;
     rc = load_modules(s);
     if (rc != HAMK_OK) return rc;
-    s->self_check_rebuilds++;
+    v->self_check_rebuilds++;
   }
   return fail(HAMK_ERR_COMPILE, "self-check failed");
 }
 
 static int load_modules(hamk_system* s) {
-  DevState* d = s->cur;
+  DevModule* d = &s->mod();
+  const Variant* v = s->curv;
   d->unload();
-  HIP_TRY(hipModuleLoadData(&d->module, s->code.data()));
-  if (!s->code2.empty()) HIP_TRY(hipModuleLoadData(&d->module2, s->code2.data()));
+  HIP_TRY(hipModuleLoadData(&d->module, v->code.data()));
+  if (!v->code2.empty()) HIP_TRY(hipModuleLoadData(&d->module2, v->code2.data()));
   for (int k = 0; k < K__COUNT; ++k)
-    HIP_TRY(hipModuleGetFunction(&d->fn[k], (s->use2[k] && d->module2) ? d->module2 : d->module, kKernelNames[k]));
-  d->code_generation = s->generation;
+    if (v->has[k]) HIP_TRY(hipModuleGetFunction(&d->fn[k], (v->use2[k] && d->module2) ? d->module2 : d->module, kKernelNames[k]));
+  d->code_generation = v->generation;
   return HAMK_OK;
 }
 
-// Select (creating it on first use) the state of the calling thread's current device.
-static int bind_device(hamk_system* s) {
+// The state of the calling thread's current device (created on first use; nothing is loaded yet).
+static int current_device_state(hamk_system* s) {
   int dev = -1;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return fail(HAMK_ERR_NODEVICE, std::string("hipGetDevice: ") + hipGetErrorString(e));
@@ -739,22 +787,37 @@ static int bind_device(hamk_system* s) {
       s->cur = d;
     }
   }
-  if (s->cur->module && s->cur->code_generation == s->generation) return HAMK_OK;
-  {
-    const int rc_load = load_modules(s);
-    if (rc_load != HAMK_OK) return rc_load;
-  }
+  return HAMK_OK;
+}
+
+static int variant_for(hamk_system* s, int64_t B, int kernel, Variant** out);
+static std::string check_options(const hamk_options& o, int n);
+
+// Everything a call over B trajectories needs in place: the device state, the specialisation chosen for (n, B) --
+// built on first use --, its modules loaded on this device and self-checked.
+static int bind_device(hamk_system* s, int64_t B, int kernel) {
+  TRY0(current_device_state(s));
+  TRY0(variant_for(s, B, kernel, &s->curv));
+  DevModule& m = s->mod();
+  if (m.module && m.code_generation == s->curv->generation) return HAMK_OK;
+  TRY0(load_modules(s));
   return self_check(s);
+}
+
+static int64_t trajectories_per_block(const Variant* v) {
+  // lane kernels: one trajectory per thread; wave kernels: 64/NP trajectories per wavefront; quad: four lanes each
+  const int n = v->desc.n;
+  if (v->mapping == HAMK_MAP_WAVE) return 4 * (64 / (n <= 16 ? 16 : n <= 32 ? 32 : 64));
+  if (v->mapping == HAMK_MAP_QUAD) return 64;
+  return 256;
 }
 
 static int launch(hamk_system* s, KernelId k, int64_t B, void** args) {
   const unsigned block = 256;
-  // lane kernels: one trajectory per thread; wave kernels: 64/NP trajectories per wavefront
-  int64_t per_block = block;
-  if (s->desc.wave) per_block = 4 * (64 / (s->desc.n <= 16 ? 16 : s->desc.n <= 32 ? 32 : 64));
+  const int64_t per_block = trajectories_per_block(s->curv);
   const int64_t grid = (B + per_block - 1) / per_block;
   if (grid > 0x7fffffffLL) return fail(HAMK_ERR_INVALID, "ensemble too large for one launch");
-  HIP_TRY(hipModuleLaunchKernel(s->cur->fn[k], (unsigned)grid, 1, 1, block, 1, 1, 0, s->stream, args, nullptr));
+  HIP_TRY(hipModuleLaunchKernel(s->mod().fn[k], (unsigned)grid, 1, 1, block, 1, 1, 0, s->cur->stream, args, nullptr));
   return HAMK_OK;
 }
 
@@ -787,8 +850,8 @@ class Stager {
   int finish() {
     if (!host_) return HAMK_OK;
     for (auto& b : bufs_)
-      if (b.out && !b.pinned) HIP_TRY(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, s_->stream));
-    HIP_TRY(hipStreamSynchronize(s_->stream));
+      if (b.out && !b.pinned) HIP_TRY(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, s_->cur->stream));
+    HIP_TRY(hipStreamSynchronize(s_->cur->stream));
     for (auto& b : bufs_)
       if (b.out && b.pinned) std::memcpy(b.host, b.pinned, b.bytes);
     return HAMK_OK;
@@ -807,7 +870,7 @@ class Stager {
     const size_t slot = nstaged_++;
     if (slot >= s_->cur->stage_buf.size()) { s_->cur->stage_buf.push_back(nullptr); s_->cur->stage_cap.push_back(0); }
     if (s_->cur->stage_cap[slot] < bytes) {
-      HIP_TRY(hipStreamSynchronize(s_->stream));          // nobody may still be using the old block
+      HIP_TRY(hipStreamSynchronize(s_->cur->stream));          // nobody may still be using the old block
       if (s_->cur->stage_buf[slot]) hipFree(s_->cur->stage_buf[slot]);
       s_->cur->stage_buf[slot] = nullptr; s_->cur->stage_cap[slot] = 0;
       HIP_TRY(hipMalloc(&s_->cur->stage_buf[slot], bytes));
@@ -815,7 +878,7 @@ class Stager {
     }
     b.dev = s_->cur->stage_buf[slot];
     bufs_.push_back(b);
-    if (copy_in) HIP_TRY(hipMemcpyAsync(b.dev, p, bytes, hipMemcpyHostToDevice, s_->stream));
+    if (copy_in) HIP_TRY(hipMemcpyAsync(b.dev, p, bytes, hipMemcpyHostToDevice, s_->cur->stream));
     *dev = b.dev;
     return HAMK_OK;
   }
@@ -856,6 +919,174 @@ static int check_call(hamk_system* s, int64_t B, int32_t mem) {
   if (!s) return fail(HAMK_ERR_INVALID, "null system handle");
   if (B < 0) return fail(HAMK_ERR_INVALID, "negative ensemble size");
   if (mem != HAMK_MEM_HOST && mem != HAMK_MEM_DEVICE) return fail(HAMK_ERR_INVALID, "mem must be HAMK_MEM_HOST or HAMK_MEM_DEVICE");
+  return HAMK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// options -> specialisations
+// ---------------------------------------------------------------------------
+// Ensemble size below which the wave-cooperative kernels beat the lane kernels (0: never), by n.
+static int64_t lane_wave_crossover(int n) {
+  (void)n;
+  return 0;                                                 // (set from profiles/r03_throughput_vs_B.jsonl)
+}
+
+static bool env_flag(const char* name, bool* value) {           // "0" / "1" test overrides
+  const char* e = std::getenv(name);
+  if (!e || (e[0] != '0' && e[0] != '1')) return false;
+  *value = e[0] == '1';
+  return true;
+}
+
+static std::string check_options(const hamk_options& o, int n) {
+  auto in = [](int v, std::initializer_list<int> ok) { for (int k : ok) if (v == k) return true; return false; };
+  if (!in(o.mapping, {HAMK_AUTO, HAMK_MAP_LANE, HAMK_MAP_WAVE, HAMK_MAP_QUAD})) return "mapping must be HAMK_AUTO or a HAMK_MAP_* value";
+  if (o.mapping == HAMK_MAP_LANE && n > 16) return "unsupported: HAMK_MAP_LANE needs n <= 16 (one trajectory no longer fits one lane)";
+  if (o.mapping == HAMK_MAP_QUAD && n > 32) return "unsupported: HAMK_MAP_QUAD needs n <= 32 (a lane holds a quarter of K in registers)";
+  if (!in(o.ad_mode, {HAMK_AUTO, HAMK_AD_H, HAMK_AD_D, HAMK_AD_R})) return "ad_mode must be HAMK_AUTO or a HAMK_AD_* value";
+  if (!in(o.rk4_body, {HAMK_AUTO, HAMK_BODY_UNROLLED, HAMK_BODY_STAGE_LOOP}) || !in(o.rkf_body, {HAMK_AUTO, HAMK_BODY_UNROLLED, HAMK_BODY_STAGE_LOOP}))
+    return "rk4_body / rkf_body must be HAMK_AUTO or a HAMK_BODY_* value";
+  if (!in(o.trig, {HAMK_AUTO, HAMK_TRIG_DIRECT, HAMK_TRIG_TABLE, HAMK_TRIG_TABLE_ROTATE})) return "trig must be HAMK_AUTO or a HAMK_TRIG_* value";
+  if (!in(o.gsl_api, {HAMK_AUTO, 1, 2})) return "gsl_api must be HAMK_AUTO, 1 (gsl_odeiv) or 2 (gsl_odeiv2)";
+  if (!in(o.build, {HAMK_AUTO, HAMK_BUILD_DEFAULT, HAMK_BUILD_NOLICM})) return "build must be HAMK_AUTO or a HAMK_BUILD_* value";
+  for (int v : {o.self_check, o.wave_blocked, o.k_reassoc, o.rk4_park, o.cache})
+    if (!in(v, {HAMK_AUTO, HAMK_ON, HAMK_OFF})) return "switches must be HAMK_AUTO, HAMK_ON or HAMK_OFF";
+  if (o.rk4_min_waves < 0 || o.rk4_min_waves > 8) return "rk4_min_waves must be 0 (auto) .. 8";
+  if (o.max_substeps < 0) return "max_substeps must be >= 0";
+  return std::string();
+}
+
+// Which lanes serve a trajectory for an ensemble of B (hamk_options::mapping = HAMK_AUTO).
+// The lane kernels do the least work per trajectory (compile-time sparsity of the seeds, everything in registers) but
+// put 64 trajectories in a wavefront: below ~64 x 1024 SIMDs trajectories they leave SIMDs idle, and for the systems
+// whose lane kernel is large the wave-cooperative kernels (4 trajectories per wavefront at n <= 16) then win.
+// Thresholds measured on MI355X (scripts/sweep_batch.py -> profiles/r03_throughput_vs_B.jsonl).
+// The quad module (hamk_quad.hpp) provides the kernels of the hot path; the rest of a system's entry points run on the
+// module that serves its size otherwise.
+static bool quad_has(int kernel) { return kernel == K_RK4 || kernel == K_HAMEQS || kernel == K_FROM_PHASE || kernel == K_OBSERVE || kernel == K_SCRIBBLE; }
+
+// Can a lane run the per-trajectory first-order sweep of this system with compile-time seeds?  It keeps one register pair
+// per DISTINCT entry of the Jacobian (hamk_codegen.cpp distinct_jacobian_entries): 2n for a chain, m n for a dense map.
+static bool quad_eligible(hamk_system* s) {
+  if (s->quad_eligible < 0) s->quad_eligible = distinct_jacobian_entries(s->base) <= 8 * s->base.n ? 1 : 0;
+  return s->quad_eligible == 1;
+}
+
+static int choose_mapping(hamk_system* s, int64_t B, int kernel) {
+  const int n = s->base.n;
+  const int rest = n > 16 ? HAMK_MAP_WAVE : HAMK_MAP_LANE;  // where the kernels the quad module lacks run
+  if (s->opt.mapping != HAMK_AUTO) return (s->opt.mapping == HAMK_MAP_QUAD && !quad_has(kernel)) ? rest : s->opt.mapping;
+  bool w = false;
+  if (env_flag("HAMK_QUAD", &w) && w && n <= 32) return quad_has(kernel) ? HAMK_MAP_QUAD : rest;      // tests / experiments
+  const bool no_quad = env_flag("HAMK_QUAD", &w) && !w;
+  if (env_flag("HAMK_WAVE", &w)) return (w || n > 16) ? HAMK_MAP_WAVE : HAMK_MAP_LANE;
+  if (n > 32) return HAMK_MAP_WAVE;
+  if (n > 16) return (!no_quad && quad_has(kernel) && quad_eligible(s)) ? HAMK_MAP_QUAD : HAMK_MAP_WAVE;
+  int64_t below = 0;                                        // ensembles smaller than this leave the lane kernels
+  if (const char* e = std::getenv("HAMK_WAVE_BELOW")) below = std::atoll(e);                // experiments: the crossover itself
+  else below = lane_wave_crossover(n);
+  return (B < below) ? HAMK_MAP_WAVE : HAMK_MAP_LANE;
+}
+
+static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4, bool* forced_rkf) {
+  const hamk_options& o = s->opt;
+  SystemDesc d = s->base;
+  const int n = d.n, m = d.m;
+  bool b = false;
+  d.mapping = mapping;
+  d.wave = mapping == HAMK_MAP_WAVE;
+  // second-order AD: measured on MI355X (scripts/sweep.py): H >= D up to n = 3, D ahead from n = 4; the reverse sweep
+  // pays from n = 8 (chain8 +4 %, chain16 +12 %); below, the compiler already strips the structural zeros of the
+  // directional jets and Jet2 is as cheap
+  d.mode_h = (n <= 3);
+  d.mode_r = (n >= 8);
+  int ad = o.ad_mode;
+  if (ad == HAMK_AUTO) if (const char* e = std::getenv("HAMK_AD_MODE")) ad = (e[0] == 'H' || e[0] == 'h') ? HAMK_AD_H : (e[0] == 'D' || e[0] == 'd') ? HAMK_AD_D : (e[0] == 'R' || e[0] == 'r') ? HAMK_AD_R : HAMK_AUTO;
+  if (ad == HAMK_AD_H) { d.mode_h = true; d.mode_r = false; }
+  if (ad == HAMK_AD_D) { d.mode_h = false; d.mode_r = false; }
+  if (ad == HAMK_AD_R) { d.mode_h = false; d.mode_r = true; }
+  // LDL^T in panels of 16 with the trailing blocks on the matrix cores (hamk_wave.hpp factor_blocked): measured on
+  // MI355X chain32 5.06e7 -> 5.66e7, chain64 4.6e6 -> 7.6e6 RK4 steps/s (profiles/r02_wave_blocked.jsonl); a single panel
+  // (n <= 16, forced wave path) has nothing to block
+  d.wave_blocked = n > 16;
+  if (o.wave_blocked != HAMK_AUTO) d.wave_blocked = (o.wave_blocked == HAMK_ON) && n > 16;
+  else if (env_flag("HAMK_WAVE_BLOCKED", &b)) d.wave_blocked = b && n > 16;
+  d.rk4_stage_loop = (n >= 7);
+  *forced_rk4 = true;
+  if (o.rk4_body != HAMK_AUTO) d.rk4_stage_loop = o.rk4_body == HAMK_BODY_STAGE_LOOP;
+  else if (env_flag("HAMK_RK4_LOOP", &b)) d.rk4_stage_loop = b;
+  else *forced_rk4 = false;
+  d.rkf_stage_loop = (n >= 4);
+  *forced_rkf = true;
+  if (o.rkf_body != HAMK_AUTO) d.rkf_stage_loop = o.rkf_body == HAMK_BODY_STAGE_LOOP;
+  else if (env_flag("HAMK_RKF_LOOP", &b)) d.rkf_stage_loop = b;
+  else *forced_rkf = false;
+  // n > 32 (one trajectory per wavefront): the RK4 kernel capped at 256 VGPRs -- two wavefronts per SIMD, ~160
+  // spilled registers -- beats one wavefront with everything in registers: chain48 1.05e7 -> 1.45e7, chain64
+  // 7.6e6 -> 9.5e6 RK4 steps/s on MI355X (profiles/r02_wave_blocked.jsonl)
+  d.rk4_min_waves = 1;
+  if (d.wave && n > 32) d.rk4_min_waves = 2;
+  if (o.rk4_min_waves > 0) d.rk4_min_waves = o.rk4_min_waves;
+  else if (const char* e = std::getenv("HAMK_RK4_WAVES")) d.rk4_min_waves = std::atoi(e);
+  // RK4 stage loop with y / acc parked in LDS (hamk_device.hpp rk4_body): where one right-hand side alone fills the
+  // register file (n >= 12) the waiting state is what spills; chain16 300 spilled registers -> 34, none in the loop
+  d.rk4_park = mapping == HAMK_MAP_LANE && n >= 12;
+  if (o.rk4_park != HAMK_AUTO) d.rk4_park = o.rk4_park == HAMK_ON;
+  else if (env_flag("HAMK_RK4_PARK", &b)) d.rk4_park = b;
+  if (d.rk4_park && (!d.rk4_stage_loop || mapping != HAMK_MAP_LANE || n > 16)) d.rk4_park = false;          // 2 x 2n x 2 KiB of LDS per block: n <= 16
+  d.k_reassoc = true;
+  if (o.k_reassoc != HAMK_AUTO) d.k_reassoc = o.k_reassoc == HAMK_ON;
+  else if (env_flag("HAMK_K_REASSOC", &b)) d.k_reassoc = b;
+  {
+    // sincos in the stepping kernels (hamk_device.hpp StageTrig).  Every evaluation through the LDS table is
+    // the fewest instructions, but each is a 16-byte gather at a lane-dependent address (~20-25 LDS cycles
+    // per wavefront) and the CU's 16 wavefronts share one LDS unit: where a right-hand side is short and
+    // trig-dense the unit saturates, and taking only the step's one full evaluation from the table (stages
+    // 2-4 by rotation in registers) is faster.  Measured on MI355X (profiles/r02_sweep_trig.jsonl): rotation
+    // wins for doublePendulum (2 sites per ~90-instruction RHS: 8.36 vs 8.21e10) and pendulum, the table for
+    // twoBody (+8 %), threeBodyPolar (+8 %) and the chains (+24 % at n = 8); spring is a tie.  The rule
+    // below reproduces those choices from an estimate of the instructions per RHS and sincos site.
+    const int f_nops = (int)d.f_ops.size(), u_nops = (int)d.u_ops.size();
+    std::vector<char> seen(f_nops > 0 ? f_nops : 1, 0);
+    int sites = 0;
+    for (int i = 0; i < f_nops; ++i)
+      if ((d.f_ops[i].op == HAMK_OP_SIN || d.f_ops[i].op == HAMK_OP_COS) && !seen[d.f_ops[i].a]) { seen[d.f_ops[i].a] = 1; ++sites; }
+    const double width = d.mode_h ? 1.0 + n + 0.5 * n * (n + 1) : 3.0 * n + 3.0;      // jet components carried per tape value
+    const double est_rhs = (f_nops + u_nops) * width + 2.0 * m * n * n + n * n * n / 3.0;
+    d.use_lut = (sites >= 1 && sites <= 4 && est_rhs / sites < 100.0) ? 2 : 1;
+    // the largest lane kernels (n >= 14) without the parked state: 512 VGPRs and hundreds spilled, bound by their
+    // scratch traffic; measured, the table variant schedules worse there (chain16 9.4e8 vs 1.05e9 steps/s)
+    if (n >= 14 && !d.wave && !d.rk4_park) d.use_lut = 0;
+  }
+  if (o.trig != HAMK_AUTO) d.use_lut = o.trig == HAMK_TRIG_DIRECT ? 0 : (o.trig == HAMK_TRIG_TABLE ? 1 : 2);
+  else if (const char* e = std::getenv("HAMK_TRIG_LUT")) { if (e[0] >= '0' && e[0] <= '2') d.use_lut = e[0] - '0'; }
+  return d;
+}
+
+static int variant_for(hamk_system* s, int64_t B, int kernel, Variant** out) {
+  const int mapping = choose_mapping(s, B, kernel);
+  if (s->var[mapping]) { *out = s->var[mapping]; return HAMK_OK; }
+  Variant* v = new Variant();
+  v->mapping = mapping;
+  v->desc = make_desc(s, mapping, &v->forced_rk4_body, &v->forced_rkf_body);
+  v->source = generate_source(v->desc);
+  int rc = build_code(v, s->cache_on, build_force(s));
+  if (rc != HAMK_OK) { delete v; return rc; }
+  // keep every kernel comfortably inside SOPP branch reach: fall back to the stage-loop bodies
+  const size_t kLimit = 64 * 1024;
+  const bool lane = mapping == HAMK_MAP_LANE;
+  const bool big_rkf = lane && !v->forced_rkf_body && !v->desc.rkf_stage_loop && chosen_kernel_bytes(v, K_RKF45) > kLimit;
+  const bool big_rk4 = lane && !v->forced_rk4_body && !v->desc.rk4_stage_loop && chosen_kernel_bytes(v, K_RK4) > kLimit;
+  if (big_rkf || big_rk4) {
+    if (big_rkf) v->desc.rkf_stage_loop = true;
+    if (big_rk4) v->desc.rk4_stage_loop = true;
+    v->source = generate_source(v->desc);
+    rc = build_code(v, s->cache_on, build_force(s));
+    if (rc != HAMK_OK) { delete v; return rc; }
+  }
+  for (int k = 0; k < K__COUNT; ++k) v->has[k] = mapping != HAMK_MAP_QUAD || quad_has(k);
+  s->var[mapping] = v;
+  *out = v;
   return HAMK_OK;
 }
 
@@ -960,9 +1191,21 @@ int hamk_gather_batch(int32_t nparts, int32_t n, const int64_t* B_parts, const d
   return HAMK_OK;
 }
 
+void hamk_options_init(hamk_options* opt) {
+  if (!opt) return;
+  std::memset(opt, 0, sizeof *opt);
+  opt->size = (uint32_t)sizeof *opt;
+}
+
 int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_op* f_ops, int32_t f_nops,
                        const int32_t* f_outs, const hamk_op* u_ops, int32_t u_nops, int32_t u_out, int32_t u_space,
                        hamk_system** out) {
+  return hamk_system_create_ex(m, n, inertia, f_ops, f_nops, f_outs, u_ops, u_nops, u_out, u_space, nullptr, out);
+}
+
+int hamk_system_create_ex(int32_t m, int32_t n, const double* inertia, const hamk_op* f_ops, int32_t f_nops,
+                          const int32_t* f_outs, const hamk_op* u_ops, int32_t u_nops, int32_t u_out, int32_t u_space,
+                          const hamk_options* opt, hamk_system** out) {
   if (!out) return fail(HAMK_ERR_INVALID, "out is null");
   *out = nullptr;
   if (m <= 0 || n <= 0) return fail(HAMK_ERR_INVALID, "m and n must be positive");
@@ -975,78 +1218,37 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
   const int nu = (u_space == HAMK_U_CARTESIAN) ? m : n;
   err = validate_tape(u_ops, u_nops, nu, &u_out, 1, "potential");
   if (!err.empty()) return fail(HAMK_ERR_TAPE, err);
+  hamk_options o;
+  hamk_options_init(&o);
+  if (opt) {
+    if (opt->size < 8 || opt->size > 4096) return fail(HAMK_ERR_INVALID, "hamk_options: size is not set (hamk_options_init)");
+    std::memcpy(&o, opt, std::min((size_t)opt->size, sizeof o));      // a caller built against an older header: the tail stays AUTO
+    o.size = (uint32_t)sizeof o;
+  }
+  err = check_options(o, n);
+  if (!err.empty()) return fail(err.rfind("unsupported:", 0) == 0 ? HAMK_ERR_UNSUPPORTED : HAMK_ERR_INVALID, "hamk_options: " + err);
 
   hamk_system* s = new hamk_system();
-  s->desc.m = m; s->desc.n = n; s->desc.u_space = u_space;
-  s->desc.inertia.assign(inertia, inertia + m);
-  s->desc.f_ops.assign(f_ops, f_ops + f_nops);
-  s->desc.f_outs.assign(f_outs, f_outs + m);
-  s->desc.u_ops.assign(u_ops, u_ops + u_nops);
-  s->desc.u_out = u_out;
-  s->desc.mode_h = (n <= 3);     // measured on MI355X (scripts/sweep.py): H >= D up to n = 3, D ahead from n = 4
-  // measured (scripts/sweep.py): the reverse sweep pays from n = 8 (chain8 +4 %, chain16 +12 %); below,
-  // the compiler already strips the structural zeros of the directional jets and Jet2 is as cheap
-  s->desc.mode_r = (n >= 8);
-  if (const char* e = std::getenv("HAMK_AD_MODE")) {          // experiments: force "H", "D" (Jet2 sweep) or "R" (reverse sweep)
-    if (e[0] == 'H' || e[0] == 'h') { s->desc.mode_h = true; s->desc.mode_r = false; }
-    if (e[0] == 'D' || e[0] == 'd') { s->desc.mode_h = false; s->desc.mode_r = false; }
-    if (e[0] == 'R' || e[0] == 'r') { s->desc.mode_h = false; s->desc.mode_r = true; }
-  }
-  // measured on MI355X (scripts/sweep_wave.py): the lane kernels win up to n = 16 even with
-  // spills (chain16: 4.5e8 vs 7.3e7 steps/s); beyond that one trajectory no longer fits a lane
-  s->desc.wave = (n > 16);
-  if (const char* e = std::getenv("HAMK_WAVE")) s->desc.wave = (e[0] == '1');      // experiments / tests
-  // LDL^T in panels of 16 with the trailing blocks on the matrix cores (hamk_wave.hpp factor_blocked): measured on
-  // MI355X chain32 5.06e7 -> 5.66e7, chain64 4.6e6 -> 7.6e6 RK4 steps/s (profiles/r02_wave_blocked.jsonl); a single panel
-  // (n <= 16, forced wave path) has nothing to block
-  s->desc.wave_blocked = n > 16;
-  if (const char* e = std::getenv("HAMK_WAVE_BLOCKED")) s->desc.wave_blocked = (e[0] == '1') && n > 16;      // experiments
-  s->desc.rk4_stage_loop = (n >= 7);
-  if (const char* e = std::getenv("HAMK_RK4_LOOP")) s->desc.rk4_stage_loop = (e[0] == '1');
-  // n > 32 (one trajectory per wavefront): the RK4 kernel capped at 256 VGPRs -- two wavefronts per SIMD, ~160
-  // spilled registers -- beats one wavefront with everything in registers: chain48 1.05e7 -> 1.45e7, chain64
-  // 7.6e6 -> 9.5e6 RK4 steps/s on MI355X (profiles/r02_wave_blocked.jsonl)
-  if (s->desc.wave && n > 32) s->desc.rk4_min_waves = 2;
-  if (const char* e = std::getenv("HAMK_RK4_WAVES")) s->desc.rk4_min_waves = std::atoi(e);
-  {
-    // sincos in the stepping kernels (hamk_device.hpp StageTrig).  Every evaluation through the LDS table is
-    // the fewest instructions, but each is a 16-byte gather at a lane-dependent address (~20-25 LDS cycles
-    // per wavefront) and the CU's 16 wavefronts share one LDS unit: where a right-hand side is short and
-    // trig-dense the unit saturates, and taking only the step's one full evaluation from the table (stages
-    // 2-4 by rotation in registers) is faster.  Measured on MI355X (profiles/r02_sweep_trig.jsonl): rotation
-    // wins for doublePendulum (2 sites per ~90-instruction RHS: 8.36 vs 8.21e10) and pendulum, the table for
-    // twoBody (+8 %), threeBodyPolar (+8 %) and the chains (+24 % at n = 8); spring is a tie.  The rule
-    // below reproduces those choices from an estimate of the instructions per RHS and sincos site.
-    std::vector<char> seen(f_nops > 0 ? f_nops : 1, 0);
-    int sites = 0;
-    for (int i = 0; i < f_nops; ++i)
-      if ((f_ops[i].op == HAMK_OP_SIN || f_ops[i].op == HAMK_OP_COS) && !seen[f_ops[i].a]) { seen[f_ops[i].a] = 1; ++sites; }
-    const double width = s->desc.mode_h ? 1.0 + n + 0.5 * n * (n + 1) : 3.0 * n + 3.0;      // jet components carried per tape value
-    const double est_rhs = (f_nops + u_nops) * width + 2.0 * m * n * n + n * n * n / 3.0;
-    s->desc.use_lut = (sites >= 1 && sites <= 4 && est_rhs / sites < 100.0) ? 2 : 1;
-    // the largest lane kernels (n >= 14: 512 VGPRs and hundreds spilled) are bound by their scratch traffic;
-    // measured, the table variant schedules worse there (chain16 9.4e8 vs 1.05e9 steps/s; chain12 +5 % with it)
-    if (n >= 14 && !s->desc.wave) s->desc.use_lut = 0;
-  }
-  if (const char* e = std::getenv("HAMK_TRIG_LUT")) { if (e[0] >= '0' && e[0] <= '2') s->desc.use_lut = e[0] - '0'; }   // experiments
-  if (const char* e = std::getenv("HAMK_GSL_API")) s->gsl_api = (e[0] == '1') ? 1 : 2;
-  s->desc.rkf_stage_loop = (n >= 4);
-  if (const char* e = std::getenv("HAMK_RKF_LOOP")) s->desc.rkf_stage_loop = (e[0] == '1');
-  const bool forced_rk4 = std::getenv("HAMK_RK4_LOOP") != nullptr, forced_rkf = std::getenv("HAMK_RKF_LOOP") != nullptr;
-  s->source = generate_source(s->desc);
-  int rc = build_code(s);
-  if (rc != HAMK_OK) { delete s; return rc; }
-  // keep every kernel comfortably inside SOPP branch reach: fall back to the stage-loop bodies
-  const size_t kLimit = 64 * 1024;
-  const bool big_rkf = !s->desc.wave && !forced_rkf && !s->desc.rkf_stage_loop && chosen_kernel_bytes(s, K_RKF45) > kLimit;
-  const bool big_rk4 = !s->desc.wave && !forced_rk4 && !s->desc.rk4_stage_loop && chosen_kernel_bytes(s, K_RK4) > kLimit;
-  if (big_rkf || big_rk4) {
-    if (big_rkf) s->desc.rkf_stage_loop = true;
-    if (big_rk4) s->desc.rk4_stage_loop = true;
-    s->source = generate_source(s->desc);
-    rc = build_code(s);
-    if (rc != HAMK_OK) { delete s; return rc; }
-  }
+  s->opt = o;
+  s->base.m = m; s->base.n = n; s->base.u_space = u_space;
+  s->base.inertia.assign(inertia, inertia + m);
+  s->base.f_ops.assign(f_ops, f_ops + f_nops);
+  s->base.f_outs.assign(f_outs, f_outs + m);
+  s->base.u_ops.assign(u_ops, u_ops + u_nops);
+  s->base.u_out = u_out;
+  s->gsl_api = o.gsl_api ? o.gsl_api : 2;
+  if (o.gsl_api == HAMK_AUTO) if (const char* e = std::getenv("HAMK_GSL_API")) s->gsl_api = (e[0] == '1') ? 1 : 2;
+  s->self_check_on = o.self_check != HAMK_OFF;
+  if (o.self_check == HAMK_AUTO) if (const char* e = std::getenv("HAMK_SELFCHECK")) if (e[0] == '0') s->self_check_on = false;
+  s->cache_on = o.cache != HAMK_OFF;
+  s->max_substeps = o.max_substeps > 0 ? o.max_substeps : (1 << 24);
+  if (o.max_substeps == HAMK_AUTO)                          // test suites: a kernel gone wrong must end, not spin through 16M attempts per lane
+    if (const char* e = std::getenv("HAMK_MAX_SUBSTEPS")) { const long k = std::atol(e); if (k > 0 && k < (1L << 24)) s->max_substeps = (int)k; }
+  // the specialisation a large ensemble uses is built now: a tape the kernels cannot be specialised for fails here
+  Variant* v = nullptr;
+  const int rc = variant_for(s, INT64_MAX, K_RK4, &v);
+  if (rc != HAMK_OK) { hamk_system_destroy(s); return rc; }
+  s->info = v;
   *out = s;
   return HAMK_OK;
 }
@@ -1054,26 +1256,62 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_o
 void hamk_system_destroy(hamk_system* s) {
   if (!s) return;
   for (DevState* d : s->devs) { d->release(); delete d; }
+  for (Variant* v : s->var) delete v;
   (void)hipGetLastError();
   delete s;
 }
 
 int hamk_system_dims(const hamk_system* s, int32_t* m, int32_t* n) {
   if (!s) return fail(HAMK_ERR_INVALID, "null system handle");
-  if (m) *m = s->desc.m;
-  if (n) *n = s->desc.n;
+  if (m) *m = s->base.m;
+  if (n) *n = s->base.n;
+  return HAMK_OK;
+}
+
+int hamk_system_get_options(hamk_system* s, int64_t B, hamk_options* r) {
+  if (!s || !r) return fail(HAMK_ERR_INVALID, "null system handle / options");
+  Variant* v = nullptr;
+  TRY(variant_for(s, B < 0 ? INT64_MAX : B, K_RK4, &v));
+  hamk_options_init(r);
+  const SystemDesc& d = v->desc;
+  r->mapping = v->mapping;
+  r->ad_mode = d.mode_h ? HAMK_AD_H : (d.mode_r ? HAMK_AD_R : HAMK_AD_D);
+  r->rk4_body = d.rk4_stage_loop ? HAMK_BODY_STAGE_LOOP : HAMK_BODY_UNROLLED;
+  r->rkf_body = d.rkf_stage_loop ? HAMK_BODY_STAGE_LOOP : HAMK_BODY_UNROLLED;
+  r->trig = d.use_lut == 0 ? HAMK_TRIG_DIRECT : (d.use_lut == 1 ? HAMK_TRIG_TABLE : HAMK_TRIG_TABLE_ROTATE);
+  r->gsl_api = s->gsl_api;
+  r->self_check = s->self_check_on ? HAMK_ON : HAMK_OFF;
+  const int bf = build_force(s);
+  r->build = bf == 0 ? HAMK_BUILD_DEFAULT : (bf == 1 ? HAMK_BUILD_NOLICM : HAMK_AUTO);
+  r->wave_blocked = d.wave_blocked ? HAMK_ON : HAMK_OFF;
+  r->rk4_min_waves = d.rk4_min_waves;
+  r->k_reassoc = d.k_reassoc ? HAMK_ON : HAMK_OFF;
+  r->rk4_park = d.rk4_park ? HAMK_ON : HAMK_OFF;
+  r->max_substeps = s->max_substeps;
+  r->cache = s->cache_on ? HAMK_ON : HAMK_OFF;
+  r->lanes_per_trajectory = v->mapping == HAMK_MAP_LANE ? 1 : (v->mapping == HAMK_MAP_QUAD ? 4 : (d.n <= 16 ? 16 : d.n <= 32 ? 32 : 64));
+  return HAMK_OK;
+}
+
+int hamk_system_describe_batch(hamk_system* s, int64_t B) {
+  if (!s) return fail(HAMK_ERR_INVALID, "null system handle");
+  Variant* v = nullptr;
+  TRY(variant_for(s, B < 0 ? INT64_MAX : B, K_RK4, &v));
+  s->info = v;
   return HAMK_OK;
 }
 
 int hamk_set_stream(hamk_system* s, void* hip_stream) {
   if (!s) return fail(HAMK_ERR_INVALID, "null system handle");
-  s->stream = (hipStream_t)hip_stream;
+  if (current_device_state(s) != HAMK_OK) return HAMK_OK;  // no device to bind to: the first launch reports that
+  s->cur->stream = (hipStream_t)hip_stream;
   return HAMK_OK;
 }
 
 int hamk_synchronize(hamk_system* s) {
   if (!s) return fail(HAMK_ERR_INVALID, "null system handle");
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  TRY(current_device_state(s));
+  HIP_TRY(hipStreamSynchronize(s->cur->stream));
   return HAMK_OK;
 }
 
@@ -1087,32 +1325,32 @@ int hamk_system_set_gsl_api(hamk_system* s, int32_t api) {
 int32_t hamk_system_get_gsl_api(const hamk_system* s) { return s ? s->gsl_api : 0; }
 
 int64_t hamk_system_code_object(const hamk_system* s, int32_t which, void* buf, int64_t cap) {
-  if (!s || (which != 0 && which != 1)) return 0;
-  const std::vector<char>& c = which ? s->code2 : s->code;
+  if (!s || !s->info || (which != 0 && which != 1)) return 0;
+  const std::vector<char>& c = which ? s->info->code2 : s->info->code;
   if (buf && cap >= (int64_t)c.size() && !c.empty()) std::memcpy(buf, c.data(), c.size());
   return (int64_t)c.size();
 }
 
-const char* hamk_system_source(const hamk_system* s) { return s ? s->source.c_str() : nullptr; }
-const char* hamk_system_build_info(const hamk_system* s) { return s ? s->build_info.c_str() : ""; }
-int64_t hamk_system_code_size(const hamk_system* s) { return s ? (int64_t)(s->code.size() + s->code2.size()) : 0; }
+const char* hamk_system_source(const hamk_system* s) { return (s && s->info) ? s->info->source.c_str() : nullptr; }
+const char* hamk_system_build_info(const hamk_system* s) { return (s && s->info) ? s->info->build_info.c_str() : ""; }
+int64_t hamk_system_code_size(const hamk_system* s) { return (s && s->info) ? (int64_t)(s->info->code.size() + s->info->code2.size()) : 0; }
 int64_t hamk_system_kernel_bytes(const hamk_system* s, const char* kernel_name) {
-  if (!s) return 0;
+  if (!s || !s->info) return 0;
   if (kernel_name)
     for (int k = 0; k < K__COUNT; ++k)
-      if (std::strcmp(kernel_name, kKernelNames[k]) == 0) return (int64_t)chosen_kernel_bytes(s, k);
-  return (int64_t)kernel_code_bytes(s->code, kernel_name);
+      if (std::strcmp(kernel_name, kKernelNames[k]) == 0) return (int64_t)chosen_kernel_bytes(s->info, k);
+  return (int64_t)kernel_code_bytes(s->info->code, kernel_name);
 }
 
 int hamk_coords_batch(hamk_system* s, int64_t B, const double* q, double* x, int32_t mem) {
   TRY(check_call(s, B, mem));
   if (!q || !x) return fail(HAMK_ERR_INVALID, "null q / x");
   if (B == 0) return HAMK_OK;
-  TRY(bind_device(s));
+  TRY(bind_device(s, B, K_COORDS));
   Stager st(s, mem);
   const double* dq; double* dx;
-  TRY(st.in(q, (size_t)s->desc.n * B, (double**)&dq));
-  TRY(st.out(x, (size_t)s->desc.m * B, &dx));
+  TRY(st.in(q, (size_t)s->base.n * B, (double**)&dq));
+  TRY(st.out(x, (size_t)s->base.m * B, &dx));
   long long b = B;
   void* args[] = {&dq, &dx, &b};
   TRY(launch(s, K_COORDS, B, args));
@@ -1123,9 +1361,9 @@ int hamk_to_phase_batch(hamk_system* s, int64_t B, const double* q, const double
   TRY(check_call(s, B, mem));
   if (!q || !qd || !p) return fail(HAMK_ERR_INVALID, "null q / qd / p");
   if (B == 0) return HAMK_OK;
-  TRY(bind_device(s));
+  TRY(bind_device(s, B, K_TO_PHASE));
   Stager st(s, mem);
-  const size_t cnt = (size_t)s->desc.n * B;
+  const size_t cnt = (size_t)s->base.n * B;
   const double *dq, *dqd; double* dp;
   TRY(st.in(q, cnt, (double**)&dq));
   TRY(st.in(qd, cnt, (double**)&dqd));
@@ -1141,9 +1379,9 @@ int hamk_from_phase_batch(hamk_system* s, int64_t B, const double* q, const doub
   TRY(check_call(s, B, mem));
   if (!q || !p || !qd) return fail(HAMK_ERR_INVALID, "null q / p / qd");
   if (B == 0) return HAMK_OK;
-  TRY(bind_device(s));
+  TRY(bind_device(s, B, K_FROM_PHASE));
   Stager st(s, mem);
-  const size_t cnt = (size_t)s->desc.n * B;
+  const size_t cnt = (size_t)s->base.n * B;
   const double *dq, *dp; double* dqd; int32_t* dst;
   TRY(st.in(q, cnt, (double**)&dq));
   TRY(st.in(p, cnt, (double**)&dp));
@@ -1161,9 +1399,9 @@ int hamk_observe_batch(hamk_system* s, int64_t B, const double* q, const double*
   if (!q) return fail(HAMK_ERR_INVALID, "null q");
   if (!p && (ke || h)) return fail(HAMK_ERR_INVALID, "ke / h need momenta p");
   if (B == 0) return HAMK_OK;
-  TRY(bind_device(s));
+  TRY(bind_device(s, B, K_OBSERVE));
   Stager st(s, mem);
-  const size_t cnt = (size_t)s->desc.n * B;
+  const size_t cnt = (size_t)s->base.n * B;
   const double *dq, *dp; double *dke, *dpe, *dh; int32_t* dst;
   TRY(st.in(q, cnt, (double**)&dq));
   TRY(st.in(p, cnt, (double**)&dp));
@@ -1182,9 +1420,9 @@ int hamk_observe_config_batch(hamk_system* s, int64_t B, const double* q, const 
   TRY(check_call(s, B, mem));
   if (!q || !qd) return fail(HAMK_ERR_INVALID, "null q / qd");
   if (B == 0) return HAMK_OK;
-  TRY(bind_device(s));
+  TRY(bind_device(s, B, K_OBSERVE_CFG));
   Stager st(s, mem);
-  const size_t cnt = (size_t)s->desc.n * B;
+  const size_t cnt = (size_t)s->base.n * B;
   const double *dq, *dqd; double *dke, *dlag;
   TRY(st.in(q, cnt, (double**)&dq));
   TRY(st.in(qd, cnt, (double**)&dqd));
@@ -1201,9 +1439,9 @@ int hamk_hameqs_batch(hamk_system* s, int64_t B, const double* q, const double* 
   TRY(check_call(s, B, mem));
   if (!q || !p || !dq || !dp) return fail(HAMK_ERR_INVALID, "null q / p / dq / dp");
   if (B == 0) return HAMK_OK;
-  TRY(bind_device(s));
+  TRY(bind_device(s, B, K_HAMEQS));
   Stager st(s, mem);
-  const size_t cnt = (size_t)s->desc.n * B;
+  const size_t cnt = (size_t)s->base.n * B;
   const double *xq, *xp; double *xdq, *xdp; int32_t* dst;
   TRY(st.in(q, cnt, (double**)&xq));
   TRY(st.in(p, cnt, (double**)&xp));
@@ -1223,9 +1461,9 @@ int hamk_rk4_steps_checked(hamk_system* s, int64_t B, double* q, double* p, doub
   if (nsteps < 0) return fail(HAMK_ERR_INVALID, "negative nsteps");
   if (drift_tol != drift_tol) return fail(HAMK_ERR_INVALID, "drift_tol is NaN");
   if (B == 0) return HAMK_OK;
-  TRY(bind_device(s));
+  TRY(bind_device(s, B, K_RK4));
   Stager st(s, mem);
-  const size_t cnt = (size_t)s->desc.n * B;
+  const size_t cnt = (size_t)s->base.n * B;
   double *xq, *xp; int32_t* dst;
   TRY(st.inout(q, cnt, &xq));
   TRY(st.inout(p, cnt, &xp));
@@ -1250,24 +1488,13 @@ static int upload_times(hamk_system* s, int32_t nt, const double* ts) {
     s->cur->d_ts_cap = nt;
   }
   // the previous launch may still be reading d_ts / h_ts: order behind it on the stream
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipStreamSynchronize(s->cur->stream));
   s->cur->h_ts.assign(ts, ts + nt);
-  HIP_TRY(hipMemcpyAsync(s->cur->d_ts, s->cur->h_ts.data(), sizeof(double) * nt, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->cur->d_ts, s->cur->h_ts.data(), sizeof(double) * nt, hipMemcpyHostToDevice, s->cur->stream));
   return HAMK_OK;
 }
 
 static const double kRefEps = 1.49012e-08;   // Hamilton.hs:448
-// sub-step budget per call and trajectory (HAMK_ST_MAXSTEPS when exhausted); HAMK_MAX_SUBSTEPS lowers it
-// (test suites: a kernel gone wrong must end, not spin through 16M attempts per lane)
-static int max_substeps() {
-  static const int v = [] {
-    const char* e = std::getenv("HAMK_MAX_SUBSTEPS");
-    const long k = e ? std::atol(e) : 0;
-    return (k > 0 && k < (1L << 24)) ? (int)k : (1 << 24);
-  }();
-  return v;
-}
-
 int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const double* p0, int32_t nt, const double* ts,
                           double* qout, double* pout, double h0, double eps_abs, double eps_rel, int32_t* status,
                           int32_t* nsub, int32_t mem) {
@@ -1275,7 +1502,7 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
   if (!q0 || !p0 || !qout || !pout || !ts) return fail(HAMK_ERR_INVALID, "null q0 / p0 / ts / qout / pout");
   if (nt < 2) return fail(HAMK_ERR_INVALID, "evolveHam needs at least two times (2 <= s, Hamilton.hs:435)");
   if (B == 0) return HAMK_OK;
-  TRY(bind_device(s));
+  TRY(bind_device(s, B, K_RKF45));
   if (!(h0 > 0.0)) h0 = (ts[1] - ts[0]) / 100.0;          // Hamilton.hs:447
   if (!(eps_abs > 0.0)) eps_abs = kRefEps;
   if (!(eps_rel > 0.0)) eps_rel = kRefEps;
@@ -1298,7 +1525,7 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
     dts = (size_t)nt * sizeof(double) <= kPinMaxBuf ? st.side_input(ts, (size_t)nt) : nullptr;
     if (!dts) { TRY(upload_times(s, nt, ts)); dts = s->cur->d_ts; }
   }
-  const size_t cnt = (size_t)s->desc.n * B;
+  const size_t cnt = (size_t)s->base.n * B;
   const double *xq, *xp; double *xqo, *xpo; int32_t *dst, *dns;
   TRY(st.in(q0, cnt, (double**)&xq));
   TRY(st.in(p0, cnt, (double**)&xp));
@@ -1307,7 +1534,7 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
   TRY(st.out(status, (size_t)B, &dst));
   TRY(st.out(nsub, (size_t)B, &dns));
   long long b = B;
-  int nt_ = nt, flags = rkf_flags(0, 0, s->gsl_api), max_sub = max_substeps();
+  int nt_ = nt, flags = rkf_flags(0, 0, s->gsl_api), max_sub = s->max_substeps;
   int ncalls = 1, it_every = 0;
   void* args[] = {&xq, &xp, &xqo, &xpo, &b, &nt_, &dts, &ts0, &ts1, &h0, &eps_abs, &eps_rel, &flags, &max_sub, &dst, &dns, &ncalls, &it_every};
   TRY(launch(s, K_RKF45, B, args));
@@ -1321,11 +1548,11 @@ int hamk_step_ham_iterate(hamk_system* s, int64_t B, double* q, double* p, doubl
   if (ncalls < 0 || out_every < 0) return fail(HAMK_ERR_INVALID, "negative ncalls / out_every");
   if (out_every > 0 && (!qout || !pout)) return fail(HAMK_ERR_INVALID, "out_every > 0 needs qout / pout");
   if (B == 0 || ncalls == 0) return HAMK_OK;
-  TRY(bind_device(s));
+  TRY(bind_device(s, B, K_RKF45));
   double ts0 = 0.0, ts1 = dt;                               // evolveHam over (0, r), Hamilton.hs:401
   double h0 = dt / 100.0, eps_abs = kRefEps, eps_rel = kRefEps;
   Stager st(s, mem);
-  const size_t cnt = (size_t)s->desc.n * B;
+  const size_t cnt = (size_t)s->base.n * B;
   const size_t rows = out_every > 0 ? (size_t)(ncalls / out_every) : 0;
   double *xq, *xp, *xqo = nullptr, *xpo = nullptr; int32_t *dst, *dns;
   TRY(st.inout(q, cnt, &xq));
@@ -1335,7 +1562,7 @@ int hamk_step_ham_iterate(hamk_system* s, int64_t B, double* q, double* p, doubl
   TRY(st.out(nsub, (size_t)B, &dns));
   long long b = B;
   // in place on (q, p); the kernel's qout/pout receive the frames (hamk_device.hpp rkf45_body, flags)
-  int nt_ = 2, flags = rkf_flags(1, 2, s->gsl_api), max_sub = max_substeps();
+  int nt_ = 2, flags = rkf_flags(1, 2, s->gsl_api), max_sub = s->max_substeps;
   int nc = ncalls, every = rows > 0 ? out_every : 0;
   const double* dts = nullptr;
   const double *cq = xq, *cp = xp;
@@ -1406,6 +1633,13 @@ int hamk_checkpoint_write(const char* path, int32_t n, int64_t B, const double* 
 static int read_ck_header(std::FILE* f, const char* path, CkHeader* h) {
   if (std::fread(h, sizeof *h, 1, f) != 1 || std::memcmp(h->magic, kCkMagic, 8) != 0 || h->version != 1 || h->n <= 0 || h->B < 0)
     return fail(HAMK_ERR_INVALID, std::string(path) + " is not a hamk checkpoint");
+  // the header must describe THIS file before anything is sized from it: 64 + 2 n B 8 + 32 bytes, without overflow
+  // (a corrupt or crafted header would otherwise ask for an arbitrary allocation before the digest is looked at)
+  struct stat st;
+  if (::fstat(fileno(f), &st) != 0) return fail(HAMK_ERR_INVALID, std::string(path) + ": cannot stat");
+  const uint64_t n = (uint64_t)h->n, B = (uint64_t)h->B, lim = (uint64_t)1 << 60;
+  if (n > 64 || (B != 0 && n * 16 > lim / B) || (uint64_t)st.st_size != sizeof(CkHeader) + 2 * n * B * 8 + 32)
+    return fail(HAMK_ERR_INVALID, std::string(path) + ": header does not match the file size (truncated or corrupted checkpoint)");
   return HAMK_OK;
 }
 

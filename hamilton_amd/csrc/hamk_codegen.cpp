@@ -8,9 +8,14 @@
 // the user's f and U are generated; every kernel around them is hand-written.
 #include "hamk_internal.h"
 
+#include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <map>
+#include <set>
 #include <sstream>
 
 namespace hamk_host {
@@ -300,7 +305,7 @@ static void emit_reverse(std::ostringstream& o, const SystemDesc& d) {
   };
   o << "  // dT[i] = -d/dq_i sum_k inertia(k) * (J v)_k * (D_v x_k)(q), (J v)_k held fixed: forward (value, tangent),\n";
   o << "  // then adjoints in reverse tape order\n";
-  o << "  template <class TC> __device__ __forceinline__ static void dT_reverse(const double (&q)[N], const double (&v)[N], TC& tc, double (&dT)[N]) {\n";
+  o << "  template <class QA, class VA, class TC> __device__ __forceinline__ static void dT_reverse(const QA& q, const VA& v, TC& tc, double (&dT)[N]) {\n";
   // ---- forward -----------------------------------------------------------------------------
   for (int i = 0; i < n; ++i) {
     const hamk_op& p = r.ops[i];
@@ -396,11 +401,69 @@ static void emit_reverse(std::ostringstream& o, const SystemDesc& d) {
   o << "  }\n";
 }
 
+// How many DISTINCT non-zero entries the Jacobian of the coordinate map has, as expressions: first-order forward mode run
+// symbolically over the tape with hash-consing (0 and 1 folded, + commutative).  A chain's dx_k/dq_j is ONE expression for
+// every k >= j (2n distinct entries in an m x n = 2n x n matrix); a generic dense map has m n.  This is what decides
+// whether a lane can run the per-trajectory sweep of a large system with compile-time seeds (hamk_quad.hpp): the compiler
+// keeps one register pair per distinct entry, not per entry.
+int distinct_jacobian_entries(const SystemDesc& d) {
+  const int n = d.n, nops = (int)d.f_ops.size();
+  enum : long long { ZERO = 0, ONE = 1 };
+  std::map<std::array<long long, 4>, long long> table;
+  long long next = 2;
+  auto node = [&](long long kind, long long a, long long b, long long c) -> long long {
+    const std::array<long long, 4> key = {kind, a, b, c};
+    auto it = table.find(key);
+    if (it != table.end()) return it->second;
+    table[key] = next;
+    return next++;
+  };
+  auto add = [&](long long a, long long b) { if (a == ZERO) return b; if (b == ZERO) return a; return node(1, std::min(a, b), std::max(a, b), 0); };
+  auto neg = [&](long long a) { return a == ZERO ? (long long)ZERO : node(2, a, 0, 0); };
+  auto scale = [&](long long factor_kind, long long factor_id, long long a) {       // (run-time factor) * a
+    if (a == ZERO) return (long long)ZERO;
+    return node(3, factor_kind * (1LL << 40) + factor_id, a, 0);                    // a == ONE: the factor itself
+  };
+  std::vector<std::vector<long long>> g(nops, std::vector<long long>(n, ZERO));
+  for (int i = 0; i < nops; ++i) {
+    const hamk_op& p = d.f_ops[i];
+    switch (p.op) {
+      case HAMK_OP_CONST: break;
+      case HAMK_OP_INPUT: g[i][p.a] = ONE; break;
+      case HAMK_OP_ADD: for (int j = 0; j < n; ++j) g[i][j] = add(g[p.a][j], g[p.b][j]); break;
+      case HAMK_OP_SUB: for (int j = 0; j < n; ++j) g[i][j] = add(g[p.a][j], neg(g[p.b][j])); break;
+      case HAMK_OP_NEG: for (int j = 0; j < n; ++j) g[i][j] = neg(g[p.a][j]); break;
+      case HAMK_OP_MUL: {
+        const bool ca = d.f_ops[p.a].op == HAMK_OP_CONST, cb = d.f_ops[p.b].op == HAMK_OP_CONST;
+        for (int j = 0; j < n; ++j) {
+          // value(a) * db + da * value(b); a constant factor is identified by its value (l * cos q_j is one node for all k)
+          const long long t1 = cb ? (long long)ZERO : scale(ca ? 5 : 4, ca ? (long long)std::hash<double>{}(d.f_ops[p.a].c) & ((1LL << 40) - 1) : p.a, g[p.b][j]);
+          const long long t2 = ca ? (long long)ZERO : scale(cb ? 5 : 4, cb ? (long long)std::hash<double>{}(d.f_ops[p.b].c) & ((1LL << 40) - 1) : p.b, g[p.a][j]);
+          g[i][j] = add(t1, t2);
+        }
+      } break;
+      case HAMK_OP_DIV: case HAMK_OP_POW: case HAMK_OP_ATAN2:
+        for (int j = 0; j < n; ++j) g[i][j] = (g[p.a][j] == ZERO && g[p.b][j] == ZERO) ? (long long)ZERO : node(6, i, g[p.a][j], g[p.b][j]);
+        break;
+      default:                                             // every unary function: g'(x) * dx, g' identified by (opcode, operand)
+        for (int j = 0; j < n; ++j) g[i][j] = scale(7 + p.op, p.a, g[p.a][j]);
+        break;
+    }
+  }
+  std::set<long long> distinct;
+  for (int k = 0; k < d.m; ++k)
+    for (int j = 0; j < n; ++j)
+      if (g[d.f_outs[k]][j] != ZERO) distinct.insert(g[d.f_outs[k]][j]);
+  return (int)distinct.size();
+}
+
 std::string generate_source(const SystemDesc& d) {
   std::ostringstream o;
   o << "// generated by libhamk (hamk_codegen.cpp) from the expression tape of one System " << d.m << " " << d.n << "\n";
   if (d.rk4_min_waves > 1) o << "#define HAMK_RK4_MIN_WAVES " << d.rk4_min_waves << "\n#define HAMK_RK4_MIN_WAVES_BIG " << d.rk4_min_waves << "\n";
   o << "#define HAMK_USE_LUT " << d.use_lut << "\n";
+  o << "#define HAMK_K_REASSOC " << (d.k_reassoc ? 1 : 0) << "\n";
+  if (d.rk4_park && !d.wave) o << "#define HAMK_RK4_PARK 1\n";
   if (d.wave && d.wave_blocked) o << "#define HAMK_WAVE_BLOCKED 1\n";
   // (sin, cos)(i 2pi/512), correctly rounded from 80-bit: the constant data behind sincos_lut's LDS table
   o << "#ifdef HAMK_HOST_EMULATION\nstatic const double hamk_trig_lut_init[1024] = {\n#else\n__device__ const double hamk_trig_lut_init[1024] = {\n#endif\n";
@@ -409,7 +472,8 @@ std::string generate_source(const SystemDesc& d) {
     o << "  " << lit((double)sinl(a)) << ", " << lit((double)cosl(a)) << (i == 511 ? "\n" : ",\n");
   }
   o << "};\n";
-  o << (d.wave ? "#include \"hamk_wave.hpp\"\n\n" : "#include \"hamk_device.hpp\"\n\n");
+  const bool quad = d.mapping == HAMK_MAP_QUAD;
+  o << (d.wave ? "#include \"hamk_wave.hpp\"\n\n" : (quad ? "#include \"hamk_quad.hpp\"\n\n" : "#include \"hamk_device.hpp\"\n\n"));
   o << "struct HamkSys {\n";
   o << "  static constexpr int N = " << d.n << ";\n";
   o << "  static constexpr int M = " << d.m << ";\n";
@@ -496,7 +560,7 @@ std::string generate_source(const SystemDesc& d) {
   o << "  static constexpr int NTRIG_F = " << ntrig_f << ";\n";
   o << "  static constexpr int NTRIG_U = " << ntrig_u << ";\n";
   o << "};\n\n";
-  o << (d.wave ? "HAMK_INSTANTIATE_WAVE(HamkSys)\n" : "HAMK_INSTANTIATE(HamkSys)\n");
+  o << (d.wave ? "HAMK_INSTANTIATE_WAVE(HamkSys)\n" : (quad ? "HAMK_INSTANTIATE_QUAD(HamkSys)\n" : "HAMK_INSTANTIATE(HamkSys)\n"));
   return o.str();
 }
 

@@ -49,7 +49,10 @@
 
 #define HAMK_DEV __device__ __forceinline__
 #ifndef HAMK_K_REASSOC
-#define HAMK_K_REASSOC 0
+#define HAMK_K_REASSOC 1      /* K = J^T M J summed with re-association allowed (mass_matrix); 0: the round-2 FMA chain */
+#endif
+#ifndef HAMK_RK4_PARK
+#define HAMK_RK4_PARK 0       /* RK4 stage loop: y and the running combination parked in LDS across the right-hand side */
 #endif
 
 namespace hamk {
@@ -326,9 +329,8 @@ HAMK_DEV double val(double a) { return a; }
 // error); degree-13/12 minimax kernels on [-pi/4, pi/4] (coefficients as published in
 // fdlibm k_sin.c / k_cos.c); quadrant fix-up on integer bits.  ~20 fp64 instructions,
 // <= 1 ulp.  |x| >= 2^20 * pi/2, NaN and Inf take the library path (rare, divergent).
-HAMK_DEV void sincos_f64(double x, double& s, double& c) {
-  // fast path for every lane, unconditionally (one skip-branch around the rare slow path
-  // instead of an if/else diamond: half the scalar branch traffic in the inner loop)
+HAMK_DEV void sincos_f64_fast(double x, double& s, double& c) {
+  // the fast path alone: valid for |x| < 1.6e6 (callers that cannot exclude more run the library path on top, below)
   const double k = rint(x * 6.36619772367581382433e-01);
   double r = fma(-k, 1.57079632673412561417e+00, x);          // pi/2 bits  0..32
   r = fma(-k, 6.07710050630396597660e-11, r);                  //          33..65
@@ -359,6 +361,11 @@ HAMK_DEV void sincos_f64(double x, double& s, double& c) {
   const double c0 = swap ? sr : cr;
   s = __hiloint2double((int)((unsigned int)__double2hiint(s0) ^ ((q << 30) & 0x80000000u)), __double2loint(s0));
   c = __hiloint2double((int)((unsigned int)__double2hiint(c0) ^ (((q + 1u) << 30) & 0x80000000u)), __double2loint(c0));
+}
+HAMK_DEV void sincos_f64(double x, double& s, double& c) {
+  // fast path for every lane, unconditionally (one skip-branch around the rare slow path
+  // instead of an if/else diamond: half the scalar branch traffic in the inner loop)
+  sincos_f64_fast(x, s, c);
   // huge, NaN, Inf: library path.  Two calls, not ::sincos(x, &s, &c): the pointer form leaves an
   // address-taken stack slot (scratch) in every kernel that inlines this.
 #ifndef HAMK_PROBE_NO_SLOWPATH                             // scripts/isa_stats.py: count the fast path alone
@@ -415,7 +422,7 @@ HAMK_DEV void lut_load() {
   __syncthreads();
 #endif
 }
-HAMK_DEV void sincos_lut(double x, double& s, double& c) {
+HAMK_DEV void sincos_lut_fast(double x, double& s, double& c) {     // |x| < 1.6e6
   const double k = rint(x * 0x1.45f306dc9c883p+6);               // 512 / 2pi
   double r = fma(-k, 0x1.921fb58p-7, x);                         // 2pi/512 bits  0..25
   r = fma(-k, -0x1.dde974p-34, r);                               //              26..51
@@ -430,6 +437,9 @@ HAMK_DEV void sincos_lut(double x, double& s, double& c) {
   const double cm1 = z * pc;                                     // cos r - 1
   s = sa + fma(sa, cm1, ca * sd);
   c = ca + fma(ca, cm1, -(sa * sd));
+}
+HAMK_DEV void sincos_lut(double x, double& s, double& c) {
+  sincos_lut_fast(x, s, c);
 #ifndef HAMK_PROBE_NO_SLOWPATH
   if (!(fabs(x) < 1.6e6)) { s = ::sin(x); c = ::cos(x); }        // huge, NaN, Inf: library path
 #endif
@@ -1063,7 +1073,49 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
   const double h2 = 0.5 * dt, h6 = dt * (1.0 / 6.0), h3 = dt * (1.0 / 3.0);
   double H0 = 0.0;
   if (drift_tol > 0.0) H0 = energy<S>(y, st);
-  if constexpr (S::RK4_STAGE_LOOP) {
+  if constexpr (S::RK4_STAGE_LOOP && HAMK_RK4_PARK) {
+    // Large systems (n = 12..16): one right-hand side alone needs ~500 of the 512 registers a lane can have (K is
+    // n(n+1)/2 doubles), so the 2 x 2n doubles that only wait across it -- the step's base point y and the running
+    // combination acc -- are what the compiler spills: to scratch, i.e. through the vector memory pipe with its
+    // ~1 us round trip and one wavefront per SIMD to hide it (chain16: 8 GB of scratch traffic per launch against
+    // 34 MB of state).  Here they wait in LDS instead -- [component][lane], conflict-free 8-byte accesses, 2 x 2n x 2 KiB
+    // per 256-thread block (128 KiB at n = 16) -- and only yt -> k is in registers while the right-hand side runs.
+    __shared__ double park[2 * D * 256];
+    double* py = park + threadIdx.x;                        // y[j]   at py[j * 256]
+    double* pa = park + D * 256 + threadIdx.x;              // acc[j] at pa[j * 256]
+#pragma unroll
+    for (int j = 0; j < D; ++j) { py[j * 256] = y[j]; pa[j * 256] = y[j]; }
+    double k[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) k[j] = 0.0;
+#pragma unroll 1
+    for (int it = 0; it < 4 * nsteps; ++it) {
+      const int sg = it & 3;
+      const double a = (sg == 0) ? 0.0 : ((sg == 3) ? dt : h2);
+      const double b = (sg == 0 || sg == 3) ? h6 : h3;
+      double yt[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) yt[j] = fma(a, k[j], py[j * 256]);
+      tc.mode = sg;
+      if (sg >= 2) tc.mode = 5 - sg;
+#ifndef HAMK_HOST_EMULATION
+      __builtin_amdgcn_sched_barrier(0);                    // nothing of the combination below may be scheduled into the right-hand side
+#endif
+      rhs<S, StageTrig<S>::dyn>(yt, k, st, tc);
+#ifndef HAMK_HOST_EMULATION
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      if (sg == 3) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) { const double v = fma(b, k[j], pa[j * 256]); pa[j * 256] = v; py[j * 256] = v; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) pa[j * 256] = fma(b, k[j], pa[j * 256]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) y[j] = py[j * 256];
+  } else if constexpr (S::RK4_STAGE_LOOP) {
     // one copy of the right-hand side, executed 4 x nsteps times: keeps the live set to a
     // single hamEqs (n >= 3 would otherwise pay for four interleaved copies in VGPRs).
     double k[D], acc[D];
@@ -1295,6 +1347,12 @@ HAMK_DEV int park_in_vgpr(int x) {
 #endif
   return x;
 }
+// scripts/isa_stats.py (rkf45_attempt_stats) brackets one attempt and its right-hand sides in probe builds
+#ifdef HAMK_PROBE_MARK
+#define HAMK_MARK(k) __builtin_amdgcn_s_setprio(k)
+#else
+#define HAMK_MARK(k) ((void)0)
+#endif
 #define HAMK_RKF_FLAGS(row0, inplace, gsl_api) (((row0) & 1) | (((inplace) & 3) << 8) | (((gsl_api) & 3) << 16))
 template <class S>
 HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt, const double* __restrict__ ts, double ts0, double ts1, double h0,
@@ -1345,6 +1403,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
     const double ti = ts ? ts[r] : ts1;
     while (sgn * (ti - t) > 0.0 && budget > 0 && !failed) {
       ++attempts; --budget;
+      HAMK_MARK(1);
       const double dt = ti - t;
       double hh = h;
       bool final_step = false;
@@ -1398,7 +1457,9 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
             }
             break;
         }
+        HAMK_MARK(3);
         rhs<S, StageTrig<S>::lut ? TRIG_LUT : TRIG_FULL>(yt, out, st, tc);
+        HAMK_MARK(0);
         switch (sg) {
           case 0:
 #pragma unroll
@@ -1491,6 +1552,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
 #pragma unroll
         for (int j = 0; j < D; ++j) { y[j] = yn[j]; f0[j] = fn[j]; }
       }
+      HAMK_MARK(2);
     }
     if (sgn * (ti - t) > 0.0 && !failed) st |= ST_MAXSTEPS;
     if (r >= row0 && calls_left == 1) {

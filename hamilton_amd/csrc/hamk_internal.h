@@ -16,7 +16,10 @@ struct SystemDesc {
   bool rkf_stage_loop = false;
   int rk4_min_waves = 1;        // __launch_bounds__ second argument of the RK4 kernel (waves per SIMD)
   int use_lut = 2;              // stepping kernels: sincos through the LDS table (hamk_device.hpp StageTrig: 0, 1, 2)
-  bool wave = false;            // wave-cooperative kernels (hamk_wave.hpp) instead of one trajectory per lane
+  int mapping = 1;              // HAMK_MAP_* (hamk.h)
+  bool wave = false;            // mapping == HAMK_MAP_WAVE: wave-cooperative kernels (hamk_wave.hpp) instead of one trajectory per lane
+  bool k_reassoc = true;        // mass_matrix summed with re-association allowed (hamk_device.hpp)
+  bool rk4_park = false;        // lane mapping: RK4 stage loop parks y / acc in LDS across the right-hand side
   bool wave_blocked = false;    // wave kernels: LDL^T in panels of 16 with the trailing blocks updated on the matrix cores
   std::vector<double> inertia;
   std::vector<hamk_op> f_ops;
@@ -28,5 +31,7 @@ struct SystemDesc {
 // empty string = valid
 std::string validate_tape(const hamk_op* ops, int nops, int n_in, const int32_t* outs, int n_out, const char* what);
 std::string generate_source(const SystemDesc& d);
+// distinct non-zero entries of the coordinate map's Jacobian, as expressions (hamk_codegen.cpp)
+int distinct_jacobian_entries(const SystemDesc& d);
 
 }  // namespace hamk_host

@@ -1,0 +1,546 @@
+// hamk_quad.hpp -- FOUR LANES PER TRAJECTORY: the kernels for 17 <= n <= 32 generalized coordinates whose coordinate
+// map has a sparse Jacobian (BASELINE.json config 5, the N-link chain at N = 32), and for smaller n when the ensemble
+// is too small to fill the chip with one trajectory per lane.
+//
+// Why this mapping.  What one right-hand side (Hamilton.hs:370-387) costs at n = 32 is the factorisation of
+// K = J^T M J (n^3/3 flops) -- IF K itself is cheap.  With one trajectory per lane it is: the AD seeds are compile-time
+// constants, the compiler deletes every structural zero and shares every repeated entry of J (a chain's dx_k/dq_j is
+// one value for all k >= j), and with re-association allowed the sum over the 2n cartesian outputs collapses to
+// "count x product" (hamk_device.hpp mass_matrix): ~3 flops per entry of K instead of 2 x 2n.  But one lane cannot
+// hold K (528 doubles at n = 32), which is why round 1-2 mapped a trajectory to 32 lanes with one AD DIRECTION per
+// lane (hamk_wave.hpp) -- and paid for it: lane-dependent seeds make J dense (K = 64 x 32 x 32 on the matrix cores),
+// and the factorisation lives in LDS (one round trip per pivot pair; the LDS unit was the busiest resource).
+// Here both are kept: EVERY lane of a quad runs the per-trajectory sweeps with compile-time seeds (4x redundant, but
+// sparse: a few hundred instructions), and only the storage and factorisation of K are shared -- row a of K lives in
+// lane a % 4 (register slot a / 4), 144 doubles per lane at n = 32 -- with the pivot column exchanged by DPP
+// quad_perm broadcasts: no LDS in the factorisation at all, no dependent memory round trips, pure VALU.
+//   per lane and right-hand side at n = 32 (counted from the code object):
+//     sincos of the lane's 8 angles + exchange      ~0.3 k instructions
+//     sweep 1 + the lane's rows of K                ~1 k
+//     LDL^T (1.7 k FMAs + 1 k DPP moves + 32 rcp)   ~3 k
+//     back substitution                             ~0.5 k
+//     reverse sweep for dT/dq (redundant x 4)       ~1 k
+//   = ~6 k per lane for 16 trajectories per wavefront (~370 per trajectory) against ~3.4 k per wavefront for 2
+//   trajectories (~1700 per trajectory) of the wave-cooperative kernels.
+// LDS holds only what the four lanes share of the state: q, qd and the sincos pairs of the trajectory, [row][64
+// trajectories of the block] -- 64 KiB per 256-thread block at n = 32 -- read with immediate offsets from one base.
+//
+// Kernels provided: hamk_rk4_steps_k, hamk_hameqs_k, hamk_from_phase_k, hamk_observe_k.  The other entry points of a
+// system keep running on its wave-cooperative module (hamk_api.cpp dispatches per kernel).
+#pragma once
+#include "hamk_device.hpp"
+
+namespace hamk {
+namespace quad {
+
+template <int N> struct Geo {
+  static constexpr int NR = (N + 3) / 4;      // rows of K (= coordinates of the state) per lane
+  static constexpr int NP4 = 4 * NR;          // N rounded up to a multiple of four; rows >= N are identity padding
+  static constexpr int TPB = 64;              // trajectories per 256-thread block
+};
+
+// [row][64]: component `a` of the block's trajectory `tl` at a * 64 + tl (a wavefront reads 16 consecutive doubles, each
+// by the four lanes of a quad: conflict-free broadcasts)
+template <class S> struct Lds {
+  static constexpr int NP4 = Geo<S::N>::NP4;
+  static constexpr int Q = 0, V = NP4 * 64, SQ = 2 * NP4 * 64, CQ = 3 * NP4 * 64, TOTAL = 4 * NP4 * 64;
+};
+#define HAMK_QUAD_SMEM(S) __shared__ double smem[hamk::quad::Lds<S>::TOTAL]
+
+#ifdef HAMK_HOST_EMULATION
+// tests/host_emulation/wave_shim.hpp: one OS thread per lane; quad primitives through a per-quad barrier
+#define HAMK_QUAD_SYNC() emu_quad_barrier()
+#else
+HAMK_DEV void quad_sync_dev() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_sched_barrier(0);
+}
+#define HAMK_QUAD_SYNC() hamk::quad::quad_sync_dev()
+#endif
+
+// value of lane SRC of the caller's quad, in all four lanes: two v_mov_b32 with DPP quad_perm [SRC, SRC, SRC, SRC]
+template <int SRC> HAMK_DEV double qbcast(double x) {
+#ifdef HAMK_HOST_EMULATION
+  return emu_quad_read(x, SRC, 0);
+#else
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), SRC * 0x55, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), SRC * 0x55, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+#endif
+}
+// value of lane (own ^ MASK), MASK = 1: quad_perm [1, 0, 3, 2] = 0xB1; MASK = 2: [2, 3, 0, 1] = 0x4E
+template <int MASK> HAMK_DEV double qxor(double x) {
+#ifdef HAMK_HOST_EMULATION
+  return emu_quad_read(x, MASK, 1);
+#else
+  constexpr int ctrl = (MASK == 1) ? 0xB1 : 0x4E;
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), ctrl, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), ctrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+#endif
+}
+template <int MASK> HAMK_DEV int qxor_i(int x) {
+#ifdef HAMK_HOST_EMULATION
+  return emu_quad_read_i(x, MASK);
+#else
+  return __builtin_amdgcn_mov_dpp(x, (MASK == 1) ? 0xB1 : 0x4E, 0xf, 0xf, true);
+#endif
+}
+// the same bits in all four lanes (both levels add the same two numbers in both orders: + is commutative)
+HAMK_DEV double qsum(double x) { x += qxor<1>(x); x += qxor<2>(x); return x; }
+HAMK_DEV double qmax(double x) {
+  double y = qxor<1>(x); x = (y > x) ? y : x;
+  y = qxor<2>(x); return (y > x) ? y : x;
+}
+HAMK_DEV int qor(int x) { x |= qxor_i<1>(x); x |= qxor_i<2>(x); return x; }
+
+// candidate `r` of four (r = lane & 3): what "row 4 i + r" means in code that all four lanes execute
+HAMK_DEV double sel4(int r, double a, double b, double c, double d) {
+  const double ab = (r & 1) ? b : a, cd = (r & 1) ? d : c;
+  return (r & 2) ? cd : ab;
+}
+
+// one component of the trajectory's shared state in LDS
+struct LdsVec {
+  const double* p;
+  HAMK_DEV double operator[](int j) const { return p[j * 64]; }
+};
+// sweep inputs with COMPILE-TIME seeds: q_j with d/dq_i = delta_ij (j is a literal after inlining)
+template <int N> struct InJet1 {
+  const double* q;
+  HAMK_DEV Jet1<N> operator[](int j) const {
+    Jet1<N> r; r.v = q[j * 64];
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = (i == j) ? 1.0 : 0.0;
+    return r;
+  }
+};
+template <int N> struct InDouble {
+  const double* q;
+  HAMK_DEV double operator[](int j) const { return q[j * 64]; }
+};
+// sincos pairs of the trajectory's inputs in LDS, addressed by SITE (same member syntax as TrigCache: tc.s[k], tc.c[k])
+template <class S> struct TrigSite {
+  const double* base;
+  HAMK_DEV double operator[](int k) const { return base[S::trig_input(k) * 64]; }
+};
+template <class S> struct TrigLdsQ {
+  TrigSite<S> s, c;
+  double* ax; double* as; double* ac;       // unused (TRIG_REUSE never touches them)
+};
+
+template <class S> struct Ctx {
+  static constexpr int N = S::N, NR = Geo<N>::NR, NP4 = Geo<N>::NP4;
+  double* smem;      // the block's __shared__ array
+  int tl;            // the quad's trajectory within the block: row a of array X at smem[X + a * 64 + tl]
+  int r;             // lane within the quad
+  HAMK_DEV double* q() const { return smem + Lds<S>::Q + tl; }
+  HAMK_DEV double* v() const { return smem + Lds<S>::V + tl; }
+  HAMK_DEV double* sq() const { return smem + Lds<S>::SQ + tl; }
+  HAMK_DEV double* cq() const { return smem + Lds<S>::CQ + tl; }
+  HAMK_DEV TrigLdsQ<S> trig() const { TrigLdsQ<S> t; t.s.base = sq(); t.c.base = cq(); t.ax = t.as = t.ac = nullptr; return t; }
+#ifdef HAMK_HOST_EMULATION
+  HAMK_DEV Ctx launder() const { return *this; }
+#else
+  // the trajectory's offset re-defined opaquely per evaluation: every LDS address is smem + tl + literal, the literal
+  // folds into the DS offset field -- and loop-invariant code motion cannot hoist hundreds of addresses out of the
+  // stepping loop into registers (the lesson of hamk_wave.hpp's Ctx::launder)
+  // (r & 3 again after the barrier: the predicates "row 4 i + r is below pivot j" fold to always / never for all but three
+  // values of j - 4 i only if the compiler still knows that r < 4 -- without it every (i, j) pair keeps its own lane mask
+  // in an SGPR pair, ~1000 spilled SGPRs at n = 32)
+  HAMK_DEV Ctx launder() const { Ctx c = *this; asm volatile("" : "+v"(c.tl), "+v"(c.r)); c.r &= 3; c.tl &= 63; return c; }
+#endif
+};
+
+// entry a of a gradient, 0 beyond N (a is a literal after unrolling; the clamp keeps the abstract machine in bounds)
+template <int N> HAMK_DEV double dget(const double (&d)[N], int a) { return (a < N) ? d[(a < N) ? a : 0] : 0.0; }
+
+// ---- the lane's rows of K = J^T M J, accumulated while the sweep runs ----------------------------------------------
+// acc[i][b] = K[4 i + r][b] for b <= 4 i + 3 (the last four columns include the entries above the diagonal: K is
+// symmetric, the factorisation updates them consistently and never reads them).  The sum over the outputs is free to be
+// re-associated: for a chain the compiler turns it into count x (S_i A_b + S'_i B_b), S_i = the lane's pick of four
+// columns of J.
+template <class S> struct SinkK {
+  static constexpr int N = S::N, NR = Geo<N>::NR, NP4 = Geo<N>::NP4;
+  double acc[NR][NP4];
+  int r;
+  HAMK_DEV void init(int r_) {
+    r = r_;
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+      for (int b = 0; b < NP4; ++b) acc[i][b] = 0.0;
+  }
+  template <int K, int SEQ> HAMK_DEV void put(const Jet1<N>& x) {
+#pragma clang fp reassociate(on)
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const double xs = S::inertia(K) * sel4(r, dget<N>(x.d, 4 * i), dget<N>(x.d, 4 * i + 1), dget<N>(x.d, 4 * i + 2), dget<N>(x.d, 4 * i + 3));
+#pragma unroll
+      for (int b = 0; b < 4 * i + 4; ++b)
+        if (b < N) acc[i][b] += xs * x.d[(b < N) ? b : 0];
+    }
+  }
+  // rows >= N (n not a multiple of four): identity, so that the factorisation of the padded matrix is that of K
+  HAMK_DEV void pad() {
+    if constexpr (NP4 != N) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        if (4 * (NR - 1) + rr >= N && r == rr) acc[NR - 1][4 * (NR - 1) + rr] = 1.0;
+    }
+  }
+};
+
+// LDL^T of the quad's K in registers, the forward substitution of one right-hand side riding along.
+// On return: Kp[i][j], j < 4 i + r: L; dinv[i] = 1 / d_(4 i + r); z[i] = (L^-1 rhs)_(4 i + r).
+// Pivot j lives in lane j % 4, slot j / 4.  Per pivot: d_j and the column below it are broadcast (2 DPP moves per double),
+// every lane scales its own entries of the column and updates its rows up to the diagonal block -- code that is the same for
+// the four lanes: slot i is updated over columns (j, 4 i + 3] whichever row of the slot the lane owns; the entries beyond
+// the lane's diagonal are the symmetric ones and never read.
+template <class S>
+HAMK_DEV void ldlt(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], double (&dinv)[Geo<S::N>::NR], int& st) {
+  constexpr int N = S::N, NR = Geo<N>::NR, NP4 = Geo<N>::NP4;
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) dinv[i] = 1.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const int sj = j >> 2, rj = j & 3;
+    double d, zj;
+    switch (rj) {                                        // (j is a literal after unrolling: one case survives)
+      case 0: d = qbcast<0>(Kp[sj][j]); zj = qbcast<0>(z[sj]); break;
+      case 1: d = qbcast<1>(Kp[sj][j]); zj = qbcast<1>(z[sj]); break;
+      case 2: d = qbcast<2>(Kp[sj][j]); zj = qbcast<2>(z[sj]); break;
+      default: d = qbcast<3>(Kp[sj][j]); zj = qbcast<3>(z[sj]); break;
+    }
+    ok = ok && (d > 0.0);
+    const double inv = frcp(d);
+    if (r == rj) dinv[sj] = inv;
+    // the lane's multipliers of this pivot, one per slot (0 for rows at or above the pivot: they do not update)
+    double l[NR];
+#pragma unroll
+    for (int i = sj; i < NR; ++i) l[i] = (4 * i + r > j) ? Kp[i][j] * inv : 0.0;
+    // column k of the trailing matrix: c = K[k][j] from its owner, then every slot that reaches column k
+#pragma unroll
+    for (int k = j + 1; k < N; ++k) {
+      const int sk = k >> 2;
+      double c;
+      switch (k & 3) {
+        case 0: c = qbcast<0>(Kp[sk][j]); break;
+        case 1: c = qbcast<1>(Kp[sk][j]); break;
+        case 2: c = qbcast<2>(Kp[sk][j]); break;
+        default: c = qbcast<3>(Kp[sk][j]); break;
+      }
+#pragma unroll
+      for (int i = sk; i < NR; ++i) Kp[i][k] = fma(-l[i], c, Kp[i][k]);
+    }
+#pragma unroll
+    for (int i = sj; i < NR; ++i) {
+      z[i] = fma(-l[i], zj, z[i]);
+      if (4 * i + 3 > j) Kp[i][j] = (4 * i + r > j) ? l[i] : Kp[i][j];      // L, final (the pivot's own lane keeps d_j)
+    }
+  }
+  if (!ok) st |= ST_SINGULAR;                            // no pivoting fallback (as in the wave kernels)
+}
+
+// D y = z, L^T v = y; returns the lane's v_(4 i + r).  Row-oriented: L[k][a] is in the lane that owns row k, so the lanes
+// accumulate partial sums s[a] = sum over their own solved rows k > a of L[k][a] v_k and the four partial sums meet in a
+// quad reduction when v_a is due.
+template <class S>
+HAMK_DEV void solve_back(int r, const double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], const double (&z)[Geo<S::N>::NR],
+                         const double (&dinv)[Geo<S::N>::NR], double (&v)[Geo<S::N>::NR]) {
+  constexpr int N = S::N, NR = Geo<N>::NR, NP4 = Geo<N>::NP4;
+  double s[NP4];
+#pragma unroll
+  for (int a = 0; a < NP4; ++a) s[a] = 0.0;
+#pragma unroll
+  for (int i = NR - 1; i >= 0; --i) {
+    const double w = z[i] * dinv[i];
+    double vi = 0.0;
+#pragma unroll
+    for (int rr = 3; rr >= 0; --rr) {
+      const int a = 4 * i + rr;
+      if (a >= N) continue;
+      const double va = w - qsum(s[a]);                  // meaningful in lane rr
+      if (r == rr) vi = va;
+      // row a's entries inside the diagonal block feed the rows of the same slot still to come
+#pragma unroll
+      for (int a2 = 4 * i; a2 < a; ++a2) s[a2] = fma((r == rr) ? Kp[i][a2] : 0.0, va, s[a2]);
+    }
+    v[i] = vi;
+#pragma unroll
+    for (int a2 = 0; a2 < 4 * i; ++a2) s[a2] = fma(Kp[i][a2], vi, s[a2]);
+  }
+}
+
+// How an evaluation gets its sincos pairs.  When every site of f takes an input as operand (angles) each lane evaluates
+// the pairs of its own coordinates once and the quad shares them through LDS (TRIG_REUSE in both sweeps); otherwise every
+// lane evaluates the sites itself in sweep 1 and keeps them in registers for the reverse sweep.
+template <class S, bool LUT> struct Trig {
+  static constexpr bool shared = S::TRIG_ALL_INPUTS && S::NTRIG_F > 0;
+  static constexpr int mode1 = shared ? TRIG_REUSE : (LUT ? TRIG_LUT : TRIG_FULL);
+};
+
+// Shared first half of every evaluation: q to LDS, sincos pairs, sweep 1 with K accumulated in the sink, LDL^T with the
+// forward substitution of p, back substitution.  Returns the lane's velocities; gU (own rows), U.
+template <class S, bool LUT, class TC>
+HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const double (&pi)[Geo<S::N>::NR],
+                       double (&vi)[Geo<S::N>::NR], double (&gUi)[Geo<S::N>::NR], double& U, int& st, TC& tc) {
+  constexpr int N = S::N, NR = Geo<N>::NR;
+  const int r = c.r;
+  HAMK_QUAD_SYNC();                                       // readers of the previous evaluation are done
+#pragma unroll
+  for (int i = 0; i < NR; ++i) c.q()[(4 * i + r) * 64] = qi[i];
+  if constexpr (Trig<S, LUT>::shared) {
+    bool far = false;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      double sv, cv;
+      if constexpr (LUT) sincos_lut_fast(qi[i], sv, cv); else sincos_f64_fast(qi[i], sv, cv);
+      c.sq()[(4 * i + r) * 64] = sv; c.cq()[(4 * i + r) * 64] = cv;
+      far = far || !(fabs(qi[i]) < 1.6e6);
+    }
+#ifndef HAMK_PROBE_NO_SLOWPATH
+    // huge, NaN, Inf: the library path -- ONE copy for the lane's angles (a rolled loop over what is already in LDS;
+    // one inlined copy per angle is ~2000 instructions and a dozen SGPR pairs of exec masks each)
+    if (far) {
+#pragma unroll 1
+      for (int i = 0; i < NR; ++i) {
+        const double x = c.q()[(4 * i + r) * 64];
+        if (!(fabs(x) < 1.6e6)) { c.sq()[(4 * i + r) * 64] = ::sin(x); c.cq()[(4 * i + r) * 64] = ::cos(x); }
+      }
+    }
+#endif
+  }
+  HAMK_QUAD_SYNC();
+  SinkK<S> sink;
+  sink.init(r);
+  InJet1<N> in{c.q()};
+  TrigCache<S::NTRIG_U> tu;
+  const Jet1<N> u = S::template coords_sink_u<Jet1<N>, Trig<S, LUT>::mode1>(in, tc, tu, sink);
+  sink.pad();
+  U = u.v;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) gUi[i] = sel4(r, dget<N>(u.d, 4 * i), dget<N>(u.d, 4 * i + 1), dget<N>(u.d, 4 * i + 2), dget<N>(u.d, 4 * i + 3));
+  double z[NR], dinv[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) z[i] = pi[i];
+  ldlt<S>(r, sink.acc, z, dinv, st);
+  solve_back<S>(r, sink.acc, z, dinv, vi);
+}
+
+// hamEqs for the quad's trajectory: the lane returns (dq, dp) of its coordinates.         Hamilton.hs:370-387
+template <class S, bool LUT>
+HAMK_DEV void ham_eqs(const Ctx<S>& c0, const double (&qi)[Geo<S::N>::NR], const double (&pi)[Geo<S::N>::NR],
+                      double (&dqi)[Geo<S::N>::NR], double (&dpi)[Geo<S::N>::NR], int& st) {
+  constexpr int N = S::N, NR = Geo<N>::NR;
+  const Ctx<S> c = c0.launder();
+  const int r = c.r;
+  double vi[NR], gUi[NR], U;
+  double dT[N];
+  // dT/dq = -d/dq [sum_k m_k (J qd)_k (D_qd x_k)] with (J qd)_k held fixed: the generated reverse sweep, per trajectory,
+  // every lane of the quad (compile-time sparsity; the cooperative alternative is dense in every direction)
+  if constexpr (Trig<S, LUT>::shared) {
+    TrigLdsQ<S> tl = c.trig();
+    velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tl);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) c.v()[(4 * i + r) * 64] = vi[i];
+    HAMK_QUAD_SYNC();
+    const Ctx<S> c2 = c.launder();
+    LdsVec q{c2.q()}, v{c2.v()};
+    TrigLdsQ<S> t2 = c2.trig();
+    S::dT_reverse(q, v, t2, dT);
+  } else {
+    TrigCache<S::NTRIG_F> tc;
+    velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tc);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) c.v()[(4 * i + r) * 64] = vi[i];
+    HAMK_QUAD_SYNC();
+    const Ctx<S> c2 = c.launder();
+    LdsVec q{c2.q()}, v{c2.v()};
+    S::dT_reverse(q, v, tc, dT);
+  }
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    dqi[i] = vi[i];
+    dpi[i] = -(sel4(r, dget<N>(dT, 4 * i), dget<N>(dT, 4 * i + 1), dget<N>(dT, 4 * i + 2), dget<N>(dT, 4 * i + 3)) + gUi[i]);
+  }
+}
+
+// velocities alone (fromPhase, keP, hamiltonian)
+template <class S, bool LUT>
+HAMK_DEV void velocity_only(const Ctx<S>& c0, const double (&qi)[Geo<S::N>::NR], const double (&pi)[Geo<S::N>::NR],
+                            double (&vi)[Geo<S::N>::NR], double& U, int& st) {
+  constexpr int NR = Geo<S::N>::NR;
+  const Ctx<S> c = c0.launder();
+  double gUi[NR];
+  if constexpr (Trig<S, LUT>::shared) { TrigLdsQ<S> tl = c.trig(); velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tl); }
+  else { TrigCache<S::NTRIG_F> tc; velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tc); }
+}
+
+// ---- kernels --------------------------------------------------------------------------------------------------------
+template <class S> struct Where {
+  static constexpr int N = S::N, NR = Geo<N>::NR;
+  i64 t;            // trajectory index (clamped to B-1 for the tail)
+  bool real;        // the quad's trajectory exists
+  Ctx<S> c;
+  HAMK_DEV Where(double* smem, i64 B) {
+    c.tl = threadIdx.x >> 2;
+    c.r = threadIdx.x & 3;
+    const i64 tt = (i64)blockIdx.x * Geo<N>::TPB + c.tl;
+    real = tt < B;
+    t = real ? tt : B - 1;
+    c.smem = smem;
+  }
+  HAMK_DEV bool owns(int i) const { return 4 * i + c.r < N; }
+  HAMK_DEV void load(const double* a, i64 B, double (&x)[NR]) const {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { const int j = owns(i) ? 4 * i + c.r : 0; const double y = a[(i64)j * B + t]; x[i] = owns(i) ? y : 0.0; }
+  }
+  HAMK_DEV void store(double* a, i64 B, const double (&x)[NR]) const {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) if (real && owns(i)) a[(i64)(4 * i + c.r) * B + t] = x[i];
+  }
+};
+
+template <class S, bool LUT> HAMK_DEV double energy(const Ctx<S>& c0, const double (&qi)[Geo<S::N>::NR], const double (&pi)[Geo<S::N>::NR], int& st) {
+  constexpr int NR = Geo<S::N>::NR;
+  double vi[NR], U;
+  velocity_only<S, LUT>(c0, qi, pi, vi, U, st);
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) t = fma(vi[i], pi[i], t);
+  return fma(0.5, qsum(t), U);
+}
+
+template <class S>
+HAMK_DEV void rk4_body(double* smem, double* q, double* p, i64 B, double dt, int nsteps, double drift_tol, int* status) {
+  constexpr int N = S::N, NR = Geo<N>::NR;
+  constexpr bool LUT = StageTrig<S>::lut;                 // the stepping kernel loads the sincos table (hamk_device.hpp)
+  if constexpr (LUT) lut_load();
+  Where<S> w(smem, B);
+  double yq[NR], yp[NR];
+  w.load(q, B, yq); w.load(p, B, yp);
+  int st = 0;
+  double H0 = 0.0;
+  if (drift_tol > 0.0) H0 = energy<S, LUT>(w.c, yq, yp, st);
+  const double h2 = 0.5 * dt, h6 = dt * (1.0 / 6.0), h3 = dt * (1.0 / 3.0);
+  double kq[NR], kp[NR], aq[NR], ap[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) { kq[i] = 0.0; kp[i] = 0.0; aq[i] = yq[i]; ap[i] = yp[i]; }
+#pragma unroll 1
+  for (int it = 0; it < 4 * nsteps; ++it) {
+    const int sg = it & 3;
+    const double a = (sg == 0) ? 0.0 : ((sg == 3) ? dt : h2);
+    const double b = (sg == 0 || sg == 3) ? h6 : h3;
+    double tq[NR], tp[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { tq[i] = fma(a, kq[i], yq[i]); tp[i] = fma(a, kp[i], yp[i]); }
+    ham_eqs<S, LUT>(w.c, tq, tp, kq, kp, st);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { aq[i] = fma(b, kq[i], aq[i]); ap[i] = fma(b, kp[i], ap[i]); }
+    if (sg == 3) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) { yq[i] = aq[i]; yp[i] = ap[i]; }
+    }
+  }
+  if (drift_tol > 0.0) {
+    int st1 = 0;
+    const double H1 = energy<S, LUT>(w.c, yq, yp, st1);
+    const double lim = drift_tol * fmax(1.0, fabs(H0));
+    if (!(fabs(H1 - H0) <= lim) || is_nonfinite_bits(H1)) st |= ST_DRIFT;
+  }
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) bad = bad || (w.owns(i) && (is_nonfinite_bits(yq[i]) || is_nonfinite_bits(yp[i])));
+  if (bad) st |= ST_NONFINITE;
+  const int stq = qor(st);
+  w.store(q, B, yq); w.store(p, B, yp);
+  if (status && w.real && w.c.r == 0) status[w.t] = stq;
+}
+
+template <class S>
+HAMK_DEV void hameqs_body(double* smem, const double* q, const double* p, double* dq, double* dp, i64 B, int* status) {
+  constexpr int NR = Geo<S::N>::NR;
+  Where<S> w(smem, B);
+  double qi[NR], pi[NR], a[NR], b[NR];
+  w.load(q, B, qi); w.load(p, B, pi);
+  int st = 0;
+  ham_eqs<S, false>(w.c, qi, pi, a, b, st);
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) bad = bad || (w.owns(i) && (is_nonfinite_bits(a[i]) || is_nonfinite_bits(b[i])));
+  if (bad) st |= ST_NONFINITE;
+  const int stq = qor(st);
+  w.store(dq, B, a); w.store(dp, B, b);
+  if (status && w.real && w.c.r == 0) status[w.t] = stq;
+}
+
+template <class S>
+HAMK_DEV void from_phase_body(double* smem, const double* q, const double* p, double* qd, i64 B, int* status) {
+  constexpr int NR = Geo<S::N>::NR;
+  Where<S> w(smem, B);
+  double qi[NR], pi[NR], vi[NR], U;
+  w.load(q, B, qi); w.load(p, B, pi);
+  int st = 0;
+  velocity_only<S, false>(w.c, qi, pi, vi, U, st);
+  const int stq = qor(st);
+  w.store(qd, B, vi);
+  if (status && w.real && w.c.r == 0) status[w.t] = stq;
+}
+
+template <class S>
+HAMK_DEV void observe_body(double* smem, const double* q, const double* p, double* ke, double* pe, double* h, i64 B, int* status) {
+  constexpr int NR = Geo<S::N>::NR;
+  Where<S> w(smem, B);
+  double qi[NR], pi[NR], vi[NR], U;
+  w.load(q, B, qi);
+  if (p) w.load(p, B, pi);
+  else {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) pi[i] = 0.0;
+  }
+  int st = 0;
+  velocity_only<S, false>(w.c, qi, pi, vi, U, st);
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) t = fma(vi[i], pi[i], t);
+  t = 0.5 * qsum(t);
+  const int stq = qor(st);
+  if (w.real && w.c.r == 0) {
+    if (ke) ke[w.t] = t;
+    if (pe) pe[w.t] = U;
+    if (h) h[w.t] = t + U;
+    if (status) status[w.t] = (ke || h) ? stq : 0;
+  }
+}
+
+}  // namespace quad
+}  // namespace hamk
+
+// The four kernels of the quad mapping (the names of HAMK_INSTANTIATE; the other four stay with the wave module).
+#define HAMK_INSTANTIATE_QUAD(S)                                                                                 \
+  HAMK_SCRIBBLE_KERNEL                                                                                           \
+  extern "C" __global__ void __launch_bounds__(256) hamk_rk4_steps_k(double* q, double* p, long long B,          \
+                                                          double dt, int nsteps, double drift_tol, int* status) { \
+    HAMK_QUAD_SMEM(S);                                                                                           \
+    hamk::quad::rk4_body<S>(smem, q, p, B, dt, nsteps, drift_tol, status);                                       \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_hameqs_k(const double* q, const double* p, double* dq,  \
+                                                                   double* dp, long long B, int* status) {       \
+    HAMK_QUAD_SMEM(S);                                                                                           \
+    hamk::quad::hameqs_body<S>(smem, q, p, dq, dp, B, status);                                                   \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_from_phase_k(const double* q, const double* p,          \
+                                                                       double* qd, long long B, int* status) {   \
+    HAMK_QUAD_SMEM(S);                                                                                           \
+    hamk::quad::from_phase_body<S>(smem, q, p, qd, B, status);                                                   \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_observe_k(const double* q, const double* p, double* ke, \
+                                                                    double* pe, double* h, long long B,          \
+                                                                    int* status) {                               \
+    HAMK_QUAD_SMEM(S);                                                                                           \
+    hamk::quad::observe_body<S>(smem, q, p, ke, pe, h, B, status);                                               \
+  }

@@ -339,11 +339,14 @@ HAMK_DEV void factor_blocked(const Ctx<S>& c, double& dinv, int& st, double& z) 
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-(xa * xd[cm]), xb[cm], acc, 0, 0, 0);
           }
           double* Tw = c.smem + c.offw + g * PER;
+          // In the diagonal block lanes (row, col) and (col, row) hold the same entry of the symmetric update, each from
+          // its own MFMA -- fl(fl(L_i d) L_j) in one, fl(fl(L_j d) L_i) in the other, equal up to the last bit -- and both
+          // would address the same packed slot: only the lane on or below the diagonal stores, so what the triangle holds
+          // never depends on the order in which a wavefront's stores land (four predicated stores per panel).
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * ib + 4 * r + kq, col = J0 + l16;
-            const int hi = (ib != pb || row > col) ? row : col, lo = (ib != pb || row > col) ? col : row;
-            Tw[hi * (hi + 1) / 2 + lo] = acc[r];
+            if (ib != pb || row >= col) Tw[row * (row + 1) / 2 + col] = acc[r];
           }
         }
       }

@@ -41,33 +41,24 @@ def gather_state(q, p, dist, world: int):
 # ---------------------------------------------------------------------------------------
 # ensemble checkpoint / resume.  The reference's "resume" story is
 # `iterate (stepHam dt s)` on a `Phase n` value (README.md:150); an ensemble is two flat fp64
-# arrays plus what is needed to regenerate or extend it.
+# arrays plus what is needed to regenerate or extend it.  ONE format: the C ABI's
+# (hamk_checkpoint_write / _info / _read: 64-byte header, SoA state, SHA-256); a sharded run
+# writes one file per rank, named by (rank, world) -- the shard's first global index follows
+# from shard_bounds / weak_bounds, the per-index seed is in the header.
 # ---------------------------------------------------------------------------------------
-CHECKPOINT_VERSION = 1
+def shard_path(base: str, rank: int, world: int) -> str:
+    return f"{base}.{rank:04d}-of-{world:04d}.hamkckp"
 
 
-def save_checkpoint(path: str, system: str, q, p, *, t: float, step: int, dt: float, seed: int,
-                    first_index: int = 0, status=None) -> None:
-    """Flat binary (.npz, uncompressed) dump of an SoA ensemble shard."""
-    def host(a):
-        return a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
-    q, p = host(q), host(p)
-    if q.shape != p.shape or q.ndim != 2:
-        raise ValueError("q and p must both be [n, B]")
-    extra = {} if status is None else {"status": host(status).astype(np.int32)}
-    np.savez(path, version=np.int64(CHECKPOINT_VERSION), system=np.array(system), q=q.astype(np.float64),
-             p=p.astype(np.float64), t=np.float64(t), step=np.int64(step), dt=np.float64(dt),
-             seed=np.int64(seed), first_index=np.int64(first_index), **extra)
+def save_shard(base: str, rank: int, world: int, phase, n: int, *, steps_done: int, seed: int, t: float) -> str:
+    """This rank's shard (numpy arrays or torch CUDA tensors, [n, B]) through hamk_checkpoint_write."""
+    from . import api
+    path = shard_path(base, rank, world)
+    api.saveCheckpoint(path, phase, n, steps_done=steps_done, seed=seed, t=t)
+    return path
 
 
-def load_checkpoint(path: str) -> dict:
-    with np.load(path if path.endswith(".npz") else path + ".npz", allow_pickle=False) as z:
-        if int(z["version"]) != CHECKPOINT_VERSION:
-            raise ValueError(f"unsupported checkpoint version {int(z['version'])}")
-        out = {k: z[k] for k in z.files}
-    out["system"] = str(out["system"])
-    for k in ("t", "dt"):
-        out[k] = float(out[k])
-    for k in ("step", "seed", "first_index", "version"):
-        out[k] = int(out[k])
-    return out
+def load_shard(base: str, rank: int, world: int, device=None):
+    """(Phase, info) of this rank's shard; device=None: numpy arrays, else CUDA tensors on it."""
+    from . import api
+    return api.loadCheckpoint(shard_path(base, rank, world), device)

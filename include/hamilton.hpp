@@ -267,7 +267,9 @@ inline Phase Phs(std::vector<double> q, std::vector<double> p) {
 // ---------------------------------------------------------------------------------------
 class System {
  public:
-  System(int m, int n, const std::vector<double>& inertia, const VecFn& f, const ScalarFn& u, int u_space)
+  // opt: the library's choices fixed by the caller (hamk.h hamk_options; nullptr = all defaults)
+  System(int m, int n, const std::vector<double>& inertia, const VecFn& f, const ScalarFn& u, int u_space,
+         const hamk_options* opt = nullptr)
       : m_(m), n_(n) {
     if ((int)inertia.size() != m) throw std::invalid_argument("inertia must have m entries");
     Tape tf(n), tu(u_space == HAMK_U_CARTESIAN ? m : n);
@@ -276,8 +278,8 @@ class System {
     f_ops_ = tf.canonical(f_outs_);
     u_ops_ = tu.canonical(u_outs_);
     hamk_system* h = nullptr;
-    check(hamk_system_create(m, n, inertia.data(), f_ops_.data(), (int32_t)f_ops_.size(), f_outs_.data(),
-                             u_ops_.data(), (int32_t)u_ops_.size(), u_outs_[0], u_space, &h));
+    check(hamk_system_create_ex(m, n, inertia.data(), f_ops_.data(), (int32_t)f_ops_.size(), f_outs_.data(),
+                                u_ops_.data(), (int32_t)u_ops_.size(), u_outs_[0], u_space, opt, &h));
     h_.reset(h, hamk_system_destroy);
   }
   // the tapes that crossed the ABI (canonical form)
@@ -288,6 +290,8 @@ class System {
   int m() const { return m_; }
   int n() const { return n_; }
   hamk_system* handle() const { return h_.get(); }
+  // every choice resolved, for a launch over B trajectories (B < 0: a large ensemble)
+  hamk_options options(int64_t B = -1) const { hamk_options o; check(hamk_system_get_options(h_.get(), B, &o)); return o; }
   std::string source() const { return hamk_system_source(h_.get()); }
   std::vector<int32_t> last_status;
 
@@ -308,12 +312,12 @@ class System {
 };
 
 // mkSystem: potential over generalized coordinates                   Hamilton.hs:201-225
-inline System mkSystem(const std::vector<double>& inertia, int n, const VecFn& f, const ScalarFn& u) {
-  return System((int)inertia.size(), n, inertia, f, u, HAMK_U_GENERALIZED);
+inline System mkSystem(const std::vector<double>& inertia, int n, const VecFn& f, const ScalarFn& u, const hamk_options* opt = nullptr) {
+  return System((int)inertia.size(), n, inertia, f, u, HAMK_U_GENERALIZED, opt);
 }
 // mkSystem': potential over the underlying cartesian coordinates      Hamilton.hs:238-254
-inline System mkSystemP(const std::vector<double>& inertia, int n, const VecFn& f, const ScalarFn& u) {
-  return System((int)inertia.size(), n, inertia, f, u, HAMK_U_CARTESIAN);
+inline System mkSystemP(const std::vector<double>& inertia, int n, const VecFn& f, const ScalarFn& u, const hamk_options* opt = nullptr) {
+  return System((int)inertia.size(), n, inertia, f, u, HAMK_U_CARTESIAN, opt);
 }
 
 // ---------------------------------------------------------------------------------------

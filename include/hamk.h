@@ -144,6 +144,62 @@ typedef struct hamk_op {
 
 typedef struct hamk_system hamk_system;   /* opaque */
 
+/* ---- options of a system (hamk_system_create_ex) -----------------------------------------------------
+ * Everything the library decides for itself when it specialises its kernels for a system can be fixed by the host
+ * instead.  HAMK_AUTO (0) in a field leaves that decision to the library; a zero-filled struct with `size` set is
+ * "all defaults".  The environment variables of DESIGN.md section 6c are TEST overrides: they apply only where the
+ * field is HAMK_AUTO.  hamk_system_get_options reports what was actually chosen.                                  */
+#define HAMK_AUTO 0
+#define HAMK_ON   1
+#define HAMK_OFF  2
+/* which lanes serve one trajectory */
+#define HAMK_MAP_LANE 1   /* one trajectory per wavefront lane, everything in registers (n <= 16)                      */
+#define HAMK_MAP_WAVE 2   /* wave-cooperative: 16 / 32 / 64 lanes per trajectory, one AD direction per lane, K and its
+                             factorisation on the matrix cores and in LDS (any n <= 64; the only mapping for n > 32)   */
+#define HAMK_MAP_QUAD 3   /* four lanes per trajectory: every lane runs the sparse per-trajectory AD sweeps, the rows of
+                             K are dealt out over the four lanes and factorised in registers with DPP exchanges
+                             (17 <= n <= 32 when the coordinate map's Jacobian is sparse enough; also usable for n <= 16) */
+/* second-order AD strategy */
+#define HAMK_AD_H 1       /* one sweep of full second-order jets                        */
+#define HAMK_AD_D 2       /* first-order sweep, then a directional second-order sweep   */
+#define HAMK_AD_R 3       /* first-order sweep, then a generated reverse sweep          */
+/* stepping-loop bodies */
+#define HAMK_BODY_UNROLLED   1
+#define HAMK_BODY_STAGE_LOOP 2
+/* sincos of the stepping kernels */
+#define HAMK_TRIG_DIRECT       1   /* sincos_f64, no table                              */
+#define HAMK_TRIG_TABLE        2   /* every evaluation through the 512-pair table in LDS */
+#define HAMK_TRIG_TABLE_ROTATE 3   /* one table evaluation per step, stages 2-4 by rotation */
+/* which of the two builds of a module its kernels are taken from */
+#define HAMK_BUILD_DEFAULT 1
+#define HAMK_BUILD_NOLICM  2       /* -mllvm -disable-machine-licm                      */
+
+typedef struct hamk_options {
+  uint32_t size;           /* sizeof(hamk_options) as the caller's header has it (hamk_options_init sets it)           */
+  int32_t mapping;         /* HAMK_MAP_*; AUTO: chosen PER LAUNCH from (n, ensemble size B): a small ensemble of a
+                              mid-size system cannot fill the chip with one trajectory per lane                         */
+  int32_t ad_mode;         /* HAMK_AD_*                                                                                 */
+  int32_t rk4_body;        /* HAMK_BODY_*                                                                               */
+  int32_t rkf_body;        /* HAMK_BODY_*                                                                               */
+  int32_t trig;            /* HAMK_TRIG_*                                                                               */
+  int32_t gsl_api;         /* 1 | 2 (hamk_system_set_gsl_api); AUTO: 2                                                  */
+  int32_t self_check;      /* ON | OFF: first-use self-check of the stepping kernels; AUTO: ON                          */
+  int32_t build;           /* HAMK_BUILD_*; AUTO: per kernel, the build that spills fewer SGPRs                         */
+  int32_t wave_blocked;    /* ON | OFF: wave mapping, LDL^T in panels of 16 with MFMA trailing updates; AUTO: n > 16    */
+  int32_t rk4_min_waves;   /* __launch_bounds__ waves per SIMD of the RK4 kernel; AUTO: measured default                */
+  int32_t k_reassoc;       /* ON | OFF: K = J^T M J summed with re-association allowed (repeated Jacobian entries are
+                              multiplied by their count instead of added up); AUTO: ON                                  */
+  int32_t rk4_park;        /* ON | OFF: lane mapping, RK4 stage loop keeps y and the running combination in LDS across
+                              the right-hand side; AUTO: n >= 12                                                        */
+  int32_t max_substeps;    /* sub-step budget per stepHam / evolveHam interval and trajectory; AUTO: 2^24               */
+  int32_t cache;           /* ON | OFF: on-disk cache of compiled code objects; AUTO: ON                                */
+  int32_t lanes_per_trajectory;  /* OUTPUT of hamk_system_get_options: 1, 4, 16, 32 or 64                               */
+  int32_t reserved[16];           /* sizeof(hamk_options) = 128 */
+} hamk_options;
+
+/* Zero-fills *opt and sets opt->size.                                                                                 */
+void hamk_options_init(hamk_options* opt);
+
 /* ---- system construction (mkSystem / mkSystem') --------------------------
  * inertia[m]; coordinate map f: n inputs -> m outputs f_outs[m] (value ids in
  * f_ops); potential u: scalar output u_out (value id in u_ops) over n
@@ -153,12 +209,26 @@ int hamk_system_create(int32_t m, int32_t n, const double* inertia,
                        const hamk_op* f_ops, int32_t f_nops, const int32_t* f_outs,
                        const hamk_op* u_ops, int32_t u_nops, int32_t u_out,
                        int32_t u_space, hamk_system** out);
+/* The same with options (NULL = all defaults = hamk_system_create).  Builds the specialisation the options name; with
+ * mapping = HAMK_AUTO the one a large ensemble uses (others are built the first time a launch needs them).            */
+int hamk_system_create_ex(int32_t m, int32_t n, const double* inertia,
+                          const hamk_op* f_ops, int32_t f_nops, const int32_t* f_outs,
+                          const hamk_op* u_ops, int32_t u_nops, int32_t u_out,
+                          int32_t u_space, const hamk_options* opt, hamk_system** out);
+/* What a launch over B trajectories uses (every field resolved, no HAMK_AUTO left; lanes_per_trajectory filled in).
+ * Builds that specialisation if it does not exist yet.                                                                */
+int hamk_system_get_options(hamk_system* s, int64_t B, hamk_options* resolved);
+/* Makes the introspection entry points below (source, code_size, code_object, build_info, kernel_bytes) describe the
+ * specialisation a launch over B trajectories uses (default: the one built at creation).                              */
+int hamk_system_describe_batch(hamk_system* s, int64_t B);
 void hamk_system_destroy(hamk_system* s);
 int  hamk_system_dims(const hamk_system* s, int32_t* m, int32_t* n);
 
-/* Launch on this HIP stream (hipStream_t as void*; NULL = default stream).  */
+/* Launch on this HIP stream (hipStream_t as void*; NULL = default stream).  A stream belongs to one device: the
+ * binding is made for the device that is CURRENT when this is called and used whenever the handle runs on that
+ * device; other devices keep their own (default: the null stream).                                                 */
 int hamk_set_stream(hamk_system* s, void* hip_stream);
-/* Block until everything queued on the handle's stream has finished.        */
+/* Block until everything queued on the handle's stream of the current device has finished.                         */
 int hamk_synchronize(hamk_system* s);
 
 /* Which of the two GSL bindings in hmatrix-gsl's gsl-ode.c stepHam / evolveHam reproduce
@@ -294,7 +364,10 @@ int hamk_gather_batch(int32_t nparts, int32_t n, const int64_t* B_parts, const d
  * is staged in 8 MiB pieces.  Written aside and renamed: a crash leaves the previous file.
  * steps_done / seed / t are the caller's bookkeeping (per-index splitmix64 seed of the initial
  * conditions, steps taken, model time) and come back from hamk_checkpoint_info.  Every kernel is a
- * pure function of the state, so a resumed run continues bit-identically.                         */
+ * pure function of the state, so a resumed run continues bit-identically.
+ * Device state is copied on the NULL stream: hamk_synchronize the handle (or synchronise the stream that
+ * produced / will consume q, p) before a write and before using the arrays after a read.  A header that does
+ * not match the file's size is rejected before anything is allocated from it.                      */
 int hamk_checkpoint_write(const char* path, int32_t n, int64_t B, const double* q, const double* p,
                           int32_t mem, int64_t steps_done, uint64_t seed, double t);
 int hamk_checkpoint_info(const char* path, int32_t* n, int64_t* B, int64_t* steps_done,

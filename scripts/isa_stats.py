@@ -225,6 +225,59 @@ def rk4_step_stats(spec, system=None):
                       "removed) and -DHAMK_PROBE_TRIG (wave-uniform sincos case fixed), stepping loop of hamk_rk4_steps_k, weighted per step"}
 
 
+def rkf45_attempt_stats(spec, system=None):
+    """Cost of ONE attempt of the adaptive stepper (hamk_rkf45_k; six right-hand sides + controller) of one wavefront,
+    counted from a probe build of the same module: -DHAMK_PROBE_NO_SLOWPATH removes the never-executed library branches,
+    -DHAMK_PROBE_MARK brackets the attempt (s_setprio 1 ... 2) and, in the stage-loop body, the one inlined right-hand
+    side (s_setprio 3 ... 0), which an attempt executes six times.  Lane kernels only."""
+    if not os.path.exists(OBJDUMP):
+        return None
+    from hamilton_amd import api
+    if system is None:
+        system = api.system_from_spec(spec)
+    src = system.source
+    if "HAMK_INSTANTIATE_WAVE" in src:
+        return None
+    env = {"HAMK_RKF_LOOP": "1" if "RKF_STAGE_LOOP = true" in src else "0", "HAMK_WAVE": "0",
+           "HAMK_AD_MODE": "H" if "MODE_H = true" in src else ("R" if "MODE_R = true" in src else "D"),
+           "HAMK_HIPRTC_FLAGS": (os.environ.get("HAMK_HIPRTC_FLAGS", "") + " -DHAMK_PROBE_NO_SLOWPATH -DHAMK_PROBE_MARK").strip()}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        probe = api.system_from_spec(spec)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    info = {l.split()[0]: l.split()[1] for l in probe.build_info.splitlines() if l}
+    co = probe.code_object(1 if "no-machine-licm" in info.get("hamk_rkf45_k", "") else 0)
+    ins = disassemble(co).get("hamk_rkf45_k") if co else None
+    if not ins:
+        return None
+    where = {}
+    for i, (_, mn, ops) in enumerate(ins):
+        if mn == "s_setprio":
+            where.setdefault(int(ops.split()[0]), []).append(i)
+    if 1 not in where or 2 not in where:
+        return None
+    lo, hi = min(where[1]), max(where[2])
+    rhs_spans = list(zip(sorted(where.get(3, [])), sorted(where.get(0, []))))
+    in_rhs = lambda i: any(a <= i <= b for a, b in rhs_spans)
+    once = collections.Counter(classify(mn) for i, (_, mn, _) in enumerate(ins[lo:hi + 1], lo) if not in_rhs(i))
+    rhs = collections.Counter(classify(mn) for i, (_, mn, _) in enumerate(ins[lo:hi + 1], lo) if in_rhs(i))
+    tot = collections.Counter()
+    for k, v in once.items():
+        tot[k] += v
+    for k, v in rhs.items():
+        tot[k] += 6 * v
+    valu = sum(v for c, v in tot.items() if c.startswith("valu"))
+    return {"valu_per_wave_attempt": valu, "valu_f64_per_wave_attempt": tot.get("valu_f64", 0), "lds_per_wave_attempt": tot.get("lds", 0),
+            "scratch_per_wave_attempt": tot.get("scratch", 0), "body": "stage loop (one inlined right-hand side x 6)" if rhs_spans else "unrolled",
+            "source": "llvm-objdump of hamk_rkf45_k built with -DHAMK_PROBE_NO_SLOWPATH -DHAMK_PROBE_MARK: one attempt between its markers"}
+
+
 def main():
     from hamilton_amd import api, examples
     name = sys.argv[1] if len(sys.argv) > 1 else "doublePendulum"

@@ -9,7 +9,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}_{system}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-KERNEL = "hamk_rk4_steps_k"
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "hamk_rk4_steps_k"
 
 shutil.copy(os.path.join(src, "stats", f"{tag}_kernel_stats.csv"), os.path.join(dst, f"{tag}_{system}_kernel_stats.csv"))
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "stats", f"{tag}_kernel_stats.csv")))}
@@ -24,7 +24,7 @@ if os.path.exists(bj) and os.path.getsize(bj):
     summary["rocprof_vs_hip_events"] = float(stats[KERNEL]["AverageNs"]) * 1e-6 / bench["roofline"]["kernel_ms"]
 
 pmc = {}
-for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds", "pmc_mfma"):
     path = os.path.join(src, name, f"{tag}_counter_collection.csv")
     if not os.path.exists(path):
         continue
@@ -56,7 +56,21 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and bench:
               open(os.path.join(dst, f"pmc_traffic_{system}.json"), "w"), indent=1)
 if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc and K:
     summary["valu_insts_per_wave_per_rk4_step"] = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"] / K
-    if "SQ_ACTIVE_INST_VALU" in pmc and "SQ_BUSY_CYCLES" in pmc:
-        summary["valu_busy_frac"] = pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_BUSY_CYCLES"]
+    # SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count QUAD-cycles summed over every wavefront (or SIMD) of the chip,
+    # GRBM_GUI_ACTIVE counts cycles summed over the 8 XCDs (MI355X_MICROARCH.md): a fraction needs the same unit on both
+    # sides.  (Round 2 divided SQ_ACTIVE_INST_VALU by SQ_BUSY_CYCLES and called 7.8 a fraction.)
+    if "SQ_ACTIVE_INST_VALU" in pmc and "SQ_WAVE_CYCLES" in pmc:
+        summary["valu_active_frac_of_wave_cycles"] = pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_WAVE_CYCLES"]
+    if "SQ_ACTIVE_INST_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
+        summary["valu_pipe_busy_frac_of_1024_simds"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (pmc["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    if "SQ_WAIT_INST_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc:
+        summary["wait_frac_of_wave_cycles"] = pmc["SQ_WAIT_INST_ANY"] / pmc["SQ_WAVE_CYCLES"]
+if "SQ_LDS_IDX_ACTIVE" in pmc and "GRBM_GUI_ACTIVE" in pmc:
+    # LDS-array cycles summed over the 256 CUs against the kernel's cycles x 256 LDS units
+    summary["lds_busy_frac_of_256_units"] = pmc["SQ_LDS_IDX_ACTIVE"] / (pmc["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)
+    if "SQ_LDS_BANK_CONFLICT" in pmc:
+        summary["lds_bank_conflict_frac_of_lds_cycles"] = pmc["SQ_LDS_BANK_CONFLICT"] / max(1.0, pmc["SQ_LDS_IDX_ACTIVE"])
+if "SQ_INSTS_LDS" in pmc and "SQ_WAVES" in pmc and K:
+    summary["lds_insts_per_wave_per_rk4_step"] = pmc["SQ_INSTS_LDS"] / pmc["SQ_WAVES"] / K
 json.dump(summary, open(os.path.join(dst, f"{tag}_{system}_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))

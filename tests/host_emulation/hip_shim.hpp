@@ -16,6 +16,9 @@
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
+#ifndef __shared__
+#define __shared__ static                /* one OS thread at a time per block (lane kernels): a static array indexed by threadIdx */
+#endif
 
 struct emu_dim3 { unsigned x = 0, y = 0, z = 0; };
 static thread_local emu_dim3 threadIdx, blockIdx, blockDim;

@@ -11,12 +11,18 @@
 #include <thread>
 #include <vector>
 
+#ifndef __shared__
 #define __shared__ static
+#endif
 
+struct EmuQuadBarrier { std::barrier<> b{4}; };
 struct EmuWave {
   std::barrier<> bar{64};
   int xi[64];
   double xd[64], xa[64], xb[64];
+  EmuQuadBarrier qbar[16];                        // hamk_quad.hpp: four lanes per trajectory, quads run independently
+  double qd[64];
+  int qi[64];
 };
 static EmuWave* emu_wave = nullptr;              // the wavefront being executed
 static thread_local int emu_lane = 0;
@@ -26,6 +32,22 @@ static inline void emu_wave_barrier() { emu_wave->bar.arrive_and_wait(); }
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 
+// quad primitives of hamk_quad.hpp (on the device: DPP quad_perm moves, no memory)
+static inline void emu_quad_barrier() { emu_wave->qbar[emu_lane >> 2].b.arrive_and_wait(); }
+static inline double emu_quad_read(double x, int sel, int xor_mode) {
+  emu_wave->qd[emu_lane] = x;
+  emu_quad_barrier();
+  const double r = emu_wave->qd[xor_mode ? (emu_lane ^ sel) : ((emu_lane & ~3) | sel)];
+  emu_quad_barrier();
+  return r;
+}
+static inline int emu_quad_read_i(int x, int mask) {
+  emu_wave->qi[emu_lane] = x;
+  emu_quad_barrier();
+  const int r = emu_wave->qi[emu_lane ^ mask];
+  emu_quad_barrier();
+  return r;
+}
 static inline int __builtin_amdgcn_ds_bpermute(int byte_index, int v) {
   emu_wave->xi[emu_lane] = v;
   emu_wave_barrier();

@@ -189,3 +189,41 @@ def test_wave_specialisation_compiles_for_gfx950(hamk_lib, monkeypatch, name):
     monkeypatch.setenv("HAMK_WAVE", "1")
     s = api.system_from_spec(E.get(name))
     assert "HAMK_INSTANTIATE_WAVE(HamkSys)" in s.source and s.num_device_functions == 9
+
+
+def test_options_cross_the_abi_not_the_environment(hamk_lib, monkeypatch):
+    """hamk_system_create_ex / hamk_system_get_options: a host language selects the specialisation through a struct;
+    environment variables only fill what the struct leaves to the library (HAMK_AUTO)."""
+    from hamilton_amd import _abi, api
+    for k in ("HAMK_WAVE", "HAMK_AD_MODE", "HAMK_TRIG_LUT", "HAMK_RK4_LOOP", "HAMK_RKF_LOOP", "HAMK_GSL_API"):
+        monkeypatch.delenv(k, raising=False)
+    spec = E.get("chain8")
+    d = api.system_from_spec(spec).options()
+    assert d["mapping"] == _abi.MAP_LANE and d["ad_mode"] == _abi.AD_R and d["lanes_per_trajectory"] == 1
+    assert d["gsl_api"] == 2 and d["self_check"] == _abi.ON and d["k_reassoc"] == _abi.ON
+    s = api.system_from_spec(spec, {"mapping": _abi.MAP_WAVE, "ad_mode": _abi.AD_D, "trig": _abi.TRIG_DIRECT, "gsl_api": 1,
+                                    "self_check": _abi.OFF, "max_substeps": 777})
+    r = s.options()
+    assert (r["mapping"], r["trig"], r["gsl_api"], r["self_check"], r["max_substeps"]) == (_abi.MAP_WAVE, _abi.TRIG_DIRECT, 1, _abi.OFF, 777)
+    assert r["lanes_per_trajectory"] == 16 and "HAMK_INSTANTIATE_WAVE" in s.source and s.gsl_api == 1
+    # the environment is an override of AUTO fields only
+    monkeypatch.setenv("HAMK_AD_MODE", "D")
+    monkeypatch.setenv("HAMK_GSL_API", "1")
+    assert api.system_from_spec(spec).options()["ad_mode"] == _abi.AD_D
+    assert api.system_from_spec(spec, {"ad_mode": _abi.AD_R, "gsl_api": 2}).options()["ad_mode"] == _abi.AD_R
+    assert api.system_from_spec(spec, {"ad_mode": _abi.AD_R, "gsl_api": 2}).gsl_api == 2
+    # misuse
+    with pytest.raises(api.HamkError) as e:
+        api.system_from_spec(spec, {"mapping": 9})
+    assert e.value.code == _abi.HAMK_ERR_INVALID
+    with pytest.raises(api.HamkError) as e:
+        api.system_from_spec(E.get("chain20"), {"mapping": _abi.MAP_LANE})
+    assert e.value.code == _abi.HAMK_ERR_UNSUPPORTED
+    # a caller built against an older, shorter header: the tail of the struct stays AUTO
+    o = _abi.HamkOptions(mapping=_abi.MAP_WAVE)
+    o.size = 12
+    o.k_reassoc = _abi.OFF                                    # beyond `size`: must be ignored
+    assert api.system_from_spec(spec, o).options()["k_reassoc"] == _abi.ON
+    o.size = 0
+    with pytest.raises(api.HamkError):
+        api.system_from_spec(spec, o)

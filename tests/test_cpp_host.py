@@ -38,6 +38,9 @@ def test_cpp_host_runs_on_gpu(dp_binary):
     q0, q1, p0, p1 = map(float, m.groups())
     assert abs(q0 - 1.5705463267948976) < 1e-9 and abs(p0 + 0.0999999981) < 1e-9   # oracle: test_oracle_golden
     assert "evolveHam rows = 3" in out
+    assert "iterateStepHam same = 1 frames = 2" in out
+    m = re.search(r"options trig = (\d+) rkf_body = (\d+) gsl_api = (\d+) lanes = (\d+) dq = (\S+)", out)
+    assert [int(x) for x in m.groups()[:4]] == [1, 2, 1, 1] and float(m.group(5)) < 1e-12      # same step under other choices
     m = re.search(r"hamiltonian = (\S+)", out)
     assert abs(float(m.group(1)) - 7.5) < 1e-7                                      # H conserved from seInit
 

@@ -50,7 +50,7 @@ def emulate(hamk_lib, tmp_path_factory):
             cpp, so = str(tmp / f"{key}.cpp"), str(tmp / f"{key}.so")
             with open(cpp, "w") as fh:
                 fh.write(src + open(os.path.join(EMU, "driver.inc")).read())
-            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-attributes",
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-fno-gnu-unique", "-Wno-unknown-pragmas", "-Wno-attributes",
                                    "-include", os.path.join(EMU, "hip_shim.hpp"), "-I" + os.path.join(ROOT, "hamilton_amd", "csrc"),
                                    "-o", so, cpp])
             cache[key] = ctypes.CDLL(so)
@@ -322,7 +322,7 @@ def test_device_code_on_host_matches_golden_fixtures(emulate, name):
 @pytest.fixture(scope="module")
 def elementary(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("emu_elem") / "elem.so")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-attributes",
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-fno-gnu-unique", "-Wno-unknown-pragmas", "-Wno-attributes",
                            "-include", os.path.join(EMU, "hip_shim.hpp"), "-I" + os.path.join(ROOT, "hamilton_amd", "csrc"),
                            "-o", so, os.path.join(EMU, "sincos_driver.cpp")])
     return ctypes.CDLL(so)
@@ -455,7 +455,7 @@ def emulate_wave(hamk_lib, tmp_path_factory):
             cpp, so = str(tmp / f"{key}.cpp"), str(tmp / f"{key}.so")
             with open(cpp, "w") as fh:
                 fh.write(src + open(os.path.join(EMU, "wave_driver.inc")).read())
-            subprocess.check_call(["g++", "-O1", "-std=c++20", "-pthread", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-attributes",
+            subprocess.check_call(["g++", "-O1", "-std=c++20", "-pthread", "-fPIC", "-shared", "-fno-gnu-unique", "-Wno-unknown-pragmas", "-Wno-attributes",
                                    "-Wno-psabi", "-include", os.path.join(EMU, "wave_shim.hpp"), "-I" + EMU,
                                    "-I" + os.path.join(ROOT, "hamilton_amd", "csrc"), "-o", so, cpp])
             cache[key] = ctypes.CDLL(so)
@@ -524,3 +524,90 @@ def test_iterate_stepham_is_the_calls_one_by_one(emulate, oracle_lib, name, env)
     for _ in range(ncalls):
         oq, op, _ = o.step_ham_batch(oq, op, dt)
     assert relerr(q2, oq) < 1e-9 and relerr(p2, op) < 1e-9
+
+
+# ---- four lanes per trajectory (hamk_quad.hpp) ----------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def emulate_quad(hamk_lib, tmp_path_factory):
+    from hamilton_amd import _abi, api
+    cache = {}
+    tmp = tmp_path_factory.mktemp("emuq")
+
+    def make(spec, options=None):
+        opt = {"mapping": _abi.MAP_QUAD}
+        opt.update(options or {})
+        src = api.system_from_spec(spec, opt).source
+        assert "hamk_quad.hpp" in src and "HAMK_INSTANTIATE_QUAD" in src
+        key = hashlib.sha1(src.encode()).hexdigest()[:16]
+        if key not in cache:
+            cpp, so = str(tmp / f"{key}.cpp"), str(tmp / f"{key}.so")
+            with open(cpp, "w") as fh:
+                fh.write(src + open(os.path.join(EMU, "quad_driver.inc")).read())
+            subprocess.check_call(["g++", "-O1", "-std=c++20", "-pthread", "-fPIC", "-shared", "-fno-gnu-unique", "-Wno-unknown-pragmas", "-Wno-attributes",
+                                   "-Wno-psabi", "-include", os.path.join(EMU, "wave_shim.hpp"), "-I" + EMU,
+                                   "-I" + os.path.join(ROOT, "hamilton_amd", "csrc"), "-o", so, cpp])
+            cache[key] = ctypes.CDLL(so)
+        return cache[key]
+    return make
+
+
+def check_quad_against_oracle(L, spec, o, B, steps=2, tol=1e-10, start=11):
+    q, qd = E.sample_config(spec, start, B)
+    rng = np.random.default_rng(5)
+    qd = qd + 0.3 * rng.standard_normal(qd.shape)           # the chains' box has them at rest
+    p = o.to_phase_batch(q, qd)
+    st = np.zeros(B, np.int32)
+    odq, odp, ost = o.hameqs_batch(q, p)
+    assert not ost.any()
+    dq, dp = np.zeros_like(q), np.zeros_like(q)
+    L.emu_hameqs(P(q), P(p), P(dq), P(dp), LL(B), I(st))
+    assert not st.any()
+    assert relerr(dq, odq) < tol and relerr(dp, odp) < tol, (relerr(dq, odq), relerr(dp, odp))
+    v = np.zeros_like(q)
+    L.emu_from_phase(P(q), P(p), P(v), LL(B), I(st))
+    assert relerr(v, o.from_phase_batch(q, p)[0]) < tol
+    ke, pe, h = np.zeros(B), np.zeros(B), np.zeros(B)
+    L.emu_observe(P(q), P(p), P(ke), P(pe), P(h), LL(B), I(st))
+    oke, ope, oh = o.observe_batch(q, p)
+    assert relerr(ke, oke) < tol and relerr(pe, ope) < tol and relerr(h, oh) < tol
+    q2, p2 = q.copy(), p.copy()
+    L.emu_rk4(P(q2), P(p2), LL(B), ctypes.c_double(spec.dt), steps, I(st))
+    oq, op = o.rk4_steps_batch(q, p, spec.dt, steps)
+    assert relerr(q2, oq) < 10 * tol and relerr(p2, op) < 10 * tol, (relerr(q2, oq), relerr(p2, op))
+    # one launch = two launches, bitwise; the checked entry point takes the same steps and flags nothing at a loose tolerance
+    q3, p3 = q.copy(), p.copy()
+    L.emu_rk4(P(q3), P(p3), LL(B), ctypes.c_double(spec.dt), 1, I(st))
+    L.emu_rk4(P(q3), P(p3), LL(B), ctypes.c_double(spec.dt), steps - 1, I(st))
+    assert np.array_equal(q3, q2) and np.array_equal(p3, p2)
+    q4, p4 = q.copy(), p.copy()
+    L.emu_rk4_checked(P(q4), P(p4), LL(B), ctypes.c_double(spec.dt), steps, ctypes.c_double(0.5), I(st))
+    assert np.array_equal(q4, q2) and not st.any()
+    L.emu_rk4_checked(P(q4), P(p4), LL(B), ctypes.c_double(spec.dt), steps, ctypes.c_double(1e-300), I(st))
+    assert np.all((st == 16) | (st == 0)) and (st == 16).any()      # HAMK_ST_DRIFT wherever H moved at all
+
+
+@pytest.mark.parametrize("name,B", [("chain32", 17), ("chain20", 3), ("chain18", 5), ("chain17", 2), ("chain8", 19), ("chain5", 4),
+                                    ("threeBodyPolar", 6), ("spring", 9), ("opcodeZoo", 7), ("twoBody", 5)])
+def test_quad_kernels_on_host_match_oracle(emulate_quad, oracle_lib, name, B):
+    """Every lane runs the per-trajectory sweeps with compile-time seeds, the rows of K are dealt out over the four lanes of
+    a quad and factorised in registers with (emulated) DPP broadcasts, the reverse sweep gives dT/dq -- against the oracle:
+    n a multiple of four and not (identity padding: 17, 18, 5, 6, 3, 2), one to eight rows per lane, sincos pairs shared
+    through LDS (angles as inputs) and per lane (opcodeZoo: sites that are not inputs), potentials over cartesian and
+    generalized coordinates, unequal inertias, ensembles that do not fill the last wavefront or block."""
+    spec = E.get(name)
+    L = emulate_quad(spec)
+    check_quad_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=B)
+
+
+def test_quad_flags_a_singular_mass_matrix(emulate_quad, oracle_lib):
+    """twoBody at r = 0: K = diag(mu, mu r^2) has a zero pivot -> HAMK_ST_SINGULAR for that trajectory only."""
+    spec = E.get("twoBody")
+    L = emulate_quad(spec)
+    B = 6
+    q, qd = E.sample_config(spec, 3, B)
+    p = oracle_lib.OracleSystem(spec).to_phase_batch(q, qd)
+    q[0, 2] = 0.0
+    st = np.zeros(B, np.int32)
+    dq, dp = np.zeros_like(q), np.zeros_like(q)
+    L.emu_hameqs(P(q), P(p), P(dq), P(dp), LL(B), I(st))
+    assert (st[2] & 1) and not np.delete(st, 2).any()

@@ -71,19 +71,33 @@ def test_shard_bounds_partition():
         ensemble.shard_bounds(10, 2, 2)
 
 
-def test_checkpoint_roundtrip(tmp_path, oracle_lib):
-    """Resume = reload the two flat arrays and keep stepping: identical bits to an uninterrupted run."""
+def test_checkpoint_roundtrip(tmp_path, oracle_lib, hamk_lib):
+    """Resume = reload the two flat arrays and keep stepping: identical bits to an uninterrupted run.  One checkpoint
+    format -- the C ABI's (hamk_checkpoint_*), one file per rank of a sharded run."""
+    from hamilton_amd import api
     spec = E.get("spring")
     o = oracle_lib.OracleSystem(spec)
-    q, qd = E.sample_config(spec, 10, 32)
+    world = 2
+    q, qd = E.sample_config(spec, 0, 64)
     p = o.to_phase_batch(q, qd, threads=1)
-    q1, p1 = o.rk4_steps_batch(q, p, spec.dt, 4, threads=1)
-    path = str(tmp_path / "ens")
-    ensemble.save_checkpoint(path, spec.name, q1, p1, t=4 * spec.dt, step=4, dt=spec.dt, seed=E.SEED, first_index=10)
-    ck = ensemble.load_checkpoint(path)
-    assert ck["system"] == "spring" and ck["step"] == 4 and ck["first_index"] == 10 and ck["seed"] == E.SEED
-    np.testing.assert_array_equal(ck["q"], q1)
-    q2, p2 = o.rk4_steps_batch(ck["q"], ck["p"], ck["dt"], 3, threads=1)
     qf, pf = o.rk4_steps_batch(q, p, spec.dt, 7, threads=1)
-    np.testing.assert_array_equal(q2, qf)
-    np.testing.assert_array_equal(p2, pf)
+    for rank in range(world):
+        lo, hi = ensemble.shard_bounds(64, world, rank)
+        q1, p1 = o.rk4_steps_batch(q[:, lo:hi], p[:, lo:hi], spec.dt, 4, threads=1)
+        ensemble.save_shard(str(tmp_path / "ens"), rank, world, api.Phase(q1, p1), spec.n, steps_done=4, seed=E.SEED, t=4 * spec.dt)
+    for rank in range(world):
+        lo, hi = ensemble.shard_bounds(64, world, rank)
+        ph, info = ensemble.load_shard(str(tmp_path / "ens"), rank, world)
+        assert info == {"n": spec.n, "B": hi - lo, "steps_done": 4, "seed": E.SEED, "t": 4 * spec.dt}
+        q2, p2 = o.rk4_steps_batch(ph.positions, ph.momenta, spec.dt, 3, threads=1)
+        np.testing.assert_array_equal(q2, qf[:, lo:hi])
+        np.testing.assert_array_equal(p2, pf[:, lo:hi])
+    # a header that does not describe its file is rejected before anything is allocated from it
+    path = ensemble.shard_path(str(tmp_path / "ens"), 0, world)
+    raw = bytearray(open(path, "rb").read())
+    raw[16:24] = (1 << 50).to_bytes(8, "little")              # B
+    open(path, "wb").write(bytes(raw))
+    with pytest.raises(api.HamkError):
+        api.checkpointInfo(path)
+    with pytest.raises(api.HamkError):
+        api.loadCheckpoint(path)
