@@ -467,8 +467,9 @@ def main():
                     traffic_source = f"STATIC: profiles/pmc_traffic_{a.system}.json ({rec.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE')}), not measured by this run"
             except Exception:
                 traffic = None
-        wave = "HAMK_INSTANTIATE_WAVE" in s.source
+        s.describe_batch(B)                              # the specialisation a launch over this shard uses
         lanes_per_traj = s.lanes_per_trajectory          # 1, or the cooperative group size the module was built with
+        wave = lanes_per_traj >= 16
         fp64 = {"per_gpu_steps_per_s": per_gpu_rate, "peak_tflops": FP64_PEAK_TFLOPS, "lanes_per_trajectory": lanes_per_traj}
         if not a.no_isa:
             try:
@@ -499,7 +500,7 @@ def main():
             "config": {"workload": f"{a.system} (System {spec.m} {spec.n}) ensemble"
                                    + (f", BASELINE.json {cfg_id}" if cfg_id and a.batch == cfg_B else ""),
                        "trajectories_per_gpu": B, "rk4_steps_per_launch": a.rk4_per_step, "dt": dt,
-                       "kernel_path": "wave-cooperative" if wave else "one trajectory per lane",
+                       "kernel_path": "wave-cooperative" if wave else ("four lanes per trajectory" if lanes_per_traj == 4 else "one trajectory per lane"),
                        "parallelism": f"ensemble-shard x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -174,10 +174,11 @@ def rk4_step_stats(spec, system=None):
         system = api.system_from_spec(spec)
     src = system.source
     wave = "HAMK_INSTANTIATE_WAVE" in src
-    stage_loop = "RK4_STAGE_LOOP = true" in src or wave
+    quad = "HAMK_INSTANTIATE_QUAD" in src
+    stage_loop = "RK4_STAGE_LOOP = true" in src or wave or quad
     m = re.search(r"NTRIG_F = (\d+)", src)
-    chained = (not wave) and m is not None and 1 <= int(m.group(1)) <= 4          # hamk_device.hpp StageTrig
-    base_env = {"HAMK_RK4_LOOP": "1" if "RK4_STAGE_LOOP = true" in src else "0", "HAMK_WAVE": "1" if wave else "0",
+    chained = (not wave) and (not quad) and m is not None and 1 <= int(m.group(1)) <= 4          # hamk_device.hpp StageTrig
+    base_env = {"HAMK_RK4_LOOP": "1" if "RK4_STAGE_LOOP = true" in src else "0", "HAMK_WAVE": "1" if wave else "0", "HAMK_QUAD": "1" if quad else "0",
                 "HAMK_AD_MODE": "H" if "MODE_H = true" in src else ("R" if "MODE_R = true" in src else "D")}
 
     def count(trig):

@@ -41,6 +41,15 @@ def jobs():
         out.append((n, {"HAMK_TRIG_LUT": "1"}, False))
     for seed in range(16):
         out.append((f"random{seed}", {}, False))
+    # four lanes per trajectory (hamk_quad.hpp): the default RK4 / hamEqs module of 17 <= n <= 32 (built by the plain jobs
+    # above); the wave module those systems keep for their other entry points; forced quad builds of small systems
+    for n in ("chain17", "chain18", "chain20", "chain24", "chain32"):
+        out.append((n, {"HAMK_WAVE": "1"}, False))
+    out.append(("chain24", {}, False))
+    for n in ("chain16", "chain8", "threeBodyPolar", "spring", "opcodeZoo"):
+        out.append((n, {"HAMK_QUAD": "1"}, False))
+    for n in ("chain12", "chain16"):
+        out.append((n, {"HAMK_RK4_PARK": "0"}, False))
     return out
 
 

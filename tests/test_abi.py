@@ -82,8 +82,8 @@ def test_defaults_of_the_wave_kernels(hamk_lib, monkeypatch):
     """What the library chooses for n > 16 (each choice measured on MI355X): LDL^T in panels
     of 16 with MFMA trailing updates; beyond n = 32 the RK4 kernel capped for two wavefronts per SIMD; a forced
     wave build of a small system (one panel) keeps the flat factorisation."""
-    from hamilton_amd import api
-    mid = api.system_from_spec(E.get("chain20")).source
+    from hamilton_amd import _abi, api
+    mid = api.system_from_spec(E.get("chain20"), {"mapping": _abi.MAP_WAVE}).source
     assert "hamk_wave.hpp" in mid and "#define HAMK_WAVE_BLOCKED 1" in mid and "HAMK_RK4_MIN_WAVES_BIG" not in mid
     big = api.system_from_spec(E.get("chain33")).source
     assert "#define HAMK_WAVE_BLOCKED 1" in big and "#define HAMK_RK4_MIN_WAVES_BIG 2" in big
@@ -227,3 +227,14 @@ def test_options_cross_the_abi_not_the_environment(hamk_lib, monkeypatch):
     o.size = 0
     with pytest.raises(api.HamkError):
         api.system_from_spec(spec, o)
+
+
+def test_mapping_defaults_by_size_and_structure(hamk_lib):
+    """n <= 16: one trajectory per lane; 17 <= n <= 32 with a sparse Jacobian (the chains): four lanes per trajectory for
+    the kernels of the hot path, the wave-cooperative module for the rest; n > 32: wave-cooperative."""
+    from hamilton_amd import _abi, api
+    assert api.system_from_spec(E.get("chain16")).options()["mapping"] == _abi.MAP_LANE
+    s = api.system_from_spec(E.get("chain20"))
+    assert s.options()["mapping"] == _abi.MAP_QUAD and s.lanes_per_trajectory == 4 and "hamk_quad.hpp" in s.source
+    assert s.num_device_functions == 5                        # rk4, hamEqs, fromPhase, observe + the self-check's scribble kernel
+    assert api.system_from_spec(E.get("chain33")).options()["mapping"] == _abi.MAP_WAVE

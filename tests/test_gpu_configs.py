@@ -183,7 +183,7 @@ def test_full_size(api, oracle_lib, cid, name, B, nsteps, nsample, DRIFT_TOL):
     r_drift = float(d1.median() / d2.median())
     record(test="full_size", cid=cid, B=B, nsteps=nsteps, flagged_frac=frac_flagged, oracle_sample_err=eo,
            rev_median=float(e1.median()), rev_max=float(e1.max()), drift_median=float(d1.median()), drift_max=float(d1.max()),
-           ratio_rev=r_rev, ratio_drift=r_drift, wave="HAMK_INSTANTIATE_WAVE" in s.source)
+           ratio_rev=r_rev, ratio_drift=r_drift, lanes_per_trajectory=s.lanes_per_trajectory)
     # RK4: global error ~ dt^4, the time-reversal defect and the energy drift one order better or
     # equal; where a quantity is already at roundoff level the ratio says nothing and is skipped
     # measured: 31.5-32.0 (the defect of reversing an RK4 step is O(h^5)) and 15-26
@@ -241,8 +241,7 @@ def test_evolveham_under_both_gsl_bindings(api, oracle_lib, monkeypatch, name, f
     if force_wave:
         monkeypatch.setenv("HAMK_WAVE", "1")
     s = api.system_from_spec(spec)
-    is_wave = "HAMK_INSTANTIATE_WAVE" in s.source
-    assert is_wave == (force_wave or spec.n > 16)
+    is_wave = force_wave or spec.n > 16                     # the module the ADAPTIVE stepper of this system runs on
     o = oracle_lib.OracleSystem(spec)
     s.gsl_api = gsl_api
     o.gsl_api = gsl_api

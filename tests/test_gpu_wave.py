@@ -19,6 +19,14 @@ def api(hamk_lib):
     return _api
 
 
+def record(**kw):
+    import json, os
+    path = os.environ.get("HAMK_TEST_RECORD")
+    if path:
+        with open(path, "a") as fh:
+            fh.write(json.dumps(kw) + "\n")
+
+
 def relerr(a, b):
     return float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.maximum(1.0, np.abs(np.asarray(b)))))
 
@@ -31,9 +39,8 @@ CASES = [("spring", True), ("threeBodyPolar", True), ("chain4", True), ("opcodeZ
 @pytest.mark.parametrize("name,force", CASES)
 def test_wave_path_vs_oracle(api, oracle_lib, monkeypatch, name, force):
     spec = E.get(name)
-    if force:
-        monkeypatch.setenv("HAMK_WAVE", "1")
-    s = api.system_from_spec(spec)
+    from hamilton_amd import _abi
+    s = api.system_from_spec(spec, {"mapping": _abi.MAP_WAVE})      # through the ABI's options (17 <= n <= 32 default to the quad kernels)
     assert "HAMK_INSTANTIATE_WAVE" in s.source
     o = oracle_lib.OracleSystem(spec)
     for B in (1, 5, 67):                           # tails: not a multiple of the 8/16 trajectories per block
@@ -104,9 +111,8 @@ def test_wave_path_matches_golden_and_lane_path(api, monkeypatch):
 def test_wave_adaptive_stepper_vs_oracle(api, oracle_lib, monkeypatch, name, force):
     """stepHam / evolveHam on the wave path: GSL-semantics RKF45 with group-uniform control."""
     spec = E.get(name)
-    if force:
-        monkeypatch.setenv("HAMK_WAVE", "1")
-    s = api.system_from_spec(spec)
+    from hamilton_amd import _abi
+    s = api.system_from_spec(spec, {"mapping": _abi.MAP_WAVE})
     assert "HAMK_INSTANTIATE_WAVE" in s.source
     o = oracle_lib.OracleSystem(spec)
     B = 37
@@ -157,3 +163,64 @@ def test_lane_path_at_its_upper_size(api, oracle_lib):
     st = api.stepHam(0.005, s, api.Phase(q, p))
     sq, sp, _ = o.step_ham_batch(q, p, 0.005)
     assert relerr(st.positions, sq) < 1e-8 and relerr(st.momenta, sp) < 1e-8
+
+
+# ---- four lanes per trajectory (hamk_quad.hpp): the default for 17 <= n <= 32 with a sparse Jacobian ------------------
+QUAD_CASES = [("chain32", False), ("chain20", False), ("chain17", False), ("chain18", False),
+              ("chain16", True), ("chain8", True), ("threeBodyPolar", True), ("spring", True), ("opcodeZoo", True)]
+
+
+@pytest.mark.parametrize("name,force", QUAD_CASES)
+def test_quad_path_vs_oracle(api, oracle_lib, name, force):
+    """Every lane runs the sparse per-trajectory sweeps, the rows of K are dealt out over a quad and factorised in
+    registers with DPP broadcasts (hamk_quad.hpp).  hamEqs / velocities / energies / RK4 against the oracle at ensemble
+    sizes that leave the last wavefront and block partly filled; the entry points the quad module does not provide
+    (momenta, stepHam, ...) run on the system's other module through the same handle."""
+    from hamilton_amd import _abi
+    spec = E.get(name)
+    s = api.system_from_spec(spec, {"mapping": _abi.MAP_QUAD} if force else None)
+    r = s.options()
+    assert r["mapping"] == _abi.MAP_QUAD and r["lanes_per_trajectory"] == 4, r
+    assert "HAMK_INSTANTIATE_QUAD" in s.source
+    o = oracle_lib.OracleSystem(spec)
+    for B in (1, 5, 67, 300):
+        q, qd = E.sample_config(spec, 31, B)
+        if name.startswith("chain"):
+            qd = 0.3 * np.cos(np.arange(spec.n * B).reshape(spec.n, B) * 0.7)   # the C5 box has qd = 0
+        p = api.momenta(s, api.Config(q, qd))                                   # (wave / lane module)
+        assert relerr(p, o.to_phase_batch(q, qd)) < 1e-12
+        dq, dp = api.hamEqs(s, api.Phase(q, p))
+        odq, odp, ost = o.hameqs_batch(q, p)
+        assert not ost.any() and not np.any(s.last_status)
+        e1 = max(relerr(dq, odq), relerr(dp, odp))
+        assert e1 < 1e-10, (name, B, e1)
+        assert relerr(api.velocities(s, api.Phase(q, p)), o.from_phase_batch(q, p)[0]) < 1e-10
+        oke, ope, oh = o.observe_batch(q, p)
+        assert relerr(api.hamiltonian(s, api.Phase(q, p)), oh) < 1e-10 and relerr(api.keP(s, api.Phase(q, p)), oke) < 1e-10
+        assert relerr(api.pe(s, q), ope) < 1e-12
+        ph = api.rk4Steps(spec.dt, 5, s, api.Phase(q, p))
+        oq, op = o.rk4_steps_batch(q, p, spec.dt, 5)
+        e5 = max(relerr(ph.positions, oq), relerr(ph.momenta, op))
+        assert e5 < 1e-10 and not np.any(s.last_status), (name, B, e5)
+        two = api.rk4Steps(spec.dt, 3, s, api.rk4Steps(spec.dt, 2, s, api.Phase(q, p)))
+        assert np.array_equal(two.positions, ph.positions) and np.array_equal(two.momenta, ph.momenta)   # pure function of the state
+        st = api.stepHam(2 * spec.dt, s, api.Phase(q, p))                        # adaptive stepper: the other module
+        sq, sp, sns = o.step_ham_batch(q, p, 2 * spec.dt)
+        same = np.asarray(s.last_nsub) == sns
+        assert same.mean() >= 0.98 and max(relerr(st.positions[:, same], sq[:, same]), relerr(st.momenta[:, same], sp[:, same])) < 1e-9
+        record(test="quad_vs_oracle", name=name, B=B, hameqs=e1, rk4_5=e5)
+
+
+def test_dense_jacobians_stay_on_the_wave_kernels(api):
+    """The quad mapping needs a sparse Jacobian (every lane keeps one register pair per DISTINCT entry): a dense random
+    coordinate map of the same size is left on the wave-cooperative kernels."""
+    from hamilton_amd import _abi
+    assert api.system_from_spec(E.get("chain24")).options()["mapping"] == _abi.MAP_QUAD
+    import hamilton_amd.examples as EX
+    n, m = 18, 18
+
+    def f(q, o):
+        return [sum((0.1 + 0.05 * ((3 * k + 7 * j) % 11)) * o.sin(q[j] * (1 + 0.1 * k)) for j in range(n)) for k in range(m)]
+    spec = EX.SystemSpec(name="dense18", m=m, n=n, inertia=(1.0,) * m, f=f, u=lambda x, o: x[0] * 0.0 + 1.0 * x[1], u_space=EX.U_CARTESIAN,
+                         q0=(0.1,) * n, qd0=(0.0,) * n, q_box=((-1.0, 1.0),) * n, qd_box=((-1.0, 1.0),) * n)
+    assert api.system_from_spec(spec).options()["mapping"] == _abi.MAP_WAVE
