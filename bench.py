@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--integrator", choices=["rk4", "stepham"], default="rk4",
                     help="rk4: the BASELINE metric (hamk_rk4_steps).  stepham: the reference's own stepper "
                          "(adaptive RKF45, Hamilton.hs:390-402), one stepHam(dt) per launch -- secondary figure")
+    ap.add_argument("--calls-per-launch", type=int, default=1,
+                    help="--integrator stepham: consecutive stepHam(dt) calls fused into one launch (hamk_step_ham_iterate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the all-cores baseline leg")
     ap.add_argument("--no-isa", action="store_true", help="skip the instruction count of the stepping loop (roofline.fp64)")
@@ -265,8 +267,10 @@ def stepham_bench(a, s, spec, dt, state, dist, dev, rank, world):
     """Secondary: the reference's OWN stepper over the ensemble -- stepHam(dt) calls/s (GSL-semantics adaptive RKF45 per
     lane, Hamilton.hs:390-402, :443-448).  One bench step = one launch = one stepHam(dt) of every trajectory."""
     ph = state
+    K = max(1, a.calls_per_launch)
+    step = (lambda x: api.stepHam(dt, s, x, inplace=True)) if K == 1 else (lambda x: api.iterateStepHam(dt, K, s, x, inplace=True))
     for _ in range(a.warmup):
-        ph = api.stepHam(dt, s, ph, inplace=True)
+        ph = step(ph)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     nsub_sum = torch.zeros(ph.positions.shape[1], dtype=torch.int64, device=dev)
@@ -275,11 +279,11 @@ def stepham_bench(a, s, spec, dt, state, dist, dev, rank, world):
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(a.steps):
-        ph = api.stepHam(dt, s, ph, inplace=True)
+        ph = step(ph)
     ev1.record()
     torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    kernel_s = ev0.elapsed_time(ev1) * 1e-3 / max(1, a.steps)
+    el = (time.perf_counter() - t0) / K                      # per stepHam call
+    kernel_s = ev0.elapsed_time(ev1) * 1e-3 / max(1, a.steps) / K
     # divergence: a wavefront runs until its slowest member is done (outside the timed region: one more call, counted)
     probe = api.stepHam(dt, s, api.Phase(ph.positions.clone(), ph.momenta.clone()))
     del probe
@@ -298,6 +302,7 @@ def stepham_bench(a, s, spec, dt, state, dist, dev, rank, world):
                "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
                "data": "synthetic (per-index splitmix64 initial conditions, seed 20241008)",
                "config": {"workload": f"{a.system} (System {spec.m} {spec.n}) ensemble, stepHam dt={dt}", "trajectories_per_gpu": B,
+                          "stepham_calls_per_launch": K,
                           "kernel_path": "wave-cooperative" if lanes > 1 else "one trajectory per lane", "gsl_api": s.gsl_api},
                "mean_substeps": float(nsub.mean()), "max_substeps": float(nsub.max()),
                "rhs_evals_per_s": attempts_per_s * 6,

@@ -1349,9 +1349,17 @@ HAMK_DEV int park_in_vgpr(int x) {
 }
 // scripts/isa_stats.py (rkf45_attempt_stats) brackets one attempt and its right-hand sides in probe builds
 #ifdef HAMK_PROBE_MARK
-#define HAMK_MARK(k) __builtin_amdgcn_s_setprio(k)
+#define HAMK_MARK(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(k); __builtin_amdgcn_sched_barrier(0); } while (0)
+// (pure arithmetic may be moved across a marker by IR-level sinking: the values that enter / leave the bracketed region
+// are passed through an opaque barrier next to it)
+template <int D> HAMK_DEV void probe_pin(double (&x)[D]) {
+#pragma unroll
+  for (int j = 0; j < D; ++j) asm volatile("" : "+v"(x[j]));
+}
+#define HAMK_PIN(x) hamk::probe_pin(x)
 #else
 #define HAMK_MARK(k) ((void)0)
+#define HAMK_PIN(x) ((void)0)
 #endif
 #define HAMK_RKF_FLAGS(row0, inplace, gsl_api) (((row0) & 1) | (((inplace) & 3) << 8) | (((gsl_api) & 3) << 16))
 template <class S>
@@ -1404,6 +1412,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
     while (sgn * (ti - t) > 0.0 && budget > 0 && !failed) {
       ++attempts; --budget;
       HAMK_MARK(1);
+      HAMK_PIN(y); HAMK_PIN(f0);
       const double dt = ti - t;
       double hh = h;
       bool final_step = false;
@@ -1458,7 +1467,9 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
             break;
         }
         HAMK_MARK(3);
+        HAMK_PIN(yt);
         rhs<S, StageTrig<S>::lut ? TRIG_LUT : TRIG_FULL>(yt, out, st, tc);
+        HAMK_PIN(out);
         HAMK_MARK(0);
         switch (sg) {
           case 0:
@@ -1552,6 +1563,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
 #pragma unroll
         for (int j = 0; j < D; ++j) { y[j] = yn[j]; f0[j] = fn[j]; }
       }
+      HAMK_PIN(y); HAMK_PIN(f0);
       HAMK_MARK(2);
     }
     if (sgn * (ti - t) > 0.0 && !failed) st |= ST_MAXSTEPS;

@@ -59,6 +59,13 @@ HAMK_DEV void quad_sync_dev() {
 }
 #define HAMK_QUAD_SYNC() hamk::quad::quad_sync_dev()
 #endif
+// The phases of an evaluation (sweep, panels of the factorisation, back substitution, reverse sweep) must not be
+// interleaved by the machine scheduler: each needs most of the register file for itself, and overlapped they spill.
+#ifdef HAMK_HOST_EMULATION
+#define HAMK_PHASE() ((void)0)
+#else
+#define HAMK_PHASE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 // value of lane SRC of the caller's quad, in all four lanes: two v_mov_b32 with DPP quad_perm [SRC, SRC, SRC, SRC]
 template <int SRC> HAMK_DEV double qbcast(double x) {
@@ -195,10 +202,15 @@ template <class S> struct SinkK {
 
 // LDL^T of the quad's K in registers, the forward substitution of one right-hand side riding along.
 // On return: Kp[i][j], j < 4 i + r: L; dinv[i] = 1 / d_(4 i + r); z[i] = (L^-1 rhs)_(4 i + r).
-// Pivot j lives in lane j % 4, slot j / 4.  Per pivot: d_j and the column below it are broadcast (2 DPP moves per double),
-// every lane scales its own entries of the column and updates its rows up to the diagonal block -- code that is the same for
-// the four lanes: slot i is updated over columns (j, 4 i + 3] whichever row of the slot the lane owns; the entries beyond
-// the lane's diagonal are the symmetric ones and never read.
+// Pivot j lives in lane j % 4, slot j / 4.  Right-looking in PANELS OF FOUR PIVOTS -- one slot of rows, the quad's own
+// granularity: the four pivots of a panel are eliminated one after the other inside the panel's four columns only
+// (d_j and the three or fewer column entries below it broadcast by DPP, every lane scaling its own rows), and the
+// trailing matrix then receives the panel's rank-4 update in ONE pass -- column k's four panel entries broadcast from
+// their owner (8 DPP moves), then four FMAs per entry.  Same flops and the same DPP traffic as pivot-by-pivot, but
+// every trailing entry is read and written n/4 times instead of n: at n = 32 the lane's 144 doubles of K exceed the
+// 256 architectural VGPRs, the rest lives in AGPRs, and each touch of such an entry costs four v_accvgpr moves.
+// The code is the same for the four lanes: slot i is updated over columns up to 4 i + 3 whichever row of the slot the lane
+// owns; the entries beyond the lane's diagonal are the symmetric ones and never read.
 template <class S>
 HAMK_DEV void ldlt(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], double (&dinv)[Geo<S::N>::NR], int& st) {
   constexpr int N = S::N, NR = Geo<N>::NR, NP4 = Geo<N>::NP4;
@@ -206,41 +218,74 @@ HAMK_DEV void ldlt(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&
 #pragma unroll
   for (int i = 0; i < NR; ++i) dinv[i] = 1.0;
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const int sj = j >> 2, rj = j & 3;
-    double d, zj;
-    switch (rj) {                                        // (j is a literal after unrolling: one case survives)
-      case 0: d = qbcast<0>(Kp[sj][j]); zj = qbcast<0>(z[sj]); break;
-      case 1: d = qbcast<1>(Kp[sj][j]); zj = qbcast<1>(z[sj]); break;
-      case 2: d = qbcast<2>(Kp[sj][j]); zj = qbcast<2>(z[sj]); break;
-      default: d = qbcast<3>(Kp[sj][j]); zj = qbcast<3>(z[sj]); break;
-    }
-    ok = ok && (d > 0.0);
-    const double inv = frcp(d);
-    if (r == rj) dinv[sj] = inv;
-    // the lane's multipliers of this pivot, one per slot (0 for rows at or above the pivot: they do not update)
-    double l[NR];
+  for (int jb = 0; jb < NR; ++jb) {
+    HAMK_PHASE();
+    const int J0 = 4 * jb, J1 = (4 * jb + 4 < N) ? 4 * jb + 4 : N;        // this panel's pivots [J0, J1)
+    double l[NR][4];                                     // the lane's multipliers: l[i][jj] = L[4 i + r][J0 + jj]
 #pragma unroll
-    for (int i = sj; i < NR; ++i) l[i] = (4 * i + r > j) ? Kp[i][j] * inv : 0.0;
-    // column k of the trailing matrix: c = K[k][j] from its owner, then every slot that reaches column k
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = J0 + jj;
+      if (j >= J1) {
 #pragma unroll
-    for (int k = j + 1; k < N; ++k) {
-      const int sk = k >> 2;
-      double c;
-      switch (k & 3) {
-        case 0: c = qbcast<0>(Kp[sk][j]); break;
-        case 1: c = qbcast<1>(Kp[sk][j]); break;
-        case 2: c = qbcast<2>(Kp[sk][j]); break;
-        default: c = qbcast<3>(Kp[sk][j]); break;
+        for (int i = 0; i < NR; ++i) l[i][jj] = 0.0;
+        continue;
+      }
+      double d, zj;
+      switch (jj) {                                      // (a literal after unrolling: one case survives)
+        case 0: d = qbcast<0>(Kp[jb][j]); zj = qbcast<0>(z[jb]); break;
+        case 1: d = qbcast<1>(Kp[jb][j]); zj = qbcast<1>(z[jb]); break;
+        case 2: d = qbcast<2>(Kp[jb][j]); zj = qbcast<2>(z[jb]); break;
+        default: d = qbcast<3>(Kp[jb][j]); zj = qbcast<3>(z[jb]); break;
+      }
+      ok = ok && (d > 0.0);
+      const double inv = frcp(d);
+      if (r == jj) dinv[jb] = inv;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) l[i][jj] = (i >= jb && 4 * i + r > j) ? Kp[i][j] * inv : 0.0;
+      // inside the panel: the columns (j, J1) of every row below the pivot
+#pragma unroll
+      for (int k = j + 1; k < J1; ++k) {
+        double c;
+        switch (k & 3) {
+          case 1: c = qbcast<1>(Kp[jb][j]); break;
+          case 2: c = qbcast<2>(Kp[jb][j]); break;
+          default: c = qbcast<3>(Kp[jb][j]); break;
+        }
+#pragma unroll
+        for (int i = jb; i < NR; ++i) Kp[i][k] = fma(-l[i][jj], c, Kp[i][k]);
       }
 #pragma unroll
-      for (int i = sk; i < NR; ++i) Kp[i][k] = fma(-l[i], c, Kp[i][k]);
+      for (int i = jb; i < NR; ++i) z[i] = fma(-l[i][jj], zj, z[i]);
     }
+    // the trailing matrix, one pass: K[a][k] -= sum_jj L[a][J0 + jj] (d L[k][J0 + jj]), k >= J1
 #pragma unroll
-    for (int i = sj; i < NR; ++i) {
-      z[i] = fma(-l[i], zj, z[i]);
-      if (4 * i + 3 > j) Kp[i][j] = (4 * i + r > j) ? l[i] : Kp[i][j];      // L, final (the pivot's own lane keeps d_j)
+    for (int k = J1; k < N; ++k) {
+      const int sk = k >> 2;
+      double c[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        if (J0 + jj >= J1) { c[jj] = 0.0; continue; }
+        switch (k & 3) {
+          case 0: c[jj] = qbcast<0>(Kp[sk][J0 + jj]); break;
+          case 1: c[jj] = qbcast<1>(Kp[sk][J0 + jj]); break;
+          case 2: c[jj] = qbcast<2>(Kp[sk][J0 + jj]); break;
+          default: c[jj] = qbcast<3>(Kp[sk][J0 + jj]); break;
+        }
+      }
+#pragma unroll
+      for (int i = sk; i < NR; ++i) {
+        double t = Kp[i][k];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) t = fma(-l[i][jj], c[jj], t);
+        Kp[i][k] = t;
+      }
     }
+    // L of the panel, final (rows at or above a pivot keep what they hold: the pivot's own lane keeps d_j)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int i = jb; i < NR; ++i)
+        if (J0 + jj < J1) Kp[i][J0 + jj] = (4 * i + r > J0 + jj) ? l[i][jj] : Kp[i][J0 + jj];
   }
   if (!ok) st |= ST_SINGULAR;                            // no pivoting fallback (as in the wave kernels)
 }
@@ -257,6 +302,7 @@ HAMK_DEV void solve_back(int r, const double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4
   for (int a = 0; a < NP4; ++a) s[a] = 0.0;
 #pragma unroll
   for (int i = NR - 1; i >= 0; --i) {
+    HAMK_PHASE();
     const double w = z[i] * dinv[i];
     double vi = 0.0;
 #pragma unroll
@@ -321,14 +367,18 @@ HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const
   TrigCache<S::NTRIG_U> tu;
   const Jet1<N> u = S::template coords_sink_u<Jet1<N>, Trig<S, LUT>::mode1>(in, tc, tu, sink);
   sink.pad();
+  HAMK_PHASE();
   U = u.v;
 #pragma unroll
   for (int i = 0; i < NR; ++i) gUi[i] = sel4(r, dget<N>(u.d, 4 * i), dget<N>(u.d, 4 * i + 1), dget<N>(u.d, 4 * i + 2), dget<N>(u.d, 4 * i + 3));
   double z[NR], dinv[NR];
 #pragma unroll
   for (int i = 0; i < NR; ++i) z[i] = pi[i];
+  HAMK_PHASE();
   ldlt<S>(r, sink.acc, z, dinv, st);
+  HAMK_PHASE();
   solve_back<S>(r, sink.acc, z, dinv, vi);
+  HAMK_PHASE();
 }
 
 // hamEqs for the quad's trajectory: the lane returns (dq, dp) of its coordinates.         Hamilton.hs:370-387
@@ -416,7 +466,7 @@ template <class S, bool LUT> HAMK_DEV double energy(const Ctx<S>& c0, const doub
 }
 
 template <class S>
-HAMK_DEV void rk4_body(double* smem, double* q, double* p, i64 B, double dt, int nsteps, double drift_tol, int* status) {
+HAMK_DEV void rk4_body(double* smem, double* park, double* q, double* p, i64 B, double dt, int nsteps, double drift_tol, int* status) {
   constexpr int N = S::N, NR = Geo<N>::NR;
   constexpr bool LUT = StageTrig<S>::lut;                 // the stepping kernel loads the sincos table (hamk_device.hpp)
   if constexpr (LUT) lut_load();
@@ -427,9 +477,17 @@ HAMK_DEV void rk4_body(double* smem, double* q, double* p, i64 B, double dt, int
   double H0 = 0.0;
   if (drift_tol > 0.0) H0 = energy<S, LUT>(w.c, yq, yp, st);
   const double h2 = 0.5 * dt, h6 = dt * (1.0 / 6.0), h3 = dt * (1.0 / 3.0);
-  double kq[NR], kp[NR], aq[NR], ap[NR];
+  // The step's base point y and the running combination wait in LDS while a right-hand side runs ([component][lane],
+  // conflict-free; 4 x NR x 2 KiB per block): the lane's quarter of K alone is more than the 256 architectural VGPRs at
+  // n = 32, and what the compiler cannot keep it sends to scratch -- through the vector memory pipe, with one wavefront
+  // per SIMD to hide it.
+  double* py = park + threadIdx.x;                          // yq[i] at py[i * 256], yp[i] at py[(NR + i) * 256]
+  double* pa = park + 2 * NR * 256 + threadIdx.x;           // the same for the combination
 #pragma unroll
-  for (int i = 0; i < NR; ++i) { kq[i] = 0.0; kp[i] = 0.0; aq[i] = yq[i]; ap[i] = yp[i]; }
+  for (int i = 0; i < NR; ++i) { py[i * 256] = yq[i]; py[(NR + i) * 256] = yp[i]; pa[i * 256] = yq[i]; pa[(NR + i) * 256] = yp[i]; }
+  double kq[NR], kp[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) { kq[i] = 0.0; kp[i] = 0.0; }
 #pragma unroll 1
   for (int it = 0; it < 4 * nsteps; ++it) {
     const int sg = it & 3;
@@ -437,15 +495,27 @@ HAMK_DEV void rk4_body(double* smem, double* q, double* p, i64 B, double dt, int
     const double b = (sg == 0 || sg == 3) ? h6 : h3;
     double tq[NR], tp[NR];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) { tq[i] = fma(a, kq[i], yq[i]); tp[i] = fma(a, kp[i], yp[i]); }
+    for (int i = 0; i < NR; ++i) { tq[i] = fma(a, kq[i], py[i * 256]); tp[i] = fma(a, kp[i], py[(NR + i) * 256]); }
+#ifndef HAMK_HOST_EMULATION
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     ham_eqs<S, LUT>(w.c, tq, tp, kq, kp, st);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) { aq[i] = fma(b, kq[i], aq[i]); ap[i] = fma(b, kp[i], ap[i]); }
+#ifndef HAMK_HOST_EMULATION
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (sg == 3) {
 #pragma unroll
-      for (int i = 0; i < NR; ++i) { yq[i] = aq[i]; yp[i] = ap[i]; }
+      for (int i = 0; i < NR; ++i) {
+        const double vq = fma(b, kq[i], pa[i * 256]), vp = fma(b, kp[i], pa[(NR + i) * 256]);
+        pa[i * 256] = vq; py[i * 256] = vq; pa[(NR + i) * 256] = vp; py[(NR + i) * 256] = vp;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) { pa[i * 256] = fma(b, kq[i], pa[i * 256]); pa[(NR + i) * 256] = fma(b, kp[i], pa[(NR + i) * 256]); }
     }
   }
+#pragma unroll
+  for (int i = 0; i < NR; ++i) { yq[i] = py[i * 256]; yp[i] = py[(NR + i) * 256]; }
   if (drift_tol > 0.0) {
     int st1 = 0;
     const double H1 = energy<S, LUT>(w.c, yq, yp, st1);
@@ -526,7 +596,8 @@ HAMK_DEV void observe_body(double* smem, const double* q, const double* p, doubl
   extern "C" __global__ void __launch_bounds__(256) hamk_rk4_steps_k(double* q, double* p, long long B,          \
                                                           double dt, int nsteps, double drift_tol, int* status) { \
     HAMK_QUAD_SMEM(S);                                                                                           \
-    hamk::quad::rk4_body<S>(smem, q, p, B, dt, nsteps, drift_tol, status);                                       \
+    __shared__ double park[4 * hamk::quad::Geo<S::N>::NR * 256];                                                 \
+    hamk::quad::rk4_body<S>(smem, park, q, p, B, dt, nsteps, drift_tol, status);                                 \
   }                                                                                                              \
   extern "C" __global__ void __launch_bounds__(256) hamk_hameqs_k(const double* q, const double* p, double* dq,  \
                                                                    double* dp, long long B, int* status) {       \

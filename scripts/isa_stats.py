@@ -263,11 +263,31 @@ def rkf45_attempt_stats(spec, system=None):
             where.setdefault(int(ops.split()[0]), []).append(i)
     if 1 not in where or 2 not in where:
         return None
-    lo, hi = min(where[1]), max(where[2])
-    rhs_spans = list(zip(sorted(where.get(3, [])), sorted(where.get(0, []))))
-    in_rhs = lambda i: any(a <= i <= b for a, b in rhs_spans)
-    once = collections.Counter(classify(mn) for i, (_, mn, _) in enumerate(ins[lo:hi + 1], lo) if not in_rhs(i))
-    rhs = collections.Counter(classify(mn) for i, (_, mn, _) in enumerate(ins[lo:hi + 1], lo) if in_rhs(i))
+    addr_index = {a: i for i, (a, _, _) in enumerate(ins)}
+    back = []                                               # (head, branch) of every backward branch
+    for i, (a, mn, ops) in enumerate(ins):
+        if mn.startswith(("s_cbranch", "s_branch")):
+            m2 = re.search(r"\+0x([0-9a-f]+)>", ops)
+            tgt = addr_index.get(ins[0][0] + int(m2.group(1), 16)) if m2 else None
+            if tgt is not None and tgt <= i:
+                back.append((tgt, i))
+
+    def region(begin, end):
+        """Indices executed from marker `begin` to marker `end`.  When the loop that holds them is laid out rotated (its
+        last marker first) the path runs on to the loop's back edge and continues from the loop's head."""
+        if begin <= end:
+            return set(range(begin, end + 1))
+        holds = [(hi - lo, lo, hi) for lo, hi in back if lo <= end and hi >= begin]
+        if not holds:
+            return set()
+        _, lo, hi = min(holds)
+        return set(range(begin, hi + 1)) | set(range(lo, end + 1))
+
+    body = region(min(where[1]), max(where[2]))
+    rhs_idx = region(min(where[3]), max(where[0])) if (3 in where and 0 in where) else set()
+    once = collections.Counter(classify(ins[i][1]) for i in body if i not in rhs_idx)
+    rhs = collections.Counter(classify(ins[i][1]) for i in rhs_idx)
+    rhs_spans = bool(rhs_idx)
     tot = collections.Counter()
     for k, v in once.items():
         tot[k] += v

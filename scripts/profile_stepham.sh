@@ -1,0 +1,21 @@
+#!/bin/bash
+# GPU box: rocprofv3 passes for the reference's own stepper (hamk_rkf45_k, bench.py --integrator stepham).
+# usage: scripts/profile_stepham.sh <tag> <system> [bench args...]; results in gpurun_out/prof_<tag>_<system>_stepham/
+set -u
+TAG=${1:-r03}
+SYS=${2:-doublePendulum}
+shift 2 2>/dev/null
+EXTRA="$@"
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_${TAG}_${SYS}_stepham
+mkdir -p $OUT
+export TMPDIR=/tmp
+export HAMK_SELFCHECK=0
+cd /tmp
+B="python $R/bench.py --system $SYS --integrator stepham --no-cpu-baseline $EXTRA"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $B --steps 20 --warmup 3 > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o $TAG -- $B --no-isa --steps 3 --warmup 1 > $OUT/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $TAG -- $B --no-isa --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o $TAG -- $B --no-isa --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
+grep -h '"metric"' $OUT/stats.log | tail -1 > $OUT/bench_under_profiler.json
+ls $OUT

@@ -11,7 +11,8 @@ dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 KERNEL = sys.argv[3] if len(sys.argv) > 3 else "hamk_rk4_steps_k"
 
-shutil.copy(os.path.join(src, "stats", f"{tag}_kernel_stats.csv"), os.path.join(dst, f"{tag}_{system}_kernel_stats.csv"))
+suffix = "" if KERNEL == "hamk_rk4_steps_k" else "_stepham"
+shutil.copy(os.path.join(src, "stats", f"{tag}_kernel_stats.csv"), os.path.join(dst, f"{tag}_{system}{suffix}_kernel_stats.csv"))
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "stats", f"{tag}_kernel_stats.csv")))}
 summary = {"system": system, "kernel": KERNEL,
            "rocprofv3_kernel_stats": {k: stats[KERNEL][k] for k in ("Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")}}
@@ -40,17 +41,18 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds", "pmc_mfma"):
         summary["dispatch"] = {k: meta[k] for k in ("Grid_Size", "Workgroup_Size", "VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size")}
 summary["pmc_mean_per_launch"] = pmc
 B = bench["config"]["trajectories_per_gpu"] if bench else None
-K = bench["config"]["rk4_steps_per_launch"] if bench else None
+K = bench["config"].get("rk4_steps_per_launch") if bench else None
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and bench:
     # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE counts 128-B requests at 64 B
     # (MI355X_MICROARCH.md "HBM"): doubled.  The kernel reads 16 n B and writes 16 n B + 4 B (status)
     # per trajectory per launch.
-    n = int(bench["roofline"]["algorithmic_bytes_per_trajectory_step"] / 32)
+    n = int(bench["roofline"].get("algorithmic_bytes_per_trajectory_step", bench["roofline"].get("algorithmic_bytes_per_launch", 0) / max(1, B)) / 32)
     fetch = pmc["FETCH_SIZE"] * 1024 * 2
     write = pmc["WRITE_SIZE"] * 1024
     summary["hbm"] = {"fetch_bytes_corrected_x2": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
                       "expected_read_bytes": 16 * n * B, "expected_write_bytes": 16 * n * B + 4 * B}
-    json.dump({"system": system, "trajectories": B, "rk4_steps_per_launch": K,
+    if KERNEL == "hamk_rk4_steps_k":
+      json.dump({"system": system, "trajectories": B, "rk4_steps_per_launch": K,
                "hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
                "source": f"profiles/{tag}_{system}_summary.json: rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) / WRITE_SIZE, separate passes"},
               open(os.path.join(dst, f"pmc_traffic_{system}.json"), "w"), indent=1)
@@ -72,5 +74,7 @@ if "SQ_LDS_IDX_ACTIVE" in pmc and "GRBM_GUI_ACTIVE" in pmc:
         summary["lds_bank_conflict_frac_of_lds_cycles"] = pmc["SQ_LDS_BANK_CONFLICT"] / max(1.0, pmc["SQ_LDS_IDX_ACTIVE"])
 if "SQ_INSTS_LDS" in pmc and "SQ_WAVES" in pmc and K:
     summary["lds_insts_per_wave_per_rk4_step"] = pmc["SQ_INSTS_LDS"] / pmc["SQ_WAVES"] / K
-json.dump(summary, open(os.path.join(dst, f"{tag}_{system}_summary.json"), "w"), indent=1)
+if KERNEL != "hamk_rk4_steps_k" and "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc:
+    summary["valu_insts_per_wave_per_launch"] = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"]
+json.dump(summary, open(os.path.join(dst, f"{tag}_{system}{suffix}_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -33,7 +33,11 @@ def measure(args):
     for name in names:
         spec = examples.get(name)
         maps = [("lane", _abi.MAP_LANE)] if spec.n <= 16 else []
-        maps.append(("wave", _abi.MAP_WAVE))
+        if spec.n <= 32 and spec.n >= 4 and "quad" in args.mappings:
+            maps.append(("quad", _abi.MAP_QUAD))
+        if "wave" in args.mappings:
+            maps.append(("wave", _abi.MAP_WAVE))
+        maps = [m for m in maps if m[0] in args.mappings]
         top = max(CONFIG_B.get(name, 1 << 16), 1 << 16)
         for label, mp in maps:
             if label == "wave" and spec.n <= 3:
@@ -108,6 +112,7 @@ if __name__ == "__main__":
     ap.add_argument("--systems", default="threeBodyPolar,chain8,chain16,chain32,spring")
     ap.add_argument("--launch-ms", type=float, default=40.0)
     ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--mappings", default="lane,quad,wave")
     ap.add_argument("--predict", default=None)
     a = ap.parse_args()
     if a.predict:

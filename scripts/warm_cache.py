@@ -73,6 +73,8 @@ def build(job):
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             import isa_stats
             isa_stats.rk4_step_stats(spec, s)
+            if name in ("doublePendulum", "spring", "threeBodyPolar", "twoBody"):
+                isa_stats.rkf45_attempt_stats(spec, s)      # bench.py --integrator stepham
         return name, env, s.code_size
     except Exception as e:          # a job that cannot be built here is simply not cached
         return name, env, repr(e)[:200]

@@ -73,11 +73,11 @@ def test_wave_path_vs_oracle(api, oracle_lib, monkeypatch, name, force):
 def test_flat_and_panel_factorisation_agree(api, oracle_lib, monkeypatch):
     """n > 16: LDL^T in panels of 16 with the trailing blocks on the matrix cores (default) against the flat
     column-broadcast factorisation it replaced (HAMK_WAVE_BLOCKED=0) and the oracle."""
+    from hamilton_amd import _abi
     spec = E.get("chain32")
-    panel = api.system_from_spec(spec)
+    panel = api.system_from_spec(spec, {"mapping": _abi.MAP_WAVE})
     assert "#define HAMK_WAVE_BLOCKED 1" in panel.source
-    monkeypatch.setenv("HAMK_WAVE_BLOCKED", "0")
-    flat = api.system_from_spec(spec)
+    flat = api.system_from_spec(spec, {"mapping": _abi.MAP_WAVE, "wave_blocked": _abi.OFF})
     assert "#define HAMK_WAVE_BLOCKED 1" not in flat.source
     o = oracle_lib.OracleSystem(spec)
     B = 70
