@@ -925,10 +925,17 @@ static int check_call(hamk_system* s, int64_t B, int32_t mem) {
 // ---------------------------------------------------------------------------
 // options -> specialisations
 // ---------------------------------------------------------------------------
-// Ensemble size below which the wave-cooperative kernels beat the lane kernels (0: never), by n.
-static int64_t lane_wave_crossover(int n) {
-  (void)n;
-  return 0;                                                 // (set from profiles/r03_throughput_vs_B.jsonl)
+// Ensemble size below which a lane-kernel system (n <= 16) runs four lanes per trajectory instead (0: never).
+// One trajectory per lane does the least work per trajectory but puts 64 of them in a wavefront: 65 536 trajectories are
+// 1024 wavefronts -- one per SIMD -- and every halving of the ensemble idles half the chip, while the quad kernels spread
+// the same trajectories over four times the wavefronts.  Measured on MI355X (profiles/r03_throughput_vs_B.jsonl,
+// r03_throughput_vs_B_quad.jsonl; RK4 steps/s):
+//     chain16   B = 8192: lane 2.85e8, quad 4.76e8, wave 2.28e8    16384: 5.67e8 / 9.48e8 / 2.42e8    32768: 1.13e9 / 9.5e8
+//     chain8    B = 8192: lane 1.23e9, quad 1.12e9, wave 4.8e8     16384: 2.45e9 / 2.22e9             (lane throughout)
+//     threeBodyPolar (n = 6): lane 2.1e9 at 8192 against quad 1.15e9 (lane throughout)
+// The wave-cooperative kernels never win at n <= 16 for B >= 8192.
+static int64_t quad_below(int n) {
+  return n >= 13 ? 32768 : 0;
 }
 
 static bool env_flag(const char* name, bool* value) {           // "0" / "1" test overrides
@@ -960,7 +967,7 @@ static std::string check_options(const hamk_options& o, int n) {
 // The lane kernels do the least work per trajectory (compile-time sparsity of the seeds, everything in registers) but
 // put 64 trajectories in a wavefront: below ~64 x 1024 SIMDs trajectories they leave SIMDs idle, and for the systems
 // whose lane kernel is large the wave-cooperative kernels (4 trajectories per wavefront at n <= 16) then win.
-// Thresholds measured on MI355X (scripts/sweep_batch.py -> profiles/r03_throughput_vs_B.jsonl).
+// Thresholds measured on MI355X (scripts/sweep_batch.py -> profiles/r03_throughput_vs_B*.jsonl).
 // The quad module (hamk_quad.hpp) provides the kernels of the hot path; the rest of a system's entry points run on the
 // module that serves its size otherwise.
 static bool quad_has(int kernel) { return kernel == K_RK4 || kernel == K_HAMEQS || kernel == K_FROM_PHASE || kernel == K_OBSERVE || kernel == K_SCRIBBLE; }
@@ -982,10 +989,10 @@ static int choose_mapping(hamk_system* s, int64_t B, int kernel) {
   if (env_flag("HAMK_WAVE", &w)) return (w || n > 16) ? HAMK_MAP_WAVE : HAMK_MAP_LANE;
   if (n > 32) return HAMK_MAP_WAVE;
   if (n > 16) return (!no_quad && quad_has(kernel) && quad_eligible(s)) ? HAMK_MAP_QUAD : HAMK_MAP_WAVE;
-  int64_t below = 0;                                        // ensembles smaller than this leave the lane kernels
-  if (const char* e = std::getenv("HAMK_WAVE_BELOW")) below = std::atoll(e);                // experiments: the crossover itself
-  else below = lane_wave_crossover(n);
-  return (B < below) ? HAMK_MAP_WAVE : HAMK_MAP_LANE;
+  int64_t below = quad_below(n);                            // ensembles smaller than this leave the lane kernels
+  if (const char* e = std::getenv("HAMK_QUAD_BELOW")) below = std::atoll(e);                // experiments: the crossover itself
+  if (B < below && !no_quad && quad_eligible(s)) return quad_has(kernel) ? HAMK_MAP_QUAD : HAMK_MAP_LANE;
+  return HAMK_MAP_LANE;
 }
 
 static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4, bool* forced_rkf) {

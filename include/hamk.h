@@ -177,7 +177,9 @@ typedef struct hamk_system hamk_system;   /* opaque */
 typedef struct hamk_options {
   uint32_t size;           /* sizeof(hamk_options) as the caller's header has it (hamk_options_init sets it)           */
   int32_t mapping;         /* HAMK_MAP_*; AUTO: chosen PER LAUNCH from (n, ensemble size B): a small ensemble of a
-                              mid-size system cannot fill the chip with one trajectory per lane                         */
+                              mid-size system cannot fill the chip with one trajectory per lane.  Two mappings agree to
+                              roundoff, not bitwise: pin the mapping where results must not depend on how an ensemble
+                              is split into launches (hamk_system_get_options tells what AUTO picks for a size)         */
   int32_t ad_mode;         /* HAMK_AD_*                                                                                 */
   int32_t rk4_body;        /* HAMK_BODY_*                                                                               */
   int32_t rkf_body;        /* HAMK_BODY_*                                                                               */

@@ -2,6 +2,8 @@
 # Builds the reproducer twice -- with the options libhamk gives hiprtc, and with MachineLICM disabled --
 # prints each build's spill counts for hamk_rkf45_k and runs both (needs an MI355X for the runs).
 cd "$(dirname "$0")"
+# the frozen round-1 device library travels compressed (it is a reproducer input, not a component)
+[ -f hamk_device_r01.hpp ] || xz -dk hamk_device_r01.hpp.xz
 OPTS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -fno-honor-nans -fno-signed-zeros"
 for v in default nolicm; do
   EXTRA=""; [ $v = nolicm ] && EXTRA="-mllvm -disable-machine-licm"

@@ -11,7 +11,7 @@ dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 KERNEL = sys.argv[3] if len(sys.argv) > 3 else "hamk_rk4_steps_k"
 
-suffix = "" if KERNEL == "hamk_rk4_steps_k" else "_stepham"
+suffix = "" if (KERNEL == "hamk_rk4_steps_k" or system.endswith("_stepham")) else "_stepham"
 shutil.copy(os.path.join(src, "stats", f"{tag}_kernel_stats.csv"), os.path.join(dst, f"{tag}_{system}{suffix}_kernel_stats.csv"))
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "stats", f"{tag}_kernel_stats.csv")))}
 summary = {"system": system, "kernel": KERNEL,

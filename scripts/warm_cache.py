@@ -50,6 +50,7 @@ def jobs():
         out.append((n, {"HAMK_QUAD": "1"}, False))
     for n in ("chain12", "chain16"):
         out.append((n, {"HAMK_RK4_PARK": "0"}, False))
+    out.append(("chain32", {"HAMK_HIPRTC_FLAGS": "-DHAMK_QUAD_LEFT=0"}, True))      # right-looking LDL^T on the whole K (A/B)
     return out
 
 

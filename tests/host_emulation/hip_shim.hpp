@@ -32,5 +32,6 @@ static inline double __longlong_as_double(long long b) { double x; std::memcpy(&
 static inline long long __double_as_longlong(double x) { long long b; std::memcpy(&b, &x, 8); return b; }
 static inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))
+#define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt(x))
 #define __builtin_amdgcn_logf(x) ::log2f(x)
 #define __builtin_amdgcn_exp2f(x) ::exp2f(x)

@@ -115,7 +115,10 @@ ORACLE_BOUNDS = {"C3-twoBody": (1e-11, 1e-9), "C3-spring": (1e-11, 1e-9), "C4-th
 def test_full_size(api, oracle_lib, cid, name, B, nsteps, nsample, DRIFT_TOL):
     import torch
     spec = E.get(name)
-    s = api.system_from_spec(spec)
+    # the specialisation the library picks for THIS ensemble size, pinned: with mapping = HAMK_AUTO the choice is made per
+    # launch from (n, B), and two mappings agree to roundoff, not bitwise -- the shard-invariance check below compares a
+    # sub-range with the full run bit for bit
+    s = api.system_from_spec(spec, {"mapping": api.system_from_spec(spec).options(B)["mapping"]})
     o = oracle_lib.OracleSystem(spec)
     dt = spec.dt
     q, qd = E.sample_config(spec, 0, B)
@@ -488,3 +491,35 @@ def test_iterate_on_device_ensembles(api, oracle_lib, monkeypatch, name, force_w
     e = max(relerr(b.positions[:, idx].cpu().numpy(), oq), relerr(b.momenta[:, idx].cpu().numpy(), op))
     record(test="iterate_device", name=name, wave=force_wave, err=e)
     assert e < 1e-8, (name, e)
+
+
+# ---------------------------------------------------------------------------------------------
+# the mapping is chosen per launch from (n, B): what a GPU of an 8-way shard of config 5 runs
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["chain8", "chain16"])
+def test_the_kernel_chosen_for_a_small_shard_is_oracle_exact(api, oracle_lib, name):
+    """BASELINE configs 3 / 4 shard a FIXED ensemble over up to 8 GPUs: 65 536 / 8 = 8 192 trajectories per GPU of the C5
+    chains.  The library then leaves the one-trajectory-per-lane kernels where the measurement says so (chain16: four
+    lanes per trajectory below 32 768; chain8: lane throughout -- hamk_api.cpp quad_below); whatever it picks must be
+    oracle-exact at that size, and the same handle serves both sizes."""
+    import torch
+    from hamilton_amd import _abi
+    spec = E.get(name)
+    s = api.system_from_spec(spec)
+    o = oracle_lib.OracleSystem(spec)
+    big, small = s.options(65536), s.options(8192)
+    assert big["mapping"] == _abi.MAP_LANE
+    assert small["mapping"] == (_abi.MAP_QUAD if name == "chain16" else _abi.MAP_LANE), small
+    for B in (8192, 65536):
+        q, qd = E.sample_config(spec, 0, B)
+        ph0 = api.toPhase(s, api.Config(torch.from_numpy(q).cuda(), torch.from_numpy(qd).cuda()))
+        ph = api.rk4Steps(spec.dt, 20, s, ph0, drift_tol=1e-3)
+        assert int(torch.count_nonzero(s.last_status & ~16)) == 0
+        idx = np.arange(0, B, B // 64)[:64]
+        oq, op = o.rk4_steps_batch(ph0.positions[:, idx].cpu().numpy(), ph0.momenta[:, idx].cpu().numpy(), spec.dt, 20)
+        e = max(relerr(ph.positions[:, idx].cpu().numpy(), oq), relerr(ph.momenta[:, idx].cpu().numpy(), op))
+        dq, dp = api.hamEqs(s, ph0)
+        odq, odp, _ = o.hameqs_batch(ph0.positions[:, idx].cpu().numpy(), ph0.momenta[:, idx].cpu().numpy())
+        e2 = max(relerr(dq[:, idx].cpu().numpy(), odq), relerr(dp[:, idx].cpu().numpy(), odp))
+        record(test="small_shard", name=name, B=B, mapping=s.options(B)["mapping"], rk4_20=e, hameqs=e2)
+        assert e < 1e-11 and e2 < 1e-11, (name, B, e, e2)
