@@ -968,9 +968,9 @@ static std::string check_options(const hamk_options& o, int n) {
 // put 64 trajectories in a wavefront: below ~64 x 1024 SIMDs trajectories they leave SIMDs idle, and for the systems
 // whose lane kernel is large the wave-cooperative kernels (4 trajectories per wavefront at n <= 16) then win.
 // Thresholds measured on MI355X (scripts/sweep_batch.py -> profiles/r03_throughput_vs_B*.jsonl).
-// The quad module (hamk_quad.hpp) provides the kernels of the hot path; the rest of a system's entry points run on the
-// module that serves its size otherwise.
-static bool quad_has(int kernel) { return kernel == K_RK4 || kernel == K_HAMEQS || kernel == K_FROM_PHASE || kernel == K_OBSERVE || kernel == K_SCRIBBLE; }
+// Which kernels the quad module (hamk_quad.hpp) provides: all eight since the second half of round 3.  The per-kernel
+// dispatch stays: a module that lacks a kernel leaves it to the module that serves the system's size otherwise.
+static bool quad_has(int kernel) { (void)kernel; return true; }      // (the first version provided the four kernels of the hot path only)
 
 // Can a lane run the per-trajectory first-order sweep of this system with compile-time seeds?  It keeps one register pair
 // per DISTINCT entry of the Jacobian (hamk_codegen.cpp distinct_jacobian_entries): 2n for a chain, m n for a dense map.

@@ -461,6 +461,7 @@ std::string generate_source(const SystemDesc& d) {
   std::ostringstream o;
   o << "// generated by libhamk (hamk_codegen.cpp) from the expression tape of one System " << d.m << " " << d.n << "\n";
   if (d.rk4_min_waves > 1) o << "#define HAMK_RK4_MIN_WAVES " << d.rk4_min_waves << "\n#define HAMK_RK4_MIN_WAVES_BIG " << d.rk4_min_waves << "\n";
+  if (d.wave && d.n > 32 && d.rk4_min_waves > 1) o << "#define HAMK_RKF_MIN_WAVES " << d.rk4_min_waves << "\n";
   o << "#define HAMK_USE_LUT " << d.use_lut << "\n";
   o << "#define HAMK_K_REASSOC " << (d.k_reassoc ? 1 : 0) << "\n";
   if (d.rk4_park && !d.wave) o << "#define HAMK_RK4_PARK 1\n";

@@ -25,8 +25,8 @@
 // LDS holds only what the four lanes share of the state: q, qd and the sincos pairs of the trajectory, [row][64
 // trajectories of the block] -- 64 KiB per 256-thread block at n = 32 -- read with immediate offsets from one base.
 //
-// Kernels provided: hamk_rk4_steps_k, hamk_hameqs_k, hamk_from_phase_k, hamk_observe_k.  The other entry points of a
-// system keep running on its wave-cooperative module (hamk_api.cpp dispatches per kernel).
+// All eight kernels of the path are provided (round 3, second half: the first version had the four of the hot path and left
+// the rest to the system's wave-cooperative module).
 #pragma once
 #include "hamk_device.hpp"
 
@@ -202,7 +202,7 @@ template <class S> struct SinkK {
 };
 
 // LDL^T of the quad's K in registers, the forward substitution of one right-hand side riding along.
-// On return: Kp[i][j], j < 4 i + r: L; dinv[i] = 1 / d_(4 i + r); z[i] = (L^-1 rhs)_(4 i + r).
+// On return: Kp[i][j], j < 4 i + r: L; Kp[i][4 i + r] = 1 / d_(4 i + r); z[i] = (L^-1 rhs)_(4 i + r).
 // Pivot j lives in lane j % 4, slot j / 4.  Right-looking in PANELS OF FOUR PIVOTS -- one slot of rows, the quad's own
 // granularity: the four pivots of a panel are eliminated one after the other inside the panel's four columns only
 // (d_j and the three or fewer column entries below it broadcast by DPP, every lane scaling its own rows), and the
@@ -213,16 +213,15 @@ template <class S> struct SinkK {
 // The code is the same for the four lanes: slot i is updated over columns up to 4 i + 3 whichever row of the slot the lane
 // owns; the entries beyond the lane's diagonal are the symmetric ones and never read.
 template <class S>
-HAMK_DEV void ldlt(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], double (&dinv)[Geo<S::N>::NR], int& st) {
+HAMK_DEV void ldlt(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], int& st) {
   constexpr int N = S::N, NR = Geo<N>::NR, NP4 = Geo<N>::NP4;
   bool ok = true;
-#pragma unroll
-  for (int i = 0; i < NR; ++i) dinv[i] = 1.0;
 #pragma unroll
   for (int jb = 0; jb < NR; ++jb) {
     HAMK_PHASE();
     const int J0 = 4 * jb, J1 = (4 * jb + 4 < N) ? 4 * jb + 4 : N;        // this panel's pivots [J0, J1)
     double l[NR][4];                                     // the lane's multipliers: l[i][jj] = L[4 i + r][J0 + jj]
+    double pinv[4] = {1.0, 1.0, 1.0, 1.0};               // 1 / d of the panel's pivots
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = J0 + jj;
@@ -240,7 +239,7 @@ HAMK_DEV void ldlt(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&
       }
       ok = ok && (d > 0.0);
       const double inv = frcp(d);
-      if (r == jj) dinv[jb] = inv;
+      pinv[jj] = inv;
 #pragma unroll
       for (int i = 0; i < NR; ++i) l[i][jj] = (i >= jb && 4 * i + r > j) ? Kp[i][j] * inv : 0.0;
       // inside the panel: the columns (j, J1) of every row below the pivot
@@ -286,7 +285,7 @@ HAMK_DEV void ldlt(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&
     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
       for (int i = jb; i < NR; ++i)
-        if (J0 + jj < J1) Kp[i][J0 + jj] = (4 * i + r > J0 + jj) ? l[i][jj] : Kp[i][J0 + jj];
+        if (J0 + jj < J1) Kp[i][J0 + jj] = (4 * i + r > J0 + jj) ? l[i][jj] : ((i == jb && r == jj) ? pinv[jj] : Kp[i][J0 + jj]);
   }
   if (!ok) st |= ST_SINGULAR;                            // no pivoting fallback (as in the wave kernels)
 }
@@ -295,8 +294,7 @@ HAMK_DEV void ldlt(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&
 // accumulate partial sums s[a] = sum over their own solved rows k > a of L[k][a] v_k and the four partial sums meet in a
 // quad reduction when v_a is due.
 template <class S>
-HAMK_DEV void solve_back(int r, const double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], const double (&z)[Geo<S::N>::NR],
-                         const double (&dinv)[Geo<S::N>::NR], double (&v)[Geo<S::N>::NR]) {
+HAMK_DEV void solve_back(int r, const double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], const double (&z)[Geo<S::N>::NR], double (&v)[Geo<S::N>::NR]) {
   constexpr int N = S::N, NR = Geo<N>::NR, NP4 = Geo<N>::NP4;
   double s[NP4];
 #pragma unroll
@@ -304,13 +302,12 @@ HAMK_DEV void solve_back(int r, const double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4
 #pragma unroll
   for (int i = NR - 1; i >= 0; --i) {
     HAMK_PHASE();
-    const double w = z[i] * dinv[i];
     double vi = 0.0;
 #pragma unroll
     for (int rr = 3; rr >= 0; --rr) {
       const int a = 4 * i + rr;
       if (a >= N) continue;
-      const double va = w - qsum(s[a]);                  // meaningful in lane rr
+      const double va = fma(z[i], Kp[i][a], -qsum(s[a]));   // meaningful in lane rr, whose Kp[i][a] is 1 / d_a
       if (r == rr) vi = va;
       // row a's entries inside the diagonal block feed the rows of the same slot still to come
 #pragma unroll
@@ -383,7 +380,10 @@ HAMK_DEV void panel(const Ctx<S>& c0, TC& tc, double (&G)[Geo<S::N>::NR][Geo<S::
   // G[i][4 i + r] (the lane's diagonal entry) holds 1 / G_aa -- what both substitutions divide by -- instead of G_aa.
   constexpr int N = S::N, NR = Geo<N>::NR, J0 = 4 * JB, J1 = (J0 + 4 < N) ? J0 + 4 : N;
   HAMK_PHASE();
-  const Ctx<S> c = c0.launder();            // fresh addresses per panel: what a sweep needs of q and the sincos pairs is re-read
+#ifndef HAMK_QUAD_LAUNDER_EVERY
+#define HAMK_QUAD_LAUNDER_EVERY 1
+#endif
+  const Ctx<S> c = (JB % HAMK_QUAD_LAUNDER_EVERY == 0) ? c0.launder() : c0;   // fresh addresses per panel: what a sweep needs of q and the sincos pairs is re-read
   const int r = c.r;                        // from LDS instead of all 2n pairs being kept in registers across the factorisation
   SinkPanel<S, JB> sink;
   sink.init(r);
@@ -502,12 +502,11 @@ HAMK_DEV void solve_back_chol(int r, const double (&G)[Geo<S::N>::NR][Geo<S::N>:
   }
 }
 
-// Shared first half of every evaluation: q to LDS, sincos pairs, K and its factorisation with the forward substitution
-// of p, back substitution.  Returns the lane's velocities; gU (own rows), U.
-template <class S, bool LUT, class TC>
-HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const double (&pi)[Geo<S::N>::NR],
-                       double (&vi)[Geo<S::N>::NR], double (&gUi)[Geo<S::N>::NR], double& U, int& st, TC& tc) {
-  constexpr int N = S::N, NR = Geo<N>::NR;
+// q of the quad's trajectory to LDS and, when every sincos site of f takes an input as operand, the pairs of the lane's
+// own coordinates with it (each lane evaluates its n/4 angles once; all sweeps of the evaluation read them).
+template <class S, bool LUT>
+HAMK_DEV void stage_inputs(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR]) {
+  constexpr int NR = Geo<S::N>::NR;
   const int r = c.r;
   HAMK_QUAD_SYNC();                                       // readers of the previous evaluation are done
 #pragma unroll
@@ -534,6 +533,16 @@ HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const
 #endif
   }
   HAMK_QUAD_SYNC();
+}
+
+// Shared first half of every evaluation: q to LDS, sincos pairs, K and its factorisation with the forward substitution
+// of p, back substitution.  Returns the lane's velocities; gU (own rows), U.
+template <class S, bool LUT, class TC>
+HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const double (&pi)[Geo<S::N>::NR],
+                       double (&vi)[Geo<S::N>::NR], double (&gUi)[Geo<S::N>::NR], double& U, int& st, TC& tc) {
+  constexpr int N = S::N, NR = Geo<N>::NR;
+  const int r = c.r;
+  stage_inputs<S, LUT>(c, qi);
 #if HAMK_QUAD_LEFT
   double G[NR][Geo<N>::NP4], z[NR];
 #pragma unroll
@@ -557,13 +566,13 @@ HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const
   U = u.v;
 #pragma unroll
   for (int i = 0; i < NR; ++i) gUi[i] = sel4(r, dget<N>(u.d, 4 * i), dget<N>(u.d, 4 * i + 1), dget<N>(u.d, 4 * i + 2), dget<N>(u.d, 4 * i + 3));
-  double z[NR], dinv[NR];
+  double z[NR];
 #pragma unroll
-  for (int i = 0; i < NR; ++i) z[i] = pi[i];
+  for (int i = 0; i < NR; ++i) { z[i] = pi[i]; c.gu()[(4 * i + r) * 64] = gUi[i]; gUi[i] = 0.0; }      // (dU/dq waits in LDS: Ctx::gu)
   HAMK_PHASE();
-  ldlt<S>(r, sink.acc, z, dinv, st);
+  ldlt<S>(r, sink.acc, z, st);
   HAMK_PHASE();
-  solve_back<S>(r, sink.acc, z, dinv, vi);
+  solve_back<S>(r, sink.acc, z, vi);
   HAMK_PHASE();
 #endif
 }
@@ -602,11 +611,7 @@ HAMK_DEV void ham_eqs(const Ctx<S>& c0, const double (&qi)[Geo<S::N>::NR], const
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     dqi[i] = vi[i];
-#if HAMK_QUAD_LEFT
-    const double gu = c.gu()[(4 * i + r) * 64];           // written by this lane in the first sweep
-#else
-    const double gu = gUi[i];
-#endif
+    const double gu = c.gu()[(4 * i + r) * 64];           // written by this lane during the sweep
     dpi[i] = -(sel4(r, dget<N>(dT, 4 * i), dget<N>(dT, 4 * i + 1), dget<N>(dT, 4 * i + 2), dget<N>(dT, 4 * i + 3)) + gu);
   }
 }
@@ -779,10 +784,284 @@ HAMK_DEV void observe_body(double* smem, const double* q, const double* p, doubl
   }
 }
 
+
+// ---- the entry points around the hot path -----------------------------------------------------------------------------
+// momenta (Hamilton.hs:262-269): p_a = sum_k J[k][a] m_k (J qd)_k for the lane's rows, one sparse sweep; U rides along.
+template <class S> struct SinkP {
+  static constexpr int N = S::N, NR = Geo<N>::NR;
+  double p[NR];
+  const double* v;      // qd of the trajectory in LDS
+  int r;
+  template <int K, int SEQ> HAMK_DEV void put(const Jet1<N>& x) {
+    double w = 0.0;
+#pragma unroll
+    for (int b = 0; b < N; ++b) w = fma(x.d[b], v[b * 64], w);
+    w *= S::inertia(K);
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      p[i] = fma(sel4(r, dget<N>(x.d, 4 * i), dget<N>(x.d, 4 * i + 1), dget<N>(x.d, 4 * i + 2), dget<N>(x.d, 4 * i + 3)), w, p[i]);
+  }
+};
+template <class S>
+HAMK_DEV void momentum(const Ctx<S>& c0, const double (&qi)[Geo<S::N>::NR], const double (&vi)[Geo<S::N>::NR],
+                       double (&pi)[Geo<S::N>::NR], double& U) {
+  constexpr int N = S::N, NR = Geo<N>::NR;
+  const Ctx<S> c = c0.launder();
+  const int r = c.r;
+  stage_inputs<S, false>(c, qi);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) c.v()[(4 * i + r) * 64] = vi[i];
+  HAMK_QUAD_SYNC();
+  SinkP<S> sink;
+  sink.v = c.v(); sink.r = r;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) sink.p[i] = 0.0;
+  InJet1<N> in{c.q()};
+  TrigCache<S::NTRIG_U> tu;
+  Jet1<N> u;
+  if constexpr (Trig<S, false>::shared) { TrigLdsQ<S> tl = c.trig(); u = S::template coords_sink_u<Jet1<N>, TRIG_REUSE>(in, tl, tu, sink); }
+  else { TrigCache<S::NTRIG_F> tc; u = S::template coords_sink_u<Jet1<N>, TRIG_FULL>(in, tc, tu, sink); }
+  U = u.v;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) pi[i] = sink.p[i];
+}
+
+template <class S>
+HAMK_DEV void to_phase_body(double* smem, const double* q, const double* qd, double* p, i64 B) {
+  constexpr int NR = Geo<S::N>::NR;
+  Where<S> w(smem, B);
+  double qi[NR], vi[NR], pi[NR], U;
+  w.load(q, B, qi); w.load(qd, B, vi);
+  momentum<S>(w.c, qi, vi, pi, U);
+  w.store(p, B, pi);
+}
+
+// keC / lagrangian (Hamilton.hs:288-309)
+template <class S>
+HAMK_DEV void observe_config_body(double* smem, const double* q, const double* qd, double* ke, double* lag, i64 B) {
+  constexpr int NR = Geo<S::N>::NR;
+  Where<S> w(smem, B);
+  double qi[NR], vi[NR], pi[NR], U;
+  w.load(q, B, qi); w.load(qd, B, vi);
+  momentum<S>(w.c, qi, vi, pi, U);
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) t = fma(vi[i], pi[i], t);
+  t = 0.5 * qsum(t);
+  if (w.real && w.c.r == 0) {
+    if (ke) ke[w.t] = t;
+    if (lag) lag[w.t] = t - U;
+  }
+}
+
+// underlyingPos (Hamilton.hs:174-178): every lane evaluates f, lane r writes the outputs k = r mod 4
+template <class S> struct SinkX {
+  double* x; i64 B, t; int r; bool real;
+  template <int K, int SEQ> HAMK_DEV void put(double v) const { if (real && (K & 3) == r) x[(i64)K * B + t] = v; }
+};
+template <class S> HAMK_DEV void coords_body(double* smem, const double* q, double* x, i64 B) {
+  constexpr int N = S::N, NR = Geo<N>::NR;
+  Where<S> w(smem, B);
+  double qi[NR];
+  w.load(q, B, qi);
+  const Ctx<S> c = w.c.launder();
+  stage_inputs<S, false>(c, qi);
+  SinkX<S> sink{x, B, w.t, c.r, w.real};
+  InDouble<N> in{c.q()};
+  if constexpr (Trig<S, false>::shared) { TrigLdsQ<S> tl = c.trig(); S::template coords_sink<double, TRIG_REUSE>(in, tl, sink); }
+  else { TrigCache<S::NTRIG_F> tc; S::template coords_sink<double, TRIG_FULL>(in, tc, sink); }
+}
+
+// evolveHam / stepHam: the GSL semantics of hamk::rkf45_body (rkf45.c, cstd.c with a_y = a_dydt = 1, evolve.c, gsl-ode.c
+// under either binding), one trajectory per quad.  t, h and the accept / reject decision are uniform within a quad (the
+// error norm is a quad-wide max by DPP) but differ between the quads of a wavefront: every lane always executes the
+// attempt and a quad that has reached its output time does not commit (the structure of hamk::wave::rkf45_body).
+template <class S>
+HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt,
+                         const double* ts, double ts0, double ts1, double h0, double eps_abs, double eps_rel,
+                         int flags, int max_sub, int* status, int* nsub, int ncalls, int it_every) {
+  constexpr int N = S::N, NR = Geo<N>::NR, D = 2 * NR;
+  constexpr bool LUT = StageTrig<S>::lut;
+  if constexpr (LUT) lut_load();
+  const int row0 = flags & 1, inplace = (flags >> 8) & 3, gsl_api = (flags >> 16) & 3;      // see hamk::rkf45_body
+  const bool api2 = gsl_api != 1;
+  const double sgn = (!api2 || h0 > 0.0) ? 1.0 : -1.0;
+  bool failed = false;
+  Where<S> w(smem, B);
+  double y[D], f[D];                                       // [q of the lane's rows; p of the lane's rows]
+  {
+    double a[NR], b[NR];
+    w.load(q0, B, a); w.load(p0, B, b);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { y[i] = a[i]; y[NR + i] = b[i]; }
+    if (row0 == 0) { w.store(qout, B, a); w.store(pout, B, b); }
+  }
+  auto rhs = [&](const double (&yy)[D], double (&dy)[D], int& st_) {
+    double a[NR], b[NR], da[NR], db[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { a[i] = yy[i]; b[i] = yy[NR + i]; }
+    ham_eqs<S, LUT>(w.c, a, b, da, db, st_);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { dy[i] = da[i]; dy[NR + i] = db[i]; }
+  };
+  int st = 0, attempts = 0;
+  double t = ts ? ts[0] : ts0, h = h0;
+  rhs(y, f, st);                                           // dydt_in at the initial state
+  double* fq = qout; double* fp = pout;                    // iterate: where the next frame goes
+  int until_frame = it_every;
+#pragma unroll 1
+  for (int call = 0; call < ncalls; ++call) {
+    int budget = max_sub;
+    if (call > 0) { t = ts ? ts[0] : ts0; h = h0; failed = false; }
+    for (int rr = 1; rr < nt; ++rr) {
+      const double ti = ts ? ts[rr] : ts1;
+      for (;;) {
+        const bool active = (sgn * (ti - t) > 0.0) && (budget > 0) && !failed;
+        if (!__any(active)) break;                         // wave-uniform exit
+        const double dt = ti - t;
+        double hh = h;
+        bool final_step = false;
+        if ((dt >= 0.0 && hh > dt) || (dt < 0.0 && hh < dt)) { hh = dt; final_step = true; }
+        double k2[D], k3[D], k4[D], k5[D], k6[D], yn[D], fn[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) { k2[j] = k3[j] = k4[j] = k5[j] = k6[j] = 0.0; yn[j] = y[j]; fn[j] = 0.0; }
+        int st_try = 0;
+#pragma unroll 1
+        for (int sg = 0; sg < 6; ++sg) {
+          double yt[D], out[D];
+          switch (sg) {
+            case 0:
+#pragma unroll
+              for (int j = 0; j < D; ++j) yt[j] = y[j] + (1.0 / 4.0) * hh * f[j];
+              break;
+            case 1:
+#pragma unroll
+              for (int j = 0; j < D; ++j) yt[j] = y[j] + hh * ((3.0 / 32.0) * f[j] + (9.0 / 32.0) * k2[j]);
+              break;
+            case 2:
+#pragma unroll
+              for (int j = 0; j < D; ++j) yt[j] = y[j] + hh * ((1932.0 / 2197.0) * f[j] + (-7200.0 / 2197.0) * k2[j] + (7296.0 / 2197.0) * k3[j]);
+              break;
+            case 3:
+#pragma unroll
+              for (int j = 0; j < D; ++j)
+                yt[j] = y[j] + hh * ((8341.0 / 4104.0) * f[j] + (-32832.0 / 4104.0) * k2[j] + (29440.0 / 4104.0) * k3[j] + (-845.0 / 4104.0) * k4[j]);
+              break;
+            case 4:
+#pragma unroll
+              for (int j = 0; j < D; ++j)
+                yt[j] = y[j] + hh * ((-6080.0 / 20520.0) * f[j] + (41040.0 / 20520.0) * k2[j] + (-28352.0 / 20520.0) * k3[j] +
+                                     (9295.0 / 20520.0) * k4[j] + (-5643.0 / 20520.0) * k5[j]);
+              break;
+            default:
+#pragma unroll
+              for (int j = 0; j < D; ++j) {
+                yn[j] = y[j] + hh * ((902880.0 / 7618050.0) * f[j] + (3953664.0 / 7618050.0) * k3[j] + (3855735.0 / 7618050.0) * k4[j] +
+                                     (-1371249.0 / 7618050.0) * k5[j] + (277020.0 / 7618050.0) * k6[j]);
+                yt[j] = yn[j];
+              }
+              break;
+          }
+          rhs(yt, out, st_try);
+          switch (sg) {
+            case 0:
+#pragma unroll
+              for (int j = 0; j < D; ++j) k2[j] = out[j];
+              break;
+            case 1:
+#pragma unroll
+              for (int j = 0; j < D; ++j) k3[j] = out[j];
+              break;
+            case 2:
+#pragma unroll
+              for (int j = 0; j < D; ++j) k4[j] = out[j];
+              break;
+            case 3:
+#pragma unroll
+              for (int j = 0; j < D; ++j) k5[j] = out[j];
+              break;
+            case 4:
+#pragma unroll
+              for (int j = 0; j < D; ++j) k6[j] = out[j];
+              break;
+            default:
+#pragma unroll
+              for (int j = 0; j < D; ++j) fn[j] = out[j];
+              break;
+          }
+        }
+        if (active) st |= st_try;
+        // cstd.c: std_control_hadjust, ord = 5; the norm runs over the trajectory's 2n components = the quad's lanes
+        double rl = 2.2250738585072014e-308;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          if (!w.owns(j < NR ? j : j - NR)) continue;
+          const double e = hh * ((1.0 / 360.0) * f[j] + (-128.0 / 4275.0) * k3[j] + (-2197.0 / 75240.0) * k4[j] + (1.0 / 50.0) * k5[j] + (2.0 / 55.0) * k6[j]);
+          const double rj = fabs(e) / fabs(eps_rel * (fabs(yn[j]) + fabs(hh * fn[j])) + eps_abs);
+          rl = (rj > rl) ? rj : rl;
+        }
+        const double rmax = qmax(rl);
+        const double tnew = final_step ? ti : t + hh;
+        const double h_old = hh;
+        bool reject = false, fail_now = false;
+        if (rmax > 1.1) {
+          double rr5 = 0.9 * rpow_inv<5>(rmax);
+          if (rr5 < 0.2) rr5 = 0.2;
+          const double hdec = rr5 * h_old;
+          if (fabs(hdec) < fabs(h_old) && (tnew + hdec) != tnew) { reject = true; hh = hdec; }
+          else if (api2) { fail_now = true; hh = hdec; }     // GSL_FAILURE; y and t stay advanced
+        } else if (rmax < 0.5) {
+          double rr6 = 0.9 * rpow_inv<6>(rmax);
+          if (rr6 > 5.0) rr6 = 5.0;
+          if (rr6 < 1.0) rr6 = 1.0;
+          hh = rr6 * h_old;
+        }
+        if (active) {                                      // evolve.c: accept or undo
+          ++attempts; --budget;
+          if (fail_now) { failed = true; st |= ST_UNDERFLOW; }
+          if (reject || fail_now || !api2 || !final_step) h = hh;
+          if (!reject) {
+            if (!(sgn * (tnew - t) > 0.0)) st |= ST_UNDERFLOW;
+            t = tnew;
+#pragma unroll
+            for (int j = 0; j < D; ++j) { y[j] = yn[j]; f[j] = fn[j]; }
+          }
+        }
+      }
+      if (sgn * (ti - t) > 0.0 && !failed) st |= ST_MAXSTEPS;
+      if (rr >= row0 && call == ncalls - 1) {
+        double a[NR], b[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) { a[i] = y[i]; b[i] = y[NR + i]; }
+        double* qo = (inplace == 2) ? const_cast<double*>(q0) : (inplace ? qout : qout + (i64)rr * N * B);
+        double* po = (inplace == 2) ? const_cast<double*>(p0) : (inplace ? pout : pout + (i64)rr * N * B);
+        w.store(qo, B, a); w.store(po, B, b);
+      }
+    }
+    if (it_every > 0 && --until_frame == 0) {
+      until_frame = it_every;
+      double a[NR], b[NR];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) { a[i] = y[i]; b[i] = y[NR + i]; }
+      w.store(fq, B, a); w.store(fp, B, b);
+      fq += (i64)N * B; fp += (i64)N * B;
+    }
+  }
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) bad = bad || (w.owns(i) && (is_nonfinite_bits(y[i]) || is_nonfinite_bits(y[NR + i])));
+  if (bad) st |= ST_NONFINITE;
+  const int stq = qor(st);
+  if (w.real && w.c.r == 0) {
+    if (status) status[w.t] = stq;
+    if (nsub) nsub[w.t] = attempts;
+  }
+}
+
 }  // namespace quad
 }  // namespace hamk
 
-// The four kernels of the quad mapping (the names of HAMK_INSTANTIATE; the other four stay with the wave module).
+// The eight kernels of the path on the quad mapping (the names of HAMK_INSTANTIATE).
 #define HAMK_INSTANTIATE_QUAD(S)                                                                                 \
   HAMK_SCRIBBLE_KERNEL                                                                                           \
   extern "C" __global__ void __launch_bounds__(256) hamk_rk4_steps_k(double* q, double* p, long long B,          \
@@ -806,4 +1085,27 @@ HAMK_DEV void observe_body(double* smem, const double* q, const double* p, doubl
                                                                     int* status) {                               \
     HAMK_QUAD_SMEM(S);                                                                                           \
     hamk::quad::observe_body<S>(smem, q, p, ke, pe, h, B, status);                                               \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_coords_k(const double* q, double* x, long long B) {     \
+    HAMK_QUAD_SMEM(S);                                                                                           \
+    hamk::quad::coords_body<S>(smem, q, x, B);                                                                   \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_to_phase_k(const double* q, const double* qd,           \
+                                                                     double* p, long long B) {                   \
+    HAMK_QUAD_SMEM(S);                                                                                           \
+    hamk::quad::to_phase_body<S>(smem, q, qd, p, B);                                                             \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_observe_config_k(const double* q, const double* qd,     \
+                                                                           double* ke, double* lag,              \
+                                                                           long long B) {                        \
+    HAMK_QUAD_SMEM(S);                                                                                           \
+    hamk::quad::observe_config_body<S>(smem, q, qd, ke, lag, B);                                                 \
+  }                                                                                                              \
+  extern "C" __global__ void __launch_bounds__(256) hamk_rkf45_k(                                                \
+      const double* q0, const double* p0, double* qout, double* pout, long long B, int nt, const double* ts,     \
+      double ts0, double ts1, double h0, double eps_abs, double eps_rel, int flags, int max_sub,                 \
+      int* status, int* nsub, int ncalls, int it_every) {                                                        \
+    HAMK_QUAD_SMEM(S);                                                                                           \
+    hamk::quad::rkf45_body<S>(smem, q0, p0, qout, pout, B, nt, ts, ts0, ts1, h0, eps_abs, eps_rel, flags,        \
+                              max_sub, status, nsub, ncalls, it_every);                                          \
   }

@@ -920,6 +920,13 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
 #ifndef HAMK_RK4_MIN_WAVES_BIG                             // n > 32 (one trajectory per wavefront)
 #define HAMK_RK4_MIN_WAVES_BIG 1
 #endif
+// n > 32 (one trajectory per wavefront): the adaptive stepper capped like the RK4 kernel -- two wavefronts per SIMD with
+// spills instead of one with everything in registers (codegen defines HAMK_RKF_MIN_WAVES for those systems; round 3)
+#ifdef HAMK_RKF_MIN_WAVES
+#define HAMK_RKF_BOUNDS __launch_bounds__(256, HAMK_RKF_MIN_WAVES)
+#else
+#define HAMK_RKF_BOUNDS __launch_bounds__(256)
+#endif
 #define HAMK_INSTANTIATE_WAVE(S)                                                                                 \
   HAMK_SCRIBBLE_KERNEL                                                                                           \
   extern "C" __global__ void __launch_bounds__(256, (S::N > 32) ? HAMK_RK4_MIN_WAVES_BIG : HAMK_RK4_MIN_WAVES) hamk_rk4_steps_k(double* q, double* p, long long B, \
@@ -958,7 +965,7 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
     HAMK_WAVE_SMEM(S);                                                                                           \
     hamk::wave::observe_config_body<S>(smem, q, qd, ke, lag, B);                                                 \
   }                                                                                                              \
-  extern "C" __global__ void __launch_bounds__(256) hamk_rkf45_k(                                                \
+  extern "C" __global__ void HAMK_RKF_BOUNDS hamk_rkf45_k(                                                       \
       const double* q0, const double* p0, double* qout, double* pout, long long B, int nt, const double* ts,     \
       double ts0, double ts1, double h0, double eps_abs, double eps_rel, int flags, int max_sub,                 \
       int* status, int* nsub, int ncalls, int it_every) {                                                        \

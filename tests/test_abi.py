@@ -231,10 +231,10 @@ def test_options_cross_the_abi_not_the_environment(hamk_lib, monkeypatch):
 
 def test_mapping_defaults_by_size_and_structure(hamk_lib):
     """n <= 16: one trajectory per lane; 17 <= n <= 32 with a sparse Jacobian (the chains): four lanes per trajectory for
-    the kernels of the hot path, the wave-cooperative module for the rest; n > 32: wave-cooperative."""
+    every kernel of the path; n > 32: wave-cooperative."""
     from hamilton_amd import _abi, api
     assert api.system_from_spec(E.get("chain16")).options()["mapping"] == _abi.MAP_LANE
     s = api.system_from_spec(E.get("chain20"))
     assert s.options()["mapping"] == _abi.MAP_QUAD and s.lanes_per_trajectory == 4 and "hamk_quad.hpp" in s.source
-    assert s.num_device_functions == 5                        # rk4, hamEqs, fromPhase, observe + the self-check's scribble kernel
+    assert s.num_device_functions == 9                        # the eight kernels of the path + the self-check's scribble kernel
     assert api.system_from_spec(E.get("chain33")).options()["mapping"] == _abi.MAP_WAVE

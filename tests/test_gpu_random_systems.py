@@ -105,18 +105,17 @@ def test_random_system_vs_oracle(api, oracle_lib, seed):
     assert np.all(e3[same] <= 100 * tol[same]), (seed, float(np.max(e3[same] / tol[same])))
 
 
-@pytest.mark.parametrize("variant", ["R", "wave"])
+@pytest.mark.parametrize("variant", ["R", "wave", "quad"])
 @pytest.mark.parametrize("seed", [0, 1, 4, 7, 12, 15])
 def test_random_system_other_code_paths(api, oracle_lib, monkeypatch, seed, variant):
-    """The same random systems through the reverse-sweep variant (MODE_R) and through the
-    wave-cooperative kernels (forced on small n)."""
-    if variant == "R":
-        monkeypatch.setenv("HAMK_AD_MODE", "R")
-    else:
-        monkeypatch.setenv("HAMK_WAVE", "1")
+    """The same random systems through the reverse-sweep variant (MODE_R), through the wave-cooperative kernels and
+    through the four-lanes-per-trajectory kernels (both forced on small n, through the ABI's options)."""
+    from hamilton_amd import _abi
     spec = random_spec(seed)
-    s = api.system_from_spec(spec)
-    assert ("MODE_R = true" in s.source) if variant == "R" else ("HAMK_INSTANTIATE_WAVE" in s.source)
+    opt = {"R": {"ad_mode": _abi.AD_R}, "wave": {"mapping": _abi.MAP_WAVE}, "quad": {"mapping": _abi.MAP_QUAD}}[variant]
+    s = api.system_from_spec(spec, opt)
+    marker = {"R": "MODE_R = true", "wave": "HAMK_INSTANTIATE_WAVE", "quad": "HAMK_INSTANTIATE_QUAD"}[variant]
+    assert marker in s.source
     o = oracle_lib.OracleSystem(spec)
     B = 70
     q, qd = E.sample_config(spec, 5, B)
