@@ -327,8 +327,17 @@ template <class S, bool LUT> struct Trig {
   static constexpr int mode1 = shared ? TRIG_REUSE : (LUT ? TRIG_LUT : TRIG_FULL);
 };
 
+// Which factorisation ships (both are kept, both are tested on the host and on the GPU):
+//   0  K assembled whole by ONE sweep, LDL^T right-looking in rank-4 panels (ldlt below).  The fewest instructions (8.4 k per
+//      lane and right-hand side at n = 32), but K + the sweep's working set + a panel's multipliers exceed the 512
+//      registers: 160 spilled, ~50 scratch instructions per right-hand side.
+//   1  left-looking Cholesky, K assembled panel by panel by eight sweeps (panel<JB>): the trailing matrix is never
+//      materialised, no scratch in the stepping loop, HBM traffic 1.5 x the state -- at 9.5 k instructions (the selects
+//      "row 4 i + r" and the sincos loads are repeated per panel).
+// Measured on one MI355X, same box, back to back (profiles/r03_quad_ab.jsonl): chain32 2.51e8 vs 2.15e8 steps/s, chain24
+// 4.86e8 vs 3.85e8, chain16 at B = 16 384 9.0e8 vs 7.2e8: the instruction count decides, not the scratch traffic.
 #ifndef HAMK_QUAD_LEFT
-#define HAMK_QUAD_LEFT 1      /* 1: left-looking Cholesky, K assembled panel by panel (below); 0: K assembled whole, right-looking LDL^T */
+#define HAMK_QUAD_LEFT 0
 #endif
 
 // 1 / sqrt(d): hardware estimate + two Newton steps (d > 0; a non-positive pivot yields NaN and is flagged by the caller)

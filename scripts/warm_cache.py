@@ -50,7 +50,8 @@ def jobs():
         out.append((n, {"HAMK_QUAD": "1"}, False))
     for n in ("chain12", "chain16"):
         out.append((n, {"HAMK_RK4_PARK": "0"}, False))
-    out.append(("chain32", {"HAMK_HIPRTC_FLAGS": "-DHAMK_QUAD_LEFT=0"}, True))      # right-looking LDL^T on the whole K (A/B)
+    for n in ("chain32", "chain20"):
+        out.append((n, {"HAMK_HIPRTC_FLAGS": "-DHAMK_QUAD_LEFT=1", "HAMK_QUAD": "1"}, False))      # left-looking Cholesky, K per panel (A/B, GPU parity test)
     return out
 
 

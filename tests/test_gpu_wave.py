@@ -224,3 +224,24 @@ def test_dense_jacobians_stay_on_the_wave_kernels(api):
     spec = EX.SystemSpec(name="dense18", m=m, n=n, inertia=(1.0,) * m, f=f, u=lambda x, o: x[0] * 0.0 + 1.0 * x[1], u_space=EX.U_CARTESIAN,
                          q0=(0.1,) * n, qd0=(0.0,) * n, q_box=((-1.0, 1.0),) * n, qd_box=((-1.0, 1.0),) * n)
     assert api.system_from_spec(spec).options()["mapping"] == _abi.MAP_WAVE
+
+
+def test_quad_left_looking_variant_vs_oracle(api, oracle_lib, monkeypatch):
+    """The factorisation that does NOT ship by default (left-looking Cholesky, K assembled panel by panel: no scratch,
+    more instructions) stays correct on the GPU: chain20 and chain32 against the oracle."""
+    from hamilton_amd import _abi
+    monkeypatch.setenv("HAMK_HIPRTC_FLAGS", "-DHAMK_QUAD_LEFT=1")
+    for name in ("chain20", "chain32"):
+        spec = E.get(name)
+        s = api.system_from_spec(spec, {"mapping": _abi.MAP_QUAD})
+        o = oracle_lib.OracleSystem(spec)
+        B = 70
+        q, _ = E.sample_config(spec, 3, B)
+        qd = 0.3 * np.cos(np.arange(spec.n * B).reshape(spec.n, B) * 0.7)
+        p = o.to_phase_batch(q, qd)
+        odq, odp, _ = o.hameqs_batch(q, p)
+        dq, dp = api.hamEqs(s, api.Phase(q, p))
+        assert relerr(dq, odq) < 1e-10 and relerr(dp, odp) < 1e-10
+        ph = api.rk4Steps(spec.dt, 5, s, api.Phase(q, p))
+        oq, op = o.rk4_steps_batch(q, p, spec.dt, 5)
+        assert relerr(ph.positions, oq) < 1e-10 and relerr(ph.momenta, op) < 1e-10
