@@ -63,6 +63,10 @@ HAMK_DEV void quad_sync_dev() {
 // interleaved by the machine scheduler: each needs most of the register file for itself, and overlapped they spill.
 #ifdef HAMK_HOST_EMULATION
 #define HAMK_PHASE() ((void)0)
+#elif defined(HAMK_PROBE_MARK)
+// probe builds (scripts/quad_phases.py): a numbered s_setprio at every phase boundary, so the instructions of an evaluation
+// can be attributed to its phases from the disassembly
+#define HAMK_PHASE() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(__COUNTER__ & 3); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define HAMK_PHASE() __builtin_amdgcn_sched_barrier(0)
 #endif
