@@ -192,7 +192,7 @@ typedef struct hamk_options {
   int32_t k_reassoc;       /* ON | OFF: K = J^T M J summed with re-association allowed (repeated Jacobian entries are
                               multiplied by their count instead of added up); AUTO: ON                                  */
   int32_t rk4_park;        /* ON | OFF: lane mapping, RK4 stage loop keeps y and the running combination in LDS across
-                              the right-hand side; AUTO: n >= 12                                                        */
+                              the right-hand side; AUTO: n >= 14                                                        */
   int32_t max_substeps;    /* sub-step budget per stepHam / evolveHam interval and trajectory; AUTO: 2^24               */
   int32_t cache;           /* ON | OFF: on-disk cache of compiled code objects; AUTO: ON                                */
   int32_t lanes_per_trajectory;  /* OUTPUT of hamk_system_get_options: 1, 4, 16, 32 or 64                               */

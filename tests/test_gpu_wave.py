@@ -146,9 +146,11 @@ def test_singular_flag_on_wave_path(api, monkeypatch):
 
 
 def test_lane_path_at_its_upper_size(api, oracle_lib):
-    """n = 12 runs one trajectory per lane (the default up to n = 16): directional jets, stage loops."""
+    """n = 12 runs one trajectory per lane (the default up to n = 16 for ensembles that fill the chip; pinned here, 70
+    trajectories would otherwise go four lanes each): directional jets, stage loops."""
+    from hamilton_amd import _abi
     spec = E.get("chain12")
-    s = api.system_from_spec(spec)
+    s = api.system_from_spec(spec, {"mapping": _abi.MAP_LANE})
     assert "HAMK_INSTANTIATE(HamkSys)" in s.source
     o = oracle_lib.OracleSystem(spec)
     q, qd = E.sample_config(spec, 5, 70)
