@@ -119,7 +119,7 @@ defaultOptions :: Options
 defaultOptions = Options 0 0 0 0 0 0 0 0 0 0 0 0 0 0
 
 instance Storable Options where
-  sizeOf _ = 128                                   -- uint32 size, 14 choices, lanes_per_trajectory (output), reserved[16]
+  sizeOf _ = 128                                   -- uint32 size, 14 choices, lanes_per_trajectory (output), rkf_park (left AUTO), reserved[15]
   alignment _ = 4
   peek p = Options <$> f 4 <*> f 8 <*> f 12 <*> f 16 <*> f 20 <*> f 24 <*> f 28 <*> f 32 <*> f 36 <*> f 40 <*> f 44
                    <*> f 48 <*> f 52 <*> f 56

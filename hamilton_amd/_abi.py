@@ -50,7 +50,7 @@ class HamkOptions(ctypes.Structure):
                 ("gsl_api", ctypes.c_int32), ("self_check", ctypes.c_int32), ("build", ctypes.c_int32),
                 ("wave_blocked", ctypes.c_int32), ("rk4_min_waves", ctypes.c_int32), ("k_reassoc", ctypes.c_int32),
                 ("rk4_park", ctypes.c_int32), ("max_substeps", ctypes.c_int32), ("cache", ctypes.c_int32),
-                ("lanes_per_trajectory", ctypes.c_int32), ("reserved", ctypes.c_int32 * 16)]
+                ("lanes_per_trajectory", ctypes.c_int32), ("rkf_park", ctypes.c_int32), ("reserved", ctypes.c_int32 * 15)]
 
     def __init__(self, **kw):
         super().__init__()

@@ -261,9 +261,9 @@ static CacheKey cache_key(const Variant* s, const std::vector<const char*>& opts
   Sha256 sha;
   auto feed = [&](const void* p, size_t n) { h = fnv1a(p, n, h); const uint64_t len = n; sha.update(&len, sizeof len); sha.update(p, n); };
   feed(s->source.data(), s->source.size());
-  feed(kDeviceHeader, sizeof kDeviceHeader);
-  feed(kWaveHeader, sizeof kWaveHeader);
-  feed(kQuadHeader, sizeof kQuadHeader);
+  feed(kDeviceHeader, sizeof kDeviceHeader);                // the headers this variant's source includes
+  if (s->mapping == HAMK_MAP_WAVE) feed(kWaveHeader, sizeof kWaveHeader);
+  if (s->mapping == HAMK_MAP_QUAD) feed(kQuadHeader, sizeof kQuadHeader);
   for (const char* o : opts) feed(o, std::strlen(o) + 1);
   feed(&major, sizeof major);
   feed(&minor, sizeof minor);
@@ -959,7 +959,7 @@ static std::string check_options(const hamk_options& o, int n) {
   if (!in(o.trig, {HAMK_AUTO, HAMK_TRIG_DIRECT, HAMK_TRIG_TABLE, HAMK_TRIG_TABLE_ROTATE})) return "trig must be HAMK_AUTO or a HAMK_TRIG_* value";
   if (!in(o.gsl_api, {HAMK_AUTO, 1, 2})) return "gsl_api must be HAMK_AUTO, 1 (gsl_odeiv) or 2 (gsl_odeiv2)";
   if (!in(o.build, {HAMK_AUTO, HAMK_BUILD_DEFAULT, HAMK_BUILD_NOLICM})) return "build must be HAMK_AUTO or a HAMK_BUILD_* value";
-  for (int v : {o.self_check, o.wave_blocked, o.k_reassoc, o.rk4_park, o.cache})
+  for (int v : {o.self_check, o.wave_blocked, o.k_reassoc, o.rk4_park, o.rkf_park, o.cache})
     if (!in(v, {HAMK_AUTO, HAMK_ON, HAMK_OFF})) return "switches must be HAMK_AUTO, HAMK_ON or HAMK_OFF";
   if (o.rk4_min_waves < 0 || o.rk4_min_waves > 8) return "rk4_min_waves must be 0 (auto) .. 8";
   if (o.max_substeps < 0) return "max_substeps must be >= 0";
@@ -1046,6 +1046,18 @@ static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4,
   if (o.rk4_park != HAMK_AUTO) d.rk4_park = o.rk4_park == HAMK_ON;
   else if (env_flag("HAMK_RK4_PARK", &b)) d.rk4_park = b;
   if (d.rk4_park && (!d.rk4_stage_loop || mapping != HAMK_MAP_LANE || n > 16)) d.rk4_park = false;          // 2 x 2n x 2 KiB of LDS per block: n <= 16
+  // RKF45 stepper whose nine vectors (18 n doubles per trajectory) wait in LDS (y, dydt, the first k's) and in a
+  // run-time-indexed private array (scratch memory, touched only between right-hand sides) instead of competing with K
+  // for registers (hamk_device.hpp rkf45_body_parked, hamk_quad.hpp rkf45_body_parked).  Measured on MI355X, stepHam
+  // calls/s, registers / parked.  Lane kernels at B = 65 536 (profiles/r03_lane_rkf_park.jsonl): chain16 1.57e7 / 7.88e7
+  // (1516 -> 24 spilled registers), chain14 2.87e7 / 1.27e8, chain12 5.08e7 / 1.80e8, chain10 7.59e7 / 2.50e8, chain8
+  // 2.03e8 / 3.77e8, chain7 3.29e8 / 4.99e8, chain6 5.00e8 / 6.12e8, threeBodyPolar 7.08e8 / 8.21e8, chain5 and chain4 ties.
+  // Quad kernels at B = 16 384 (profiles/r03_quad_rkf_park.jsonl): chain32 4.14e6 / 6.63e6, chain24 1.40e7 / 1.74e7,
+  // chain20 2.70e7 / 2.94e7, chain17 3.34e7 / 3.48e7
+  d.rkf_park = (mapping == HAMK_MAP_LANE && d.rkf_stage_loop && n >= 6) || (mapping == HAMK_MAP_QUAD && n >= 17);
+  if (o.rkf_park != HAMK_AUTO) d.rkf_park = o.rkf_park == HAMK_ON;
+  else if (env_flag("HAMK_RKF_PARK", &b)) d.rkf_park = b;
+  if (d.rkf_park && (mapping == HAMK_MAP_WAVE || (mapping == HAMK_MAP_LANE && !d.rkf_stage_loop))) d.rkf_park = false;
   d.k_reassoc = true;
   if (o.k_reassoc != HAMK_AUTO) d.k_reassoc = o.k_reassoc == HAMK_ON;
   else if (env_flag("HAMK_K_REASSOC", &b)) d.k_reassoc = b;
@@ -1299,6 +1311,7 @@ int hamk_system_get_options(hamk_system* s, int64_t B, hamk_options* r) {
   r->rk4_min_waves = d.rk4_min_waves;
   r->k_reassoc = d.k_reassoc ? HAMK_ON : HAMK_OFF;
   r->rk4_park = d.rk4_park ? HAMK_ON : HAMK_OFF;
+  r->rkf_park = d.rkf_park ? HAMK_ON : HAMK_OFF;
   r->max_substeps = s->max_substeps;
   r->cache = s->cache_on ? HAMK_ON : HAMK_OFF;
   r->lanes_per_trajectory = v->mapping == HAMK_MAP_LANE ? 1 : (v->mapping == HAMK_MAP_QUAD ? 4 : (d.n <= 16 ? 16 : d.n <= 32 ? 32 : 64));

@@ -51,6 +51,15 @@
 #ifndef HAMK_K_REASSOC
 #define HAMK_K_REASSOC 1      /* K = J^T M J summed with re-association allowed (mass_matrix); 0: the round-2 FMA chain */
 #endif
+#ifndef HAMK_RKF_PARK
+#define HAMK_RKF_PARK 0       /* RKF45 stage loop: the stepper's nine vectors wait in a run-time-indexed private array (scratch) */
+#endif
+#ifndef HAMK_RKF_REUSE_MAX_N
+#define HAMK_RKF_REUSE_MAX_N 16 /* parked RKF45 stepper: largest n whose stages use the last right-hand side from the registers */
+#endif
+#ifndef HAMK_RKF_LDS_BUDGET
+#define HAMK_RKF_LDS_BUDGET 76 /* doubles of LDS per lane the parked RKF45 stepper may use (hamk::RkfPark) */
+#endif
 #ifndef HAMK_RK4_PARK
 #define HAMK_RK4_PARK 0       /* RK4 stage loop: y and the running combination parked in LDS across the right-hand side */
 #endif
@@ -1362,6 +1371,225 @@ template <int D> HAMK_DEV void probe_pin(double (&x)[D]) {
 #define HAMK_PIN(x) ((void)0)
 #endif
 #define HAMK_RKF_FLAGS(row0, inplace, gsl_api) (((row0) & 1) | (((inplace) & 3) << 8) | (((gsl_api) & 3) << 16))
+// rkf45_body for the systems whose right-hand side alone wants the whole register file (HAMK_RKF_PARK, with the stage
+// loop).  The stepper's nine vectors -- y, dydt, k2..k6, the trial state and its derivative: 18 n doubles, 576 registers
+// at n = 16 -- only WAIT while a right-hand side runs; left to the register allocator they compete with K and the spill
+// code lands inside the factorisation (chain16: 1516 spilled registers).  Here
+//   * y and dydt -- read by every stage -- wait in LDS, [component][lane] like the RK4 kernel's parked state, and so do
+//     as many of k2, k3, k4 as the CU's 160 KiB allow (RkfPark<S>::NL rows of 2n x 2 KiB per 256-thread block: y and dydt
+//     alone at n = 13..16, + k2 at n = 10..12, + k3 at n = 8, 9);
+//   * the other k's, the trial state and the error combination are rows of one private array that is written at a
+//     run-time row (the stage counter), which keeps it in scratch memory (lane-interleaved: coalesced);
+//   * dydt at the trial state never leaves the registers: it is the last right-hand side's result, consumed by the
+//     error norm and the commit right after it; every right-hand side's result is used from the registers by the stage
+//     that follows it (RkfPark<S>::REUSE; k6 is then never stored); the error combination is formed in stage 6 from the
+//     rows that stage loads anyway.
+// At n = 16, 17 rows of 2n doubles cross the vector-memory pipe per attempt.  That traffic is what bounds this kernel:
+// a first version with all nine vectors in scratch moved 44 rows -- chain16 3.6 GB of HBM traffic per launch, 4.4 TB/s,
+// VALU 22 % busy (profiles/r03f_chain16_stepham_summary.json); with 23 rows: 1.7 GB, 3.6 TB/s, 36 % (r03g).  The statements of
+// rkf45_body below otherwise (same GSL semantics, same flags; the compiler contracts the combinations into FMAs on its
+// own terms: the two bodies agree to roundoff with identical sub-step counts).
+template <class S> struct RkfPark {
+  static constexpr int D = 2 * S::N;
+  static constexpr int BUDGET = HAMK_RKF_LDS_BUDGET;        // doubles per lane; 76: (160 KiB - sincos table - slack) / 256 lanes / 8
+  static constexpr int NL = (BUDGET / D) < 2 ? 2 : ((BUDGET / D) > 5 ? 5 : (BUDGET / D));      // y, dydt, then k2, k3, k4
+  // a right-hand side's result used from the registers by the stage that follows it (k6 is then never stored); measured
+  // against re-reading it from its row (profiles/r03_lane_rkf_park.jsonl): chain13 1.29e8 -> 1.44e8 stepHam/s, chain14
+  // 1.15e8 -> 1.27e8, chain16 a tie
+  static constexpr bool REUSE = HAMK_RKF_REUSE_MAX_N >= S::N;
+};
+template <class S>
+HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt, const double* __restrict__ ts, double ts0, double ts1,
+                                double h0, double eps_abs, double eps_rel, int flags, int max_sub, int* __restrict__ status, int* __restrict__ nsub, int ncalls,
+                                int it_every) {
+  const int row0 = flags & 1, inplace = (flags >> 8) & 3, gsl_api = (flags >> 16) & 3;
+  ts0 = park_in_vgpr(ts0); ts1 = park_in_vgpr(ts1); h0 = park_in_vgpr(h0); eps_abs = park_in_vgpr(eps_abs); eps_rel = park_in_vgpr(eps_rel);
+  constexpr int N = S::N, D = 2 * N, NL = RkfPark<S>::NL;
+  constexpr bool REUSE = RkfPark<S>::REUSE;
+  if constexpr (StageTrig<S>::lut) lut_load();
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const bool api2 = gsl_api != 1;
+  const double sgn = (!api2 || h0 > 0.0) ? 1.0 : -1.0;
+  bool failed = false;
+  __shared__ double rows[NL * D * 256];
+  double* py = rows + threadIdx.x;                         // y[j]    at py[j * 256]
+  double* pf = rows + D * 256 + threadIdx.x;               // dydt[j] at pf[j * 256]
+  constexpr int YN = 5, E = 6;                             // rows 0..4: k2..k6 (those that are not in LDS)
+  double v[7][D];
+  // k_{2 + KR} at the top of stage KR + 1: the result of the right-hand side just evaluated
+  // (one base pointer per LDS row, each "array + constant + lane": offsets from a shared base beyond the 64 KiB a ds
+  // instruction can encode make the compiler keep several derived bases alive through the right-hand side -- chain16: 66
+  // spilled registers instead of 24, 7.8e7 -> 6.1e7 stepHam/s)
+#define HAMK_RKF_LROW(r) (rows + (r) * D * 256 + threadIdx.x)
+#define HAMK_RKF_K(KR, j) ((2 + (KR) < NL) ? HAMK_RKF_LROW(2 + (KR))[(j) * 256] : v[KR][j])      /* k_{2 + KR}[j] */
+#define HAMK_RKF_RECENT(KR, j) (REUSE ? out[j] : HAMK_RKF_K(KR, j))
+  auto put_k = [&](int kr, const double (&x)[D]) {         // k_{2 + kr}; kr: a run-time value (the stage counter)
+    if (NL > 2 && 2 + kr < NL) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) HAMK_RKF_LROW(2 + kr)[j * 256] = x[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < D; ++j) v[kr][j] = x[j];
+    }
+  };
+  int st = 0, attempts = 0;
+  double t = ts ? ts[0] : ts0, h = h0;
+  TrigCache<S::NTRIG_F> tc;
+  {
+    double y0[D], f0[D];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { y0[j] = q0[(i64)j * B + i]; y0[N + j] = p0[(i64)j * B + i]; }
+    if (row0 == 0) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) { qout[(i64)j * B + i] = y0[j]; pout[(i64)j * B + i] = y0[N + j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) py[j * 256] = y0[j];
+    rhs<S, StageTrig<S>::anchor>(y0, f0, st, tc);          // dydt_in at the initial state
+#pragma unroll
+    for (int j = 0; j < D; ++j) pf[j * 256] = f0[j];
+  }
+  it_every = park_in_vgpr(it_every);
+  int until_frame = it_every;
+  int calls_left = park_in_vgpr(ncalls);
+#pragma unroll 1
+  for (bool first = true; calls_left > 0; --calls_left, first = false) {
+  int budget = max_sub;
+  if (!first) { t = ts ? ts[0] : ts0; h = h0; failed = false; }
+  for (int r = 1; r < nt; ++r) {
+    const double ti = ts ? ts[r] : ts1;
+    while (sgn * (ti - t) > 0.0 && budget > 0 && !failed) {
+      ++attempts; --budget;
+      HAMK_MARK(1);
+      const double dt = ti - t;
+      double hh = h;
+      bool final_step = false;
+      if ((dt >= 0.0 && hh > dt) || (dt < 0.0 && hh < dt)) { hh = dt; final_step = true; }
+      double out[D];                                        // the last right-hand side's result: k_{sg + 1} at the top of stage sg
+#pragma unroll
+      for (int j = 0; j < D; ++j) out[j] = 0.0;
+#pragma unroll 1
+      for (int sg = 0; sg < 6; ++sg) {
+        double yt[D];
+        switch (sg) {
+          case 0:
+#pragma unroll
+            for (int j = 0; j < D; ++j) yt[j] = py[j * 256] + (1.0 / 4.0) * hh * pf[j * 256];
+            break;
+          case 1:
+#pragma unroll
+            for (int j = 0; j < D; ++j) yt[j] = py[j * 256] + hh * ((3.0 / 32.0) * pf[j * 256] + (9.0 / 32.0) * HAMK_RKF_RECENT(0, j));
+            break;
+          case 2:
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+              yt[j] = py[j * 256] + hh * ((1932.0 / 2197.0) * pf[j * 256] + (-7200.0 / 2197.0) * HAMK_RKF_K(0, j) + (7296.0 / 2197.0) * HAMK_RKF_RECENT(1, j));
+            break;
+          case 3:
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+              yt[j] = py[j * 256] + hh * ((8341.0 / 4104.0) * pf[j * 256] + (-32832.0 / 4104.0) * HAMK_RKF_K(0, j) +
+                                          (29440.0 / 4104.0) * HAMK_RKF_K(1, j) + (-845.0 / 4104.0) * HAMK_RKF_RECENT(2, j));
+            break;
+          case 4:
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+              yt[j] = py[j * 256] + hh * ((-6080.0 / 20520.0) * pf[j * 256] + (41040.0 / 20520.0) * HAMK_RKF_K(0, j) +
+                                          (-28352.0 / 20520.0) * HAMK_RKF_K(1, j) + (9295.0 / 20520.0) * HAMK_RKF_K(2, j) +
+                                          (-5643.0 / 20520.0) * HAMK_RKF_RECENT(3, j));
+            break;
+          default: {
+            double ye[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+              const double f0 = pf[j * 256], k3 = HAMK_RKF_K(1, j), k4 = HAMK_RKF_K(2, j), k5 = HAMK_RKF_K(3, j), k6 = HAMK_RKF_RECENT(4, j);
+              const double di = (902880.0 / 7618050.0) * f0 + (3953664.0 / 7618050.0) * k3 +
+                                (3855735.0 / 7618050.0) * k4 + (-1371249.0 / 7618050.0) * k5 +
+                                (277020.0 / 7618050.0) * k6;
+              yt[j] = py[j * 256] + hh * di;
+              ye[j] = hh * ((1.0 / 360.0) * f0 + (-128.0 / 4275.0) * k3 + (-2197.0 / 75240.0) * k4 + (1.0 / 50.0) * k5 + (2.0 / 55.0) * k6);
+            }
+#pragma unroll
+            for (int j = 0; j < D; ++j) v[YN][j] = yt[j];
+#pragma unroll
+            for (int j = 0; j < D; ++j) v[E][j] = ye[j];
+            break;
+          }
+        }
+        HAMK_MARK(3);
+        HAMK_PIN(yt);
+#ifndef HAMK_HOST_EMULATION
+        __builtin_amdgcn_sched_barrier(0);                  // no row is fetched early into the right-hand side
+#endif
+        rhs<S, StageTrig<S>::lut ? TRIG_LUT : TRIG_FULL>(yt, out, st, tc);
+#ifndef HAMK_HOST_EMULATION
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        HAMK_PIN(out);
+        HAMK_MARK(0);
+        if (sg < (REUSE ? 4 : 5)) put_k(sg, out);          // k2..k5, k6 unless it is used from the registers; dydt_out always is
+      }
+      // --- cstd.c: std_control_hadjust, ord = 5 ------------------------------
+      double yn[D];
+      double rmax = 2.2250738585072014e-308;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        yn[j] = v[YN][j];
+        const double D0 = eps_rel * (fabs(yn[j]) + fabs(hh * out[j])) + eps_abs;
+        const double rr = fabs(v[E][j]) / fabs(D0);
+        rmax = (rr > rmax) ? rr : rmax;
+      }
+      const double tnew = final_step ? ti : t + hh;
+      const double h_old = hh;
+      bool reject = false;
+      if (rmax > 1.1) {
+        double rr = 0.9 * rpow_inv<5>(rmax);
+        if (rr < 0.2) rr = 0.2;
+        const double hdec = rr * h_old;
+        if (fabs(hdec) < fabs(h_old) && (tnew + hdec) != tnew) { reject = true; hh = hdec; }
+        else if (api2) { failed = true; hh = hdec; st |= ST_UNDERFLOW; }
+      } else if (rmax < 0.5) {
+        double rr = 0.9 * rpow_inv<6>(rmax);
+        if (rr > 5.0) rr = 5.0;
+        if (rr < 1.0) rr = 1.0;
+        hh = rr * h_old;
+      }
+      if (reject || failed || !api2 || !final_step) h = hh;
+      if (!reject) {
+        if (!(sgn * (tnew - t) > 0.0)) st |= ST_UNDERFLOW;
+        t = tnew;
+#pragma unroll
+        for (int j = 0; j < D; ++j) { py[j * 256] = yn[j]; pf[j * 256] = out[j]; }
+      }
+      HAMK_MARK(2);
+    }
+    if (sgn * (ti - t) > 0.0 && !failed) st |= ST_MAXSTEPS;
+    if (r >= row0 && calls_left == 1) {
+      double* qo = (inplace == 2) ? const_cast<double*>(q0) : (inplace ? qout : qout + (i64)r * N * B);
+      double* po = (inplace == 2) ? const_cast<double*>(p0) : (inplace ? pout : pout + (i64)r * N * B);
+#pragma unroll
+      for (int j = 0; j < N; ++j) { qo[(i64)j * B + i] = py[j * 256]; po[(i64)j * B + i] = py[(N + j) * 256]; }
+    }
+  }
+  if (it_every > 0 && --until_frame == 0) {
+    until_frame = it_every;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { qout[(i64)j * B + i] = py[j * 256]; pout[(i64)j * B + i] = py[(N + j) * 256]; }
+    qout += (i64)N * B; pout += (i64)N * B;
+  }
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < D; ++j) bad = bad || is_nonfinite_bits(py[j * 256]);
+  if (bad) st |= ST_NONFINITE;
+  if (status) status[i] = st;
+  if (nsub) nsub[i] = attempts;
+#undef HAMK_RKF_RECENT
+#undef HAMK_RKF_K
+#undef HAMK_RKF_LROW
+}
+
 template <class S>
 HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt, const double* __restrict__ ts, double ts0, double ts1, double h0,
                          double eps_abs, double eps_rel, int flags, int max_sub,
@@ -1371,6 +1599,10 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
   //   bits 8-9   0: rows go to qout/pout + r N B (evolveHam); 1: the final state overwrites qout/pout (stepHam in place);
   //              2: iterate -- the final state overwrites q0/p0, qout/pout receive every it_every-th state
   //   bits 16-17 which binding of gsl-ode.c (1 | 2)
+  if constexpr (S::RKF_STAGE_LOOP && HAMK_RKF_PARK) {
+    rkf45_body_parked<S>(q0, p0, qout, pout, B, nt, ts, ts0, ts1, h0, eps_abs, eps_rel, flags, max_sub, status, nsub, ncalls, it_every);
+    return;
+  }
   const int row0 = flags & 1, inplace = (flags >> 8) & 3, gsl_api = (flags >> 16) & 3;
   ts0 = park_in_vgpr(ts0); ts1 = park_in_vgpr(ts1); h0 = park_in_vgpr(h0); eps_abs = park_in_vgpr(eps_abs); eps_rel = park_in_vgpr(eps_rel);
   constexpr int N = S::N, D = 2 * N;

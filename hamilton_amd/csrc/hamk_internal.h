@@ -19,6 +19,7 @@ struct SystemDesc {
   int mapping = 1;              // HAMK_MAP_* (hamk.h)
   bool wave = false;            // mapping == HAMK_MAP_WAVE: wave-cooperative kernels (hamk_wave.hpp) instead of one trajectory per lane
   bool k_reassoc = true;        // mass_matrix summed with re-association allowed (hamk_device.hpp)
+  bool rkf_park = false;        // lane / quad mapping: the RKF45 stepper's vectors in a run-time-indexed private array
   bool rk4_park = false;        // lane mapping: RK4 stage loop parks y / acc in LDS across the right-hand side
   bool wave_blocked = false;    // wave kernels: LDL^T in panels of 16 with the trailing blocks updated on the matrix cores
   std::vector<double> inertia;

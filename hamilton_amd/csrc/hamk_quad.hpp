@@ -889,10 +889,226 @@ template <class S> HAMK_DEV void coords_body(double* smem, const double* q, doub
 // under either binding), one trajectory per quad.  t, h and the accept / reject decision are uniform within a quad (the
 // error norm is a quad-wide max by DPP) but differ between the quads of a wavefront: every lane always executes the
 // attempt and a quad that has reached its output time does not commit (the structure of hamk::wave::rkf45_body).
+#ifndef HAMK_QUAD_RKF_PARK
+#define HAMK_QUAD_RKF_PARK 0       /* generated: hamk_options::rkf_park */
+#endif
+
+// The body for the larger systems (HAMK_QUAD_RKF_PARK; the library's default from n = 17).  The stepper's nine vectors (y,
+// dydt, k2..k6, the trial state and its derivative: 18 NR doubles per lane, 288 registers at n = 32) only WAIT while a
+// right-hand side runs, and one right-hand side alone wants the whole register file; left to the register allocator they
+// compete with K and the spill code lands inside the factorisation (chain32: 797 spilled registers).  As in
+// hamk::rkf45_body_parked: y and dydt (and k2.. where the CU's LDS allows) wait in LDS next to the quad's exchange
+// arrays, the other k's, the trial state and the error combination in one private array that is written at a run-time
+// row (the stage counter: it stays in scratch memory), and every right-hand side's result is used from the registers
+// by the stage -- or the error norm and the commit -- that follows it.  Same expressions (the compiler contracts them
+// into FMAs on its own terms: the two bodies agree to roundoff, with identical sub-step counts).  Measured on MI355X,
+// stepHam calls/s at B = 16 384, registers / parked (profiles/r03_quad_rkf_park.jsonl): chain32 4.14e6 / 6.63e6 (797 ->
+// 74 spilled registers), chain24 1.40e7 / 1.74e7, chain20 2.70e7 / 2.94e7, chain17 3.34e7 / 3.48e7.
+template <class S> struct RkfPark {
+  static constexpr int D = 2 * Geo<S::N>::NR;
+  static constexpr int BUDGET = (160 * 1024 - 8 * 1024 - 2 * 1024 - Lds<S>::TOTAL * 8) / 2048;       // doubles per lane left in the CU's LDS
+  static constexpr int NL = (BUDGET / D) > 5 ? 5 : (BUDGET / D);                                        // y, dydt, then k2, k3, k4
+  static_assert(NL >= 2, "the quad exchange arrays leave room for y and dydt up to n = 32");
+};
+template <class S>
+HAMK_DEV void rkf45_body_parked(double* smem, const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt,
+                                const double* ts, double ts0, double ts1, double h0, double eps_abs, double eps_rel,
+                                int flags, int max_sub, int* status, int* nsub, int ncalls, int it_every) {
+  constexpr int N = S::N, NR = Geo<N>::NR, D = 2 * NR, NL = RkfPark<S>::NL;
+  constexpr bool LUT = StageTrig<S>::lut;
+  if constexpr (LUT) lut_load();
+  const int row0 = flags & 1, inplace = (flags >> 8) & 3, gsl_api = (flags >> 16) & 3;
+  const bool api2 = gsl_api != 1;
+  const double sgn = (!api2 || h0 > 0.0) ? 1.0 : -1.0;
+  bool failed = false;
+  Where<S> w(smem, B);
+  __shared__ double rows[NL * D * 256];
+  // (one base pointer per LDS row, each "array + constant + lane": see hamk::rkf45_body_parked)
+#define HAMK_RKF_LROW(r) (rows + (r) * D * 256 + threadIdx.x)
+#define HAMK_RKF_K(KR, j) ((2 + (KR) < NL) ? HAMK_RKF_LROW(2 + (KR))[(j) * 256] : v[KR][j])      /* k_{2 + KR}[j] */
+  double* py = rows + threadIdx.x;                         // y[j]    at py[j * 256]: [q of the lane's rows; p of the lane's rows]
+  double* pf = rows + D * 256 + threadIdx.x;               // dydt[j] at pf[j * 256]
+  constexpr int YN = 4, E = 5;                             // rows 0..3: k2..k5 (those that are not in LDS)
+  double v[6][D];
+  auto put_k = [&](int kr, const double (&x)[D]) {         // k_{2 + kr}; kr: a run-time value (the stage counter)
+    if (NL > 2 && 2 + kr < NL) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) HAMK_RKF_LROW(2 + kr)[j * 256] = x[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < D; ++j) v[kr][j] = x[j];
+    }
+  };
+  auto rhs = [&](const double (&yy)[D], double (&dy)[D], int& st_) {
+    double a[NR], b[NR], da[NR], db[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { a[i] = yy[i]; b[i] = yy[NR + i]; }
+    __builtin_amdgcn_sched_barrier(0);                     // no row is fetched early into the right-hand side
+    ham_eqs<S, LUT>(w.c, a, b, da, db, st_);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { dy[i] = da[i]; dy[NR + i] = db[i]; }
+  };
+  int st = 0, attempts = 0;
+  double t = ts ? ts[0] : ts0, h = h0;
+  {
+    double a[NR], b[NR], y0[D], f0[D];
+    w.load(q0, B, a); w.load(p0, B, b);
+    if (row0 == 0) { w.store(qout, B, a); w.store(pout, B, b); }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { y0[i] = a[i]; y0[NR + i] = b[i]; }
+#pragma unroll
+    for (int j = 0; j < D; ++j) py[j * 256] = y0[j];
+    rhs(y0, f0, st);                                       // dydt_in at the initial state
+#pragma unroll
+    for (int j = 0; j < D; ++j) pf[j * 256] = f0[j];
+  }
+  auto store_state = [&](double* qo, double* po) {
+    double a[NR], b[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { a[i] = py[i * 256]; b[i] = py[(NR + i) * 256]; }
+    w.store(qo, B, a); w.store(po, B, b);
+  };
+  double* fq = qout; double* fp = pout;                    // iterate: where the next frame goes
+  int until_frame = it_every;
+#pragma unroll 1
+  for (int call = 0; call < ncalls; ++call) {
+    int budget = max_sub;
+    if (call > 0) { t = ts ? ts[0] : ts0; h = h0; failed = false; }
+    for (int rr = 1; rr < nt; ++rr) {
+      const double ti = ts ? ts[rr] : ts1;
+      for (;;) {
+        const bool active = (sgn * (ti - t) > 0.0) && (budget > 0) && !failed;
+        if (!__any(active)) break;                         // wave-uniform exit
+        const double dt = ti - t;
+        double hh = h;
+        bool final_step = false;
+        if ((dt >= 0.0 && hh > dt) || (dt < 0.0 && hh < dt)) { hh = dt; final_step = true; }
+        int st_try = 0;
+        double out[D];                                      // the last right-hand side's result: k_{sg + 1} at the top of stage sg
+#pragma unroll
+        for (int j = 0; j < D; ++j) out[j] = 0.0;
+#pragma unroll 1
+        for (int sg = 0; sg < 6; ++sg) {
+          double yt[D];
+          switch (sg) {
+            case 0:
+#pragma unroll
+              for (int j = 0; j < D; ++j) yt[j] = py[j * 256] + (1.0 / 4.0) * hh * pf[j * 256];
+              break;
+            case 1:
+#pragma unroll
+              for (int j = 0; j < D; ++j) yt[j] = py[j * 256] + hh * ((3.0 / 32.0) * pf[j * 256] + (9.0 / 32.0) * out[j]);
+              break;
+            case 2:
+#pragma unroll
+              for (int j = 0; j < D; ++j)
+                yt[j] = py[j * 256] + hh * ((1932.0 / 2197.0) * pf[j * 256] + (-7200.0 / 2197.0) * HAMK_RKF_K(0, j) + (7296.0 / 2197.0) * out[j]);
+              break;
+            case 3:
+#pragma unroll
+              for (int j = 0; j < D; ++j)
+                yt[j] = py[j * 256] + hh * ((8341.0 / 4104.0) * pf[j * 256] + (-32832.0 / 4104.0) * HAMK_RKF_K(0, j) + (29440.0 / 4104.0) * HAMK_RKF_K(1, j) +
+                                            (-845.0 / 4104.0) * out[j]);
+              break;
+            case 4:
+#pragma unroll
+              for (int j = 0; j < D; ++j)
+                yt[j] = py[j * 256] + hh * ((-6080.0 / 20520.0) * pf[j * 256] + (41040.0 / 20520.0) * HAMK_RKF_K(0, j) + (-28352.0 / 20520.0) * HAMK_RKF_K(1, j) +
+                                            (9295.0 / 20520.0) * HAMK_RKF_K(2, j) + (-5643.0 / 20520.0) * out[j]);
+              break;
+            default: {
+              double ye[D];
+#pragma unroll
+              for (int j = 0; j < D; ++j) {
+                const double f0 = pf[j * 256], k3 = HAMK_RKF_K(1, j), k4 = HAMK_RKF_K(2, j), k5 = HAMK_RKF_K(3, j), k6 = out[j];
+                yt[j] = py[j * 256] + hh * ((902880.0 / 7618050.0) * f0 + (3953664.0 / 7618050.0) * k3 + (3855735.0 / 7618050.0) * k4 +
+                                            (-1371249.0 / 7618050.0) * k5 + (277020.0 / 7618050.0) * k6);
+                ye[j] = hh * ((1.0 / 360.0) * f0 + (-128.0 / 4275.0) * k3 + (-2197.0 / 75240.0) * k4 + (1.0 / 50.0) * k5 + (2.0 / 55.0) * k6);
+              }
+#pragma unroll
+              for (int j = 0; j < D; ++j) v[YN][j] = yt[j];
+#pragma unroll
+              for (int j = 0; j < D; ++j) v[E][j] = ye[j];
+              break;
+            }
+          }
+          rhs(yt, out, st_try);
+          if (sg < 4) put_k(sg, out);                      // k2..k5 (k6 and dydt at the trial state are used from the registers)
+        }
+        if (active) st |= st_try;
+        // cstd.c: std_control_hadjust, ord = 5; the norm runs over the trajectory's 2n components = the quad's lanes
+        double yn[D];
+        double rl = 2.2250738585072014e-308;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          yn[j] = v[YN][j];
+          if (!w.owns(j < NR ? j : j - NR)) continue;
+          const double rj = fabs(v[E][j]) / fabs(eps_rel * (fabs(yn[j]) + fabs(hh * out[j])) + eps_abs);
+          rl = (rj > rl) ? rj : rl;
+        }
+        const double rmax = qmax(rl);
+        const double tnew = final_step ? ti : t + hh;
+        const double h_old = hh;
+        bool reject = false, fail_now = false;
+        if (rmax > 1.1) {
+          double rr5 = 0.9 * rpow_inv<5>(rmax);
+          if (rr5 < 0.2) rr5 = 0.2;
+          const double hdec = rr5 * h_old;
+          if (fabs(hdec) < fabs(h_old) && (tnew + hdec) != tnew) { reject = true; hh = hdec; }
+          else if (api2) { fail_now = true; hh = hdec; }     // GSL_FAILURE; y and t stay advanced
+        } else if (rmax < 0.5) {
+          double rr6 = 0.9 * rpow_inv<6>(rmax);
+          if (rr6 > 5.0) rr6 = 5.0;
+          if (rr6 < 1.0) rr6 = 1.0;
+          hh = rr6 * h_old;
+        }
+        if (active) {                                      // evolve.c: accept or undo
+          ++attempts; --budget;
+          if (fail_now) { failed = true; st |= ST_UNDERFLOW; }
+          if (reject || fail_now || !api2 || !final_step) h = hh;
+          if (!reject) {
+            if (!(sgn * (tnew - t) > 0.0)) st |= ST_UNDERFLOW;
+            t = tnew;
+#pragma unroll
+            for (int j = 0; j < D; ++j) { py[j * 256] = yn[j]; pf[j * 256] = out[j]; }
+          }
+        }
+      }
+      if (sgn * (ti - t) > 0.0 && !failed) st |= ST_MAXSTEPS;
+      if (rr >= row0 && call == ncalls - 1) {
+        double* qo = (inplace == 2) ? const_cast<double*>(q0) : (inplace ? qout : qout + (i64)rr * N * B);
+        double* po = (inplace == 2) ? const_cast<double*>(p0) : (inplace ? pout : pout + (i64)rr * N * B);
+        store_state(qo, po);
+      }
+    }
+    if (it_every > 0 && --until_frame == 0) {
+      until_frame = it_every;
+      store_state(fq, fp);
+      fq += (i64)N * B; fp += (i64)N * B;
+    }
+  }
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) bad = bad || (w.owns(i) && (is_nonfinite_bits(py[i * 256]) || is_nonfinite_bits(py[(NR + i) * 256])));
+  if (bad) st |= ST_NONFINITE;
+  const int stq = qor(st);
+  if (w.real && w.c.r == 0) {
+    if (status) status[w.t] = stq;
+    if (nsub) nsub[w.t] = attempts;
+  }
+#undef HAMK_RKF_K
+#undef HAMK_RKF_LROW
+}
+
 template <class S>
 HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt,
                          const double* ts, double ts0, double ts1, double h0, double eps_abs, double eps_rel,
                          int flags, int max_sub, int* status, int* nsub, int ncalls, int it_every) {
+  if constexpr (HAMK_QUAD_RKF_PARK != 0) {
+    rkf45_body_parked<S>(smem, q0, p0, qout, pout, B, nt, ts, ts0, ts1, h0, eps_abs, eps_rel, flags, max_sub, status, nsub, ncalls, it_every);
+    return;
+  }
   constexpr int N = S::N, NR = Geo<N>::NR, D = 2 * NR;
   constexpr bool LUT = StageTrig<S>::lut;
   if constexpr (LUT) lut_load();

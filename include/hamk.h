@@ -196,7 +196,10 @@ typedef struct hamk_options {
   int32_t max_substeps;    /* sub-step budget per stepHam / evolveHam interval and trajectory; AUTO: 2^24               */
   int32_t cache;           /* ON | OFF: on-disk cache of compiled code objects; AUTO: ON                                */
   int32_t lanes_per_trajectory;  /* OUTPUT of hamk_system_get_options: 1, 4, 16, 32 or 64                               */
-  int32_t reserved[16];           /* sizeof(hamk_options) = 128 */
+  int32_t rkf_park;        /* ON | OFF: lane and quad mappings, the adaptive stepper's vectors (y, dydt, k2..k6, trial state)
+                              wait in LDS and in a run-time-indexed private array instead of competing with the right-hand
+                              side for registers; AUTO: lane n >= 6 (with the stage-loop body), quad n >= 17              */
+  int32_t reserved[15];           /* sizeof(hamk_options) = 128 */
 } hamk_options;
 
 /* Zero-fills *opt and sets opt->size.                                                                                 */

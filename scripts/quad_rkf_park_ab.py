@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""stepHam calls/s of the four-lane adaptive kernel with its stage vectors left to the register allocator
+(hamk_options::rkf_park OFF) and parked in a run-time-indexed private array (the default from n = 17), one MI355X:
+  python scripts/quad_rkf_park_ab.py > gpurun_out/r03_quad_rkf_park.jsonl"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from hamilton_amd import _abi, api, examples
+
+
+def stepham_rate(s, spec, B, dt):
+    q, qd = examples.sample_config(spec, 0, B)
+    qd = 0.3 * np.cos(np.arange(spec.n * B).reshape(spec.n, B) * 0.7)
+    ph = api.toPhase(s, api.Config(torch.from_numpy(q).cuda(), torch.from_numpy(qd).cuda()))
+    st = api.Phase(ph.positions.clone(), ph.momenta.clone())
+    out = api.stepHam(dt, s, st)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); out = api.stepHam(dt, s, st); e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    return B / (best * 1e-3), float(s.last_nsub.double().mean()), out
+
+
+def main():
+    for name, B in (("chain32", 16384), ("chain32", 65536), ("chain24", 16384), ("chain20", 16384), ("chain17", 16384)):
+        spec = examples.get(name)
+        res = {}
+        for park in (0, 1):
+            s = api.system_from_spec(spec, {"mapping": _abi.MAP_QUAD, "rkf_park": _abi.ON if park else _abi.OFF})
+            rate, nsub, out = stepham_rate(s, spec, B, 4 * spec.dt)
+            res[park] = out
+            print(json.dumps({"what": "stepham", "system": name, "B": B, "rkf_park": park, "calls_per_s": rate, "mean_substeps": nsub}), flush=True)
+        d = max(float((res[0].positions - res[1].positions).abs().max()), float((res[0].momenta - res[1].momenta).abs().max()))
+        print(json.dumps({"what": "agreement", "system": name, "B": B, "max_abs_diff_parked_vs_registers": d}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

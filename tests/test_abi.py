@@ -240,6 +240,13 @@ def test_mapping_defaults_by_size_and_structure(hamk_lib):
         t = api.system_from_spec(E.get(name))
         assert t.options(16384)["mapping"] == small and t.options(32768)["mapping"] == _abi.MAP_LANE, name
         assert t.options(65536)["rk4_park"] == park, name
+    # the adaptive stepper's vectors parked in LDS / a run-time-indexed private array: lane kernels from n = 6 (with the
+    # stage loop), quad kernels from n = 17 (profiles/r03_lane_rkf_park.jsonl, r03_quad_rkf_park.jsonl); never the wave kernels
+    for name, want in (("chain4", _abi.OFF), ("threeBodyPolar", _abi.ON), ("chain8", _abi.ON), ("chain16", _abi.ON), ("chain20", _abi.ON), ("chain33", _abi.OFF)):
+        assert api.system_from_spec(E.get(name)).options(65536)["rkf_park"] == want, name
+    assert api.system_from_spec(E.get("chain14")).options(8192)["rkf_park"] == _abi.OFF          # (the quad module of a small ensemble: n < 17)
+    t = api.system_from_spec(E.get("chain8"), {"rkf_park": _abi.OFF})
+    assert t.options()["rkf_park"] == _abi.OFF and "HAMK_RKF_PARK 1" not in t.source
     s = api.system_from_spec(E.get("chain20"))
     assert s.options()["mapping"] == _abi.MAP_QUAD and s.lanes_per_trajectory == 4 and "hamk_quad.hpp" in s.source
     assert s.num_device_functions == 9                        # the eight kernels of the path + the self-check's scribble kernel

@@ -277,6 +277,43 @@ def test_mid_size_systems_on_host(emulate, oracle_lib, name):
     check_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=8, steps=2, tol=1e-10)
 
 
+@pytest.mark.parametrize("park", ["1", "0"])
+def test_adaptive_stepper_with_parked_stage_vectors_on_host(emulate, oracle_lib, park):
+    """hamk_device.hpp rkf45_body_parked (hamk_options::rkf_park; the default of the lane kernels from n = 6) and the body
+    it replaces, chain8: an evolveHam time grid under both GSL bindings with the oracle's sub-step counts on every
+    trajectory, and `iterate (stepHam dt)` in one launch == the calls one by one, bitwise."""
+    spec = E.get("chain8")
+    o = oracle_lib.OracleSystem(spec)
+    L, src = emulate(spec, {"HAMK_RKF_PARK": park})
+    assert ("#define HAMK_RKF_PARK 1" in src) == (park == "1")
+    B = 9
+    q, qd = E.sample_config(spec, 3, B)
+    qd = qd + 0.4 * np.cos(np.arange(spec.n * B).reshape(spec.n, B))
+    p = o.to_phase_batch(q, qd)
+    try:
+        for api in (2, 1):
+            o.gsl_api = api
+            L.emu_set_gsl_api(api)
+            ts = np.array([0.0, 0.02, 0.05, 0.05, 0.09])
+            qo, po = np.zeros((len(ts), spec.n, B)), np.zeros((len(ts), spec.n, B))
+            st, ns = np.zeros(B, np.int32), np.zeros(B, np.int32)
+            L.emu_evolve_ham(P(q), P(p), len(ts), P(ts), P(qo), P(po), LL(B), I(st), I(ns))
+            oq, op, ons = o.evolve_ham_batch(q, p, ts)
+            assert np.array_equal(ns, ons) and not st.any() and ns.min() > 4
+            assert relerr(qo, oq) < 1e-10 and relerr(po, op) < 1e-10
+            q1, p1, tot = q.copy(), p.copy(), np.zeros(B, np.int64)
+            for _ in range(3):
+                L.emu_step_ham(P(q1), P(p1), LL(B), ctypes.c_double(0.03), I(st), I(ns))
+                tot += ns
+            q2, p2 = q.copy(), p.copy()
+            fq, fp = np.zeros((3, spec.n, B)), np.zeros((3, spec.n, B))
+            L.emu_step_ham_iterate(P(q2), P(p2), LL(B), ctypes.c_double(0.03), 3, 1, P(fq), P(fp), I(st), I(ns))
+            assert np.array_equal(q1, q2) and np.array_equal(p1, p2) and np.array_equal(tot, ns.astype(np.int64))
+            assert np.array_equal(fq[2], q2) and np.array_equal(fp[2], p2)
+    finally:
+        L.emu_set_gsl_api(2)
+
+
 @pytest.mark.parametrize("seed", [0, 3, 8, 10, 12, 15])
 def test_random_systems_on_host(emulate, oracle_lib, seed):
     """The random expression-tree systems of the GPU suite (incl. seed 8, whose unrolled RKF45 kernel
@@ -634,11 +671,13 @@ def test_quad_random_systems_on_host(emulate_quad, oracle_lib, seed):
     assert np.all(e2[good] <= 10 * tol[good]), (seed, float(np.max(e2[good] / tol[good])))
 
 
+@pytest.mark.parametrize("name", ["chain5", "chain21"])
 @pytest.mark.parametrize("api", [2, 1])
-def test_quad_adaptive_stepper_on_host(emulate_quad, oracle_lib, api):
+def test_quad_adaptive_stepper_on_host(emulate_quad, oracle_lib, api, name):
     """evolveHam over a time grid and `iterate (stepHam dt)` on the four-lane kernels under both GSL bindings: sub-step
-    counts identical to the oracle's on every trajectory, one launch of k calls == k launches bitwise."""
-    spec = E.get("chain5")
+    counts identical to the oracle's on every trajectory, one launch of k calls == k launches bitwise.  chain21 takes the
+    body whose stage vectors wait in LDS and a run-time-indexed private array (HAMK_QUAD_RKF_PARK, n >= 17), chain5 the other."""
+    spec = E.get(name)
     o = oracle_lib.OracleSystem(spec)
     o.gsl_api = api
     L = emulate_quad(spec)
