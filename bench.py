@@ -303,7 +303,7 @@ def stepham_bench(a, s, spec, dt, state, dist, dev, rank, world):
                "data": "synthetic (per-index splitmix64 initial conditions, seed 20241008)",
                "config": {"workload": f"{a.system} (System {spec.m} {spec.n}) ensemble, stepHam dt={dt}", "trajectories_per_gpu": B,
                           "stepham_calls_per_launch": K,
-                          "kernel_path": "wave-cooperative" if lanes > 1 else "one trajectory per lane", "gsl_api": s.gsl_api},
+                          "kernel_path": ("four lanes per trajectory" if lanes == 4 else "wave-cooperative") if lanes > 1 else "one trajectory per lane", "gsl_api": s.gsl_api},
                "mean_substeps": float(nsub.mean()), "max_substeps": float(nsub.max()),
                "rhs_evals_per_s": attempts_per_s * 6,
                "divergence": {"mean_substeps_per_lane": float(nsub.mean()), "mean_of_wave_max_substeps": float(wmax.mean()),
