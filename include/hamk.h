@@ -25,8 +25,11 @@
  *
  * The reference evaluates ONE trajectory per call on the CPU through `ad`
  * (AD), hmatrix (LAPACK/BLAS) and hmatrix-gsl (GSL odeiv).  This library
- * evaluates an ENSEMBLE of B independent trajectories per call on the GPU,
- * one trajectory per wavefront lane.  B = 1 reproduces the reference API.
+ * evaluates an ENSEMBLE of B independent trajectories per call on the GPU:
+ * one trajectory per wavefront lane up to n = 16, four lanes per trajectory
+ * (sparse coordinate maps up to n = 32, and small ensembles of mid-size
+ * systems) or 16 / 32 / 64 lanes per trajectory beyond -- chosen per launch
+ * from (n, B), see hamk_options::mapping.  B = 1 reproduces the reference API.
  *
  * Data layout: every state array is structure-of-arrays, fp64, component
  * major: q[j*B + i] is generalized coordinate j of trajectory i (j < n,
