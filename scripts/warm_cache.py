@@ -50,6 +50,11 @@ def jobs():
         out.append((n, {"HAMK_QUAD": "1"}, False))
     for n in ("chain12", "chain16"):
         out.append((n, {"HAMK_RK4_PARK": "0"}, False))
+    # the adaptive stepper with and without its parked stage vectors (tests/test_gpu_wave.py)
+    for n in ("chain8", "threeBodyPolar", "chain13"):
+        out.append((n, {"HAMK_WAVE": "0", "HAMK_QUAD": "0"}, False))
+        out.append((n, {"HAMK_WAVE": "0", "HAMK_QUAD": "0", "HAMK_RKF_PARK": "0"}, False))
+    out.append(("chain24", {"HAMK_RKF_PARK": "0"}, False))
     for n in ("chain32", "chain20"):
         out.append((n, {"HAMK_HIPRTC_FLAGS": "-DHAMK_QUAD_LEFT=1", "HAMK_QUAD": "1"}, False))      # left-looking Cholesky, K per panel (A/B, GPU parity test)
     return out
@@ -75,7 +80,7 @@ def build(job):
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             import isa_stats
             isa_stats.rk4_step_stats(spec, s)
-            if name in ("doublePendulum", "spring", "threeBodyPolar", "twoBody"):
+            if name in ("doublePendulum", "spring", "threeBodyPolar", "twoBody", "chain8", "chain16"):
                 isa_stats.rkf45_attempt_stats(spec, s)      # bench.py --integrator stepham
         return name, env, s.code_size
     except Exception as e:          # a job that cannot be built here is simply not cached

@@ -213,6 +213,58 @@ def test_quad_path_vs_oracle(api, oracle_lib, name, force):
         record(test="quad_vs_oracle", name=name, B=B, hameqs=e1, rk4_5=e5)
 
 
+@pytest.mark.parametrize("name,quad", [("chain8", False), ("threeBodyPolar", False), ("chain13", False), ("chain24", True)])
+def test_parked_adaptive_stepper_takes_the_reference_steps(api, oracle_lib, name, quad):
+    """hamk_options::rkf_park: the adaptive stepper whose stage vectors wait in LDS / a run-time-indexed private array
+    (the default of the lane kernels from n = 6 and the quad kernels from n = 17) against the body that leaves them to the
+    register allocator and against the oracle: the same sub-step counts on every trajectory, states to roundoff; `iterate
+    (stepHam dt)` in one launch == the calls one by one, bitwise; evolveHam over a grid under the old GSL binding too."""
+    from hamilton_amd import _abi
+    spec = E.get(name)
+    mp = _abi.MAP_QUAD if quad else _abi.MAP_LANE
+    on = api.system_from_spec(spec, {"mapping": mp, "rkf_park": _abi.ON})
+    off = api.system_from_spec(spec, {"mapping": mp, "rkf_park": _abi.OFF})
+    assert on.options()["rkf_park"] == _abi.ON and off.options()["rkf_park"] == _abi.OFF
+    assert api.system_from_spec(spec, {"mapping": mp}).options()["rkf_park"] == _abi.ON          # what AUTO picks
+    o = oracle_lib.OracleSystem(spec)
+    for B in (3, 300):
+        q, qd = E.sample_config(spec, 17, B)
+        if name.startswith("chain"):
+            qd = 0.3 * np.cos(np.arange(spec.n * B).reshape(spec.n, B) * 0.7)
+        p = o.to_phase_batch(q, qd)
+        dt = 4 * spec.dt
+        a = api.stepHam(dt, on, api.Phase(q, p))
+        na = np.asarray(on.last_nsub).copy()
+        b = api.stepHam(dt, off, api.Phase(q, p))
+        nb = np.asarray(off.last_nsub).copy()
+        assert np.array_equal(na, nb) and na.min() >= 3 and not np.any(on.last_status)
+        d = max(relerr(a.positions, b.positions), relerr(a.momenta, b.momenta))
+        assert d < 1e-12, (name, B, d)
+        k = min(B, 40)
+        sq, sp, sns = o.step_ham_batch(q[:, :k], p[:, :k], dt)
+        assert np.array_equal(na[:k], sns) and max(relerr(a.positions[:, :k], sq), relerr(a.momenta[:, :k], sp)) < 1e-9
+        one = a
+        for _ in range(2):
+            one = api.stepHam(dt, on, one)
+        it = api.iterateStepHam(dt, 3, on, api.Phase(q, p))
+        assert np.array_equal(it.positions, one.positions) and np.array_equal(it.momenta, one.momenta)
+        record(test="parked_rkf", name=name, B=B, parked_vs_registers=d, mean_substeps=float(na.mean()))
+    on.gsl_api = 1
+    o.gsl_api = 1
+    try:
+        q, qd = E.sample_config(spec, 5, 20)
+        if name.startswith("chain"):
+            qd = 0.3 * np.cos(np.arange(spec.n * 20).reshape(spec.n, 20) * 0.9)
+        p = o.to_phase_batch(q, qd)
+        ts = np.array([0.0, 2 * spec.dt, 5 * spec.dt, 5 * spec.dt, 9 * spec.dt])
+        rows = api.evolveHam(on, api.Phase(q, p), ts)
+        oq, op, ons = o.evolve_ham_batch(q, p, ts)
+        assert np.array_equal(np.asarray(on.last_nsub), ons)
+        assert max(relerr(np.stack([r.positions for r in rows]), oq), relerr(np.stack([r.momenta for r in rows]), op)) < 1e-9
+    finally:
+        on.gsl_api = 2
+
+
 def test_dense_jacobians_stay_on_the_wave_kernels(api):
     """The quad mapping needs a sparse Jacobian (every lane keeps one register pair per DISTINCT entry): a dense random
     coordinate map of the same size is left on the wave-cooperative kernels."""
