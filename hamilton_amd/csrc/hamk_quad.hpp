@@ -952,16 +952,11 @@ HAMK_DEV void rkf45_body_parked(double* smem, const double* q0, const double* p0
   int st = 0, attempts = 0;
   double t = ts ? ts[0] : ts0, h = h0;
   {
-    double a[NR], b[NR], y0[D], f0[D];
+    double a[NR], b[NR];
     w.load(q0, B, a); w.load(p0, B, b);
     if (row0 == 0) { w.store(qout, B, a); w.store(pout, B, b); }
 #pragma unroll
-    for (int i = 0; i < NR; ++i) { y0[i] = a[i]; y0[NR + i] = b[i]; }
-#pragma unroll
-    for (int j = 0; j < D; ++j) py[j * 256] = y0[j];
-    rhs(y0, f0, st);                                       // dydt_in at the initial state
-#pragma unroll
-    for (int j = 0; j < D; ++j) pf[j * 256] = f0[j];
+    for (int i = 0; i < NR; ++i) { py[i * 256] = a[i]; py[(NR + i) * 256] = b[i]; }
   }
   auto store_state = [&](double* qo, double* po) {
     double a[NR], b[NR];
@@ -975,6 +970,16 @@ HAMK_DEV void rkf45_body_parked(double* smem, const double* q0, const double* p0
   for (int call = 0; call < ncalls; ++call) {
     int budget = max_sub;
     if (call > 0) { t = ts ? ts[0] : ts0; h = h0; failed = false; }
+    {
+      // dydt_in of EVERY call by the instructions a separate launch starts with (see hamk::rkf45_body_parked): `iterate`
+      // is bit-identical to the calls one by one by construction, not by two inlined copies compiling alike
+      double y0[D], f0[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) y0[j] = py[j * 256];
+      rhs(y0, f0, st);
+#pragma unroll
+      for (int j = 0; j < D; ++j) pf[j * 256] = f0[j];
+    }
     for (int rr = 1; rr < nt; ++rr) {
       const double ti = ts ? ts[rr] : ts1;
       for (;;) {

@@ -324,8 +324,8 @@ int hamk_step_ham_batch(hamk_system* s, int64_t B, double* q, double* p, double 
  * stepHam dt in ONE launch, IN PLACE.  Every call is what a separate hamk_step_ham_batch would do -- a fresh
  * evolveHam over (0, dt): t = 0, h0 = dt/100 (Hamilton.hs:400-402, :447), its own sub-step budget -- and the
  * result is bit-identical to ncalls separate calls; what is saved is ncalls - 1 launches and stream
- * synchronisations (one trajectory is launch-latency bound: BASELINE config 1) and one right-hand side per
- * call (dydt_in of a call is the dydt_out the previous one already holds).
+ * synchronisations (one trajectory is launch-latency bound: BASELINE config 1) and, in the kernels of the small
+ * systems, one right-hand side per call (dydt_in of a call is the dydt_out the previous one already holds).
  * out_every > 0: the state after every out_every-th call goes to qout/pout, [ncalls / out_every][n][B]
  * (the frames an animation shows); out_every == 0: qout/pout may be NULL.  status: OR over the calls;
  * nsub: sub-steps summed over the calls.                                                                 */
