@@ -16,7 +16,7 @@ CACHE = os.path.join(ROOT, ".hamk_cache")
 def jobs():
     out = []
     base = ["pendulum", "doublePendulum", "room", "twoBody", "spring", "bezier", "threeBodyPolar", "opcodeZoo",
-            "chain4", "chain8", "chain12", "chain16", "chain17", "chain18", "chain20", "chain32", "chain33", "chain40", "chain48", "chain64"]
+            "chain4", "chain5", "chain8", "chain12", "chain16", "chain17", "chain18", "chain20", "chain32", "chain33", "chain40", "chain48", "chain64"]
     for n in base:
         out.append((n, {}, True))
         out.append((n, {"HAMK_GSL_API": "1"}, False))

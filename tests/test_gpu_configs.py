@@ -460,9 +460,11 @@ def test_c1_as_one_launch_is_bit_identical_to_1000_calls(api, oracle_lib, gsl_ap
     assert e < 1e-8, e
 
 
-@pytest.mark.parametrize("name,force_wave", [("doublePendulum", False), ("threeBodyPolar", False), ("chain20", False), ("chain8", True)])
+@pytest.mark.parametrize("name,force_wave", [("doublePendulum", False), ("threeBodyPolar", False), ("chain5", False), ("chain20", False), ("chain8", True)])
 def test_iterate_on_device_ensembles(api, oracle_lib, monkeypatch, name, force_wave):
-    """The same on ensembles resident in HBM, lane and wave kernels: one launch of k calls == k launches, bitwise."""
+    """The same on ensembles resident in HBM -- the unrolled body (doublePendulum), the parked lane body (threeBodyPolar), the
+    plain stage-loop body (chain5), the parked quad body (chain20), the wave kernels (chain8 forced): one launch of k calls ==
+    k launches, bitwise."""
     import torch
     if force_wave:
         monkeypatch.setenv("HAMK_WAVE", "1")
