@@ -148,16 +148,20 @@ def test_evolveham_time_grid_on_host(emulate, oracle_lib, api):
         L.emu_set_gsl_api(2)
 
 
-def test_odeiv2_backward_grid_and_failure_on_host(emulate, oracle_lib):
-    """gsl_odeiv2 semantics the old API does not have: (a) the direction of integration is the sign
+@pytest.mark.parametrize("name", ["doublePendulum", "chain8"])
+def test_odeiv2_backward_grid_and_failure_on_host(emulate, oracle_lib, name):
+    """(doublePendulum: the unrolled body; chain8: the body with parked stage vectors.)
+    gsl_odeiv2 semantics the old API does not have: (a) the direction of integration is the sign
     of the initial step, so a monotone decreasing grid integrates BACKWARDS (the old API's
     `while (t < ti)` does nothing); (b) a step that must shrink but cannot -- here: tolerances no
     fp64 step can meet -- is GSL_FAILURE: the lane stops, ST_UNDERFLOW, later rows = last state."""
-    spec = E.get("doublePendulum")
+    spec = E.get(name)
     o = oracle_lib.OracleSystem(spec)
     L, _ = emulate(spec)
     B = 12
     q, qd = E.sample_config(spec, 5, B)
+    if name.startswith("chain"):
+        qd = qd + 0.4 * np.cos(np.arange(spec.n * B).reshape(spec.n, B))
     p = o.to_phase_batch(q, qd)
     ts = np.array([0.0, -0.05, -0.12])
     qo, po = np.zeros((3, spec.n, B)), np.zeros((3, spec.n, B))
@@ -704,6 +708,13 @@ def test_quad_adaptive_stepper_on_host(emulate_quad, oracle_lib, api, name):
         L.emu_step_ham_iterate(P(q2), P(p2), LL(B), ctypes.c_double(0.03), 4, 2, P(fq), P(fp), I(st), I(ns))
         assert np.array_equal(q1, q2) and np.array_equal(p1, p2) and np.array_equal(tot, ns.astype(np.int64))
         assert np.array_equal(fq[1], q2) and np.array_equal(fp[1], p2)
+        if api == 2:                                       # gsl_odeiv2: a decreasing grid integrates backwards
+            tb = np.array([0.0, -0.02, -0.05])
+            qb, pb = np.zeros((3, spec.n, B)), np.zeros((3, spec.n, B))
+            L.emu_evolve_ham(P(q), P(p), 3, P(tb), P(qb), P(pb), LL(B), I(st), I(ns))
+            oqb, opb, onb = o.evolve_ham_batch(q, p, tb)
+            assert np.array_equal(ns, onb) and ns.min() > 2 and not st.any()
+            assert relerr(qb, oqb) < 1e-9 and relerr(pb, opb) < 1e-9
     finally:
         L.emu_set_gsl_api(2)
 
