@@ -323,7 +323,7 @@ def stepham_bench(a, s, spec, dt, state, dist, dev, rank, world):
                 fp64.update(isa)
                 fp64["wave_attempts_per_s"] = wave_attempts_per_s
                 fp64["valu_issue_frac"] = wave_attempts_per_s * isa["valu_per_wave_attempt"] * 4.0 / (N_SIMD * NOMINAL_HZ)
-                fp64["achieved_tflops_useful"] = B * float(nsub.mean()) / kernel_s * isa["valu_f64_per_wave_attempt"] * 2 / 1e12
+                fp64["achieved_tflops_useful"] = lanes * B * float(nsub.mean()) / kernel_s * isa["valu_f64_per_wave_attempt"] * 2 / 1e12
                 fp64["note"] = ("valu_issue_frac counts what the wavefronts EXECUTE (wave-max attempts); achieved_tflops_useful counts "
                                 "fp64 instructions x 2 on the attempts the lanes needed (an upper bound: not every fp64 instruction is an FMA)")
         out["roofline"] = {"bound": "hbm", "achieved": alg / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

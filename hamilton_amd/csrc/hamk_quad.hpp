@@ -63,7 +63,7 @@ HAMK_DEV void quad_sync_dev() {
 // interleaved by the machine scheduler: each needs most of the register file for itself, and overlapped they spill.
 #ifdef HAMK_HOST_EMULATION
 #define HAMK_PHASE() ((void)0)
-#elif defined(HAMK_PROBE_MARK)
+#elif defined(HAMK_PROBE_PHASE)
 // probe builds (scripts/quad_phases.py): a numbered s_setprio at every phase boundary, so the instructions of an evaluation
 // can be attributed to its phases from the disassembly
 #define HAMK_PHASE() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(__COUNTER__ & 3); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -985,6 +985,7 @@ HAMK_DEV void rkf45_body_parked(double* smem, const double* q0, const double* p0
       for (;;) {
         const bool active = (sgn * (ti - t) > 0.0) && (budget > 0) && !failed;
         if (!__any(active)) break;                         // wave-uniform exit
+        HAMK_MARK(1);                                      // (probe builds: scripts/isa_stats.py rkf45_attempt_stats)
         const double dt = ti - t;
         double hh = h;
         bool final_step = false;
@@ -1038,7 +1039,11 @@ HAMK_DEV void rkf45_body_parked(double* smem, const double* q0, const double* p0
               break;
             }
           }
+          HAMK_MARK(3);
+          HAMK_PIN(yt);
           rhs(yt, out, st_try);
+          HAMK_PIN(out);
+          HAMK_MARK(0);
           if (sg < 4) put_k(sg, out);                      // k2..k5 (k6 and dydt at the trial state are used from the registers)
         }
         if (active) st |= st_try;
@@ -1079,6 +1084,7 @@ HAMK_DEV void rkf45_body_parked(double* smem, const double* q0, const double* p0
             for (int j = 0; j < D; ++j) { py[j * 256] = yn[j]; pf[j * 256] = out[j]; }
           }
         }
+        HAMK_MARK(2);
       }
       if (sgn * (ti - t) > 0.0 && !failed) st |= ST_MAXSTEPS;
       if (rr >= row0 && call == ncalls - 1) {

@@ -230,7 +230,8 @@ def rkf45_attempt_stats(spec, system=None):
     """Cost of ONE attempt of the adaptive stepper (hamk_rkf45_k; six right-hand sides + controller) of one wavefront,
     counted from a probe build of the same module: -DHAMK_PROBE_NO_SLOWPATH removes the never-executed library branches,
     -DHAMK_PROBE_MARK brackets the attempt (s_setprio 1 ... 2) and, in the stage-loop body, the one inlined right-hand
-    side (s_setprio 3 ... 0), which an attempt executes six times.  Lane kernels only."""
+    side (s_setprio 3 ... 0), which an attempt executes six times.  Lane kernels, and the quad kernels' parked body (a wavefront
+    then holds 16 trajectories)."""
     if not os.path.exists(OBJDUMP):
         return None
     from hamilton_amd import api
@@ -239,7 +240,9 @@ def rkf45_attempt_stats(spec, system=None):
     src = system.source
     if "HAMK_INSTANTIATE_WAVE" in src:
         return None
-    env = {"HAMK_RKF_LOOP": "1" if "RKF_STAGE_LOOP = true" in src else "0", "HAMK_WAVE": "0",
+    quad = "HAMK_INSTANTIATE_QUAD" in src
+    env = {"HAMK_RKF_LOOP": "1" if ("RKF_STAGE_LOOP = true" in src or quad) else "0", "HAMK_WAVE": "0", "HAMK_QUAD": "1" if quad else "0",
+           "HAMK_RKF_PARK": "1" if ("HAMK_RKF_PARK 1" in src or "HAMK_QUAD_RKF_PARK 1" in src) else "0",
            "HAMK_AD_MODE": "H" if "MODE_H = true" in src else ("R" if "MODE_R = true" in src else "D"),
            "HAMK_HIPRTC_FLAGS": (os.environ.get("HAMK_HIPRTC_FLAGS", "") + " -DHAMK_PROBE_NO_SLOWPATH -DHAMK_PROBE_MARK").strip()}
     old = {k: os.environ.get(k) for k in env}

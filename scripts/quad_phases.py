@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the instructions of one right-hand side of the four-lane kernels go (no GPU needed): builds the quad module of a
-system with -DHAMK_PROBE_MARK (a numbered s_setprio at every phase boundary of hamk_quad.hpp), disassembles hamk_hameqs_k and
+system with -DHAMK_PROBE_PHASE (a numbered s_setprio at every phase boundary of hamk_quad.hpp), disassembles hamk_hameqs_k and
 prints the instruction classes between consecutive markers.
   python scripts/quad_phases.py chain32"""
 import collections
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 d = tempfile.mkdtemp(); os.chmod(d, 0o700); os.environ["HAMK_CACHE_DIR"] = d
-os.environ["HAMK_HIPRTC_FLAGS"] = (os.environ.get("HAMK_HIPRTC_FLAGS", "") + " -DHAMK_PROBE_NO_SLOWPATH -DHAMK_PROBE_MARK").strip()
+os.environ["HAMK_HIPRTC_FLAGS"] = (os.environ.get("HAMK_HIPRTC_FLAGS", "") + " -DHAMK_PROBE_NO_SLOWPATH -DHAMK_PROBE_PHASE").strip()
 from hamilton_amd import _abi, api, examples
 import isa_stats
 

@@ -80,7 +80,7 @@ def build(job):
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             import isa_stats
             isa_stats.rk4_step_stats(spec, s)
-            if name in ("doublePendulum", "spring", "threeBodyPolar", "twoBody", "chain8", "chain16"):
+            if name in ("doublePendulum", "spring", "threeBodyPolar", "twoBody", "chain8", "chain16", "chain32"):
                 isa_stats.rkf45_attempt_stats(spec, s)      # bench.py --integrator stepham
         return name, env, s.code_size
     except Exception as e:          # a job that cannot be built here is simply not cached
