@@ -935,10 +935,12 @@ static int check_call(hamk_system* s, int64_t B, int32_t mem) {
 //     threeBodyPolar (n = 6): lane 2.1e9 at 8192 against quad 1.15e9 (lane throughout)
 //     chain14   B = 8192: lane 3.86e8, quad 4.98e8    16384: 7.69e8 / 9.92e8    32768: 1.54e9 / 1.28e9
 //     chain12   B = 8192: lane 5.33e8, quad 7.01e8    16384: 1.06e9 / 1.37e9    32768: 2.12e9 / 1.73e9
+//     chain11   B = 8192: lane 6.69e8, quad 7.39e8    16384: 1.34e9 / 1.46e9    32768: 2.68e9 / 1.85e9
 //     chain10   B = 8192: lane 7.99e8, quad 7.94e8    16384: 1.59e9 / 1.58e9    32768: 3.17e9 / 1.99e9   (a tie: lane)
-// (profiles/r03_rules_probe.jsonl).  The wave-cooperative kernels never win at n <= 16 for B >= 8192.
+// (profiles/r03_rules_probe.jsonl; chain13 the same picture, +15 %).  The wave-cooperative kernels never win at n <= 16
+// for B >= 8192.
 static int64_t quad_below(int n) {
-  return n >= 12 ? 32768 : 0;
+  return n >= 11 ? 32768 : 0;
 }
 
 static bool env_flag(const char* name, bool* value) {           // "0" / "1" test overrides
@@ -1041,7 +1043,7 @@ static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4,
   // RK4 stage loop with y / acc parked in LDS (hamk_device.hpp rk4_body): where one right-hand side alone fills the
   // register file the waiting state is what spills; chain16 300 spilled registers -> 34, none in the loop.  Measured
   // at B = 65 536 (profiles/r03_rules_probe.jsonl; RK4 steps/s parked / not): chain16 2.09e9 / 1.01e9, chain14
-  // 2.77e9 / 2.63e9, chain12 3.74e9 / 3.90e9, chain10 5.03e9 / 5.42e9 -- it pays from n = 14
+  // 2.77e9 / 2.63e9, chain13 3.19e9 / 3.46e9, chain12 3.74e9 / 3.90e9, chain10 5.03e9 / 5.42e9 -- it pays from n = 14
   d.rk4_park = mapping == HAMK_MAP_LANE && n >= 14;
   if (o.rk4_park != HAMK_AUTO) d.rk4_park = o.rk4_park == HAMK_ON;
   else if (env_flag("HAMK_RK4_PARK", &b)) d.rk4_park = b;

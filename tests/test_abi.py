@@ -234,7 +234,7 @@ def test_mapping_defaults_by_size_and_structure(hamk_lib):
     every kernel of the path; n > 32: wave-cooperative."""
     from hamilton_amd import _abi, api
     assert api.system_from_spec(E.get("chain16")).options()["mapping"] == _abi.MAP_LANE
-    # ensembles under 32 768 leave the lane kernels from n = 12 (a lane kernel puts 64 trajectories in a wavefront);
+    # ensembles under 32 768 leave the lane kernels from n = 11 (a lane kernel puts 64 trajectories in a wavefront);
     # the LDS-parked RK4 state from n = 14 (profiles/r03_rules_probe.jsonl)
     for name, small, park in (("chain10", _abi.MAP_LANE, _abi.OFF), ("chain12", _abi.MAP_QUAD, _abi.OFF), ("chain14", _abi.MAP_QUAD, _abi.ON)):
         t = api.system_from_spec(E.get(name))
