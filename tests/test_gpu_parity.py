@@ -317,6 +317,30 @@ def test_host_pointer_paths_equal_device_path(api, systems, B):
     torch.cuda.synchronize()
 
 
+def test_large_host_arrays_cross_in_chunks(api, systems):
+    """Host arrays from 4 MiB cross PCIe in 16 MiB chunks through two pinned bounce buffers, a multi-threaded memcpy on one
+    while the DMA engine works on the other (hamk_api.cpp Stager::copy_in_chunks / copy_out).  67 MB per array here -- five
+    chunks with a ragged tail, four arrays in, four out over two calls -- against the device-pointer path, bitwise; then
+    the same handle on small arrays again (the pinned arena) and a mid-size one (plain staging)."""
+    import torch
+    spec, s, o = systems["doublePendulum"]
+    B = (1 << 22) + 7
+    q, qd = E.sample_config(spec, 4242, B)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ph_h = api.toPhase(s, api.Config(q, qd))
+    ph_d = api.toPhase(s, api.Config(T(q), T(qd)))
+    assert np.array_equal(ph_h.momenta, ph_d.momenta.cpu().numpy())
+    r_h = api.rk4Steps(0.01, 3, s, ph_h)
+    r_d = api.rk4Steps(0.01, 3, s, ph_d)
+    assert np.array_equal(r_h.positions, r_d.positions.cpu().numpy()) and np.array_equal(r_h.momenta, r_d.momenta.cpu().numpy())
+    assert not np.shares_memory(r_h.positions, ph_h.positions) and np.array_equal(ph_h.positions, q)       # inputs untouched
+    for Bs in (130, 100000):
+        qs, ps = q[:, :Bs].copy(), ph_h.momenta[:, :Bs].copy()
+        a = api.rk4Steps(0.01, 3, s, api.Phase(qs, ps))
+        assert np.array_equal(a.positions, r_h.positions[:, :Bs]) and np.array_equal(a.momenta, r_h.momenta[:, :Bs])
+    torch.cuda.synchronize()
+
+
 def test_small_host_calls_see_fresh_inputs(api, systems):
     """The pinned arena of small host-pointer calls is rewritten by the CPU before every call and
     reused at the same offsets by every entry point: alternate different inputs through one handle,
