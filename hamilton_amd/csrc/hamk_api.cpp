@@ -17,7 +17,6 @@
 #include <fstream>
 #include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include <sys/stat.h>
@@ -114,12 +113,6 @@ struct DevState {
   char* pin = nullptr;          // host address
   char* pin_dev = nullptr;      // the same block as the device sees it
   bool pin_failed = false;
-  // two pinned bounce buffers for LARGE host arrays (>= kBounceMin): the array crosses in chunks, a parallel memcpy
-  // between the caller's pageable memory and one buffer while the DMA engine works on the other (Stager::copy_in /
-  // copy_out).  hipMemcpy from pageable memory does the same with one thread: 7-18 GB/s measured on the GPU boxes.
-  char* bounce[2] = {nullptr, nullptr};
-  hipEvent_t bounce_ev[2] = {nullptr, nullptr};
-  bool bounce_failed = false;
   // small device scratch for evolveHam's time grid
   double* d_ts = nullptr;
   size_t d_ts_cap = 0;
@@ -130,10 +123,6 @@ struct DevState {
     for (void*& b : stage_buf) if (b) { hipFree(b); b = nullptr; }
     stage_cap.assign(stage_cap.size(), 0);
     if (pin) { hipHostFree(pin); pin = pin_dev = nullptr; }
-    for (int k = 0; k < 2; ++k) {
-      if (bounce[k]) { hipHostFree(bounce[k]); bounce[k] = nullptr; }
-      if (bounce_ev[k]) { hipEventDestroy(bounce_ev[k]); bounce_ev[k] = nullptr; }
-    }
   }
 };
 
@@ -833,7 +822,6 @@ static int launch(hamk_system* s, KernelId k, int64_t B, void** args) {
 }
 
 // ---- host-pointer staging -----------------------------------------------------
-#define TRY_RC(expr) do { int rc_ = (expr); if (rc_ != HAMK_OK) return rc_; } while (0)
 namespace {
 struct Staged {
   void* dev = nullptr;
@@ -844,32 +832,6 @@ struct Staged {
 };
 constexpr size_t kPinArena = 256 << 10;    // bytes of pinned arena per handle
 constexpr size_t kPinMaxBuf = 32 << 10;    // larger arrays go through device staging
-constexpr size_t kBounceMin = 4u << 20;    // from here on: chunks through the pinned bounce buffers, parallel memcpy
-constexpr size_t kBounceChunk = 16u << 20;
-
-// memcpy with up to 8 threads (>= 2 MiB each): one core moves ~10 GB/s, PCIe 5 x16 ~50
-void par_memcpy(void* dst, const void* src, size_t bytes) {
-  static const unsigned hw = [] {
-    unsigned h = std::thread::hardware_concurrency();
-    const char* e = std::getenv("HAMK_COPY_THREADS");      // test override
-    if (e && std::atoi(e) > 0) h = (unsigned)std::atoi(e);
-    return h ? h : 1u;
-  }();
-  size_t nt = std::min<size_t>(std::min<size_t>(8, hw), bytes / (2u << 20));
-  if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
-  const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
-  std::vector<std::thread> th;
-  th.reserve(nt - 1);
-  for (size_t k = 1; k < nt; ++k) {
-    const size_t off = k * per;
-    if (off >= bytes) break;
-    const size_t len = std::min(per, bytes - off);
-    th.emplace_back([=] { std::memcpy((char*)dst + off, (const char*)src + off, len); });
-  }
-  std::memcpy(dst, src, std::min(per, bytes));
-  for (auto& t : th) t.join();
-}
-
 class Stager {
  public:
   explicit Stager(hamk_system* s, int mem) : s_(s), host_(mem == HAMK_MEM_HOST) {}
@@ -888,10 +850,7 @@ class Stager {
   int finish() {
     if (!host_) return HAMK_OK;
     for (auto& b : bufs_)
-      if (b.out && !b.pinned) {
-        if (b.bytes >= kBounceMin && bounce_ready()) TRY_RC(copy_out(b));
-        else HIP_TRY(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, s_->cur->stream));
-      }
+      if (b.out && !b.pinned) HIP_TRY(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, s_->cur->stream));
     HIP_TRY(hipStreamSynchronize(s_->cur->stream));
     for (auto& b : bufs_)
       if (b.out && b.pinned) std::memcpy(b.host, b.pinned, b.bytes);
@@ -919,70 +878,8 @@ class Stager {
     }
     b.dev = s_->cur->stage_buf[slot];
     bufs_.push_back(b);
-    if (copy_in) {
-      if (bytes >= kBounceMin && bounce_ready()) TRY_RC(copy_in_chunks(b));
-      else HIP_TRY(hipMemcpyAsync(b.dev, p, bytes, hipMemcpyHostToDevice, s_->cur->stream));
-    }
+    if (copy_in) HIP_TRY(hipMemcpyAsync(b.dev, p, bytes, hipMemcpyHostToDevice, s_->cur->stream));
     *dev = b.dev;
-    return HAMK_OK;
-  }
-  // the two pinned bounce buffers of this device, allocated at the first large host array
-  bool bounce_ready() {
-    DevState* d = s_->cur;
-    if (d->bounce_failed) return false;
-    if (d->bounce[0]) return true;
-    static const bool off = [] { const char* e = std::getenv("HAMK_BOUNCE"); return e && e[0] == '0'; }();
-    bool ok = !off;
-    for (int k = 0; k < 2 && ok; ++k)
-      ok = hipHostMalloc((void**)&d->bounce[k], kBounceChunk, hipHostMallocDefault) == hipSuccess &&
-           hipEventCreateWithFlags(&d->bounce_ev[k], hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
-      for (int k = 0; k < 2; ++k) {
-        if (d->bounce[k]) { hipHostFree(d->bounce[k]); d->bounce[k] = nullptr; }
-        if (d->bounce_ev[k]) { hipEventDestroy(d->bounce_ev[k]); d->bounce_ev[k] = nullptr; }
-      }
-      (void)hipGetLastError();
-      d->bounce_failed = true;
-    }
-    return ok;
-  }
-  // host -> device: chunk k is copied into bounce[k % 2] by the CPU while the DMA of chunk k - 1 runs
-  int copy_in_chunks(const Staged& b) {
-    DevState* d = s_->cur;
-    size_t k = 0;
-    for (size_t off = 0; off < b.bytes; off += kBounceChunk, ++k) {
-      const int slot = (int)(k & 1);
-      const size_t len = std::min(kBounceChunk, b.bytes - off);
-      if (bounce_used_[slot]) HIP_TRY(hipEventSynchronize(d->bounce_ev[slot]));      // its last DMA has read it
-      par_memcpy(d->bounce[slot], (const char*)b.host + off, len);
-      HIP_TRY(hipMemcpyAsync((char*)b.dev + off, d->bounce[slot], len, hipMemcpyHostToDevice, d->stream));
-      HIP_TRY(hipEventRecord(d->bounce_ev[slot], d->stream));
-      bounce_used_[slot] = true;
-    }
-    return HAMK_OK;
-  }
-  // device -> host: two DMAs in flight, the CPU empties a buffer as soon as its event fires
-  int copy_out(const Staged& b) {
-    DevState* d = s_->cur;
-    const size_t nchunk = (b.bytes + kBounceChunk - 1) / kBounceChunk;
-    auto issue = [&](size_t k) -> int {
-      const int slot = (int)(k & 1);
-      const size_t off = k * kBounceChunk, len = std::min(kBounceChunk, b.bytes - off);
-      HIP_TRY(hipMemcpyAsync(d->bounce[slot], (const char*)b.dev + off, len, hipMemcpyDeviceToHost, d->stream));
-      HIP_TRY(hipEventRecord(d->bounce_ev[slot], d->stream));
-      bounce_used_[slot] = true;
-      return HAMK_OK;
-    };
-    for (int slot = 0; slot < 2; ++slot)                   // the H2D copies that used the buffers are long done (the kernel ran after them)
-      if (bounce_used_[slot]) HIP_TRY(hipEventSynchronize(d->bounce_ev[slot]));
-    for (size_t k = 0; k < nchunk && k < 2; ++k) TRY_RC(issue(k));
-    for (size_t k = 0; k < nchunk; ++k) {
-      const int slot = (int)(k & 1);
-      const size_t off = k * kBounceChunk, len = std::min(kBounceChunk, b.bytes - off);
-      HIP_TRY(hipEventSynchronize(d->bounce_ev[slot]));
-      par_memcpy((char*)b.host + off, d->bounce[slot], len);
-      if (k + 2 < nchunk) TRY_RC(issue(k + 2));
-    }
     return HAMK_OK;
   }
   // bump allocation in the handle's pinned arena; every host-pointer call ends with a stream
@@ -1012,7 +909,6 @@ class Stager {
   bool host_;
   size_t pin_used_ = 0;
   size_t nstaged_ = 0;
-  bool bounce_used_[2] = {false, false};
   std::vector<Staged> bufs_;
 };
 }  // namespace

@@ -317,11 +317,10 @@ def test_host_pointer_paths_equal_device_path(api, systems, B):
     torch.cuda.synchronize()
 
 
-def test_large_host_arrays_cross_in_chunks(api, systems):
-    """Host arrays from 4 MiB cross PCIe in 16 MiB chunks through two pinned bounce buffers, a multi-threaded memcpy on one
-    while the DMA engine works on the other (hamk_api.cpp Stager::copy_in_chunks / copy_out).  67 MB per array here -- five
-    chunks with a ragged tail, four arrays in, four out over two calls -- against the device-pointer path, bitwise; then
-    the same handle on small arrays again (the pinned arena) and a mid-size one (plain staging)."""
+def test_large_host_arrays(api, systems):
+    """Host arrays far beyond the pinned arena (67 MB per array, a ragged size; staged through device memory with
+    hipMemcpyAsync -- 50 GB/s both ways from touched pageable memory on the MI355X boxes, scripts/pcie_rate.py) against the
+    device-pointer path, bitwise; then the same handle on small arrays again (the pinned arena) and a mid-size one."""
     import torch
     spec, s, o = systems["doublePendulum"]
     B = (1 << 22) + 7
