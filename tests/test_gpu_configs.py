@@ -111,6 +111,40 @@ ORACLE_BOUNDS = {"C3-twoBody": (1e-11, 1e-9), "C3-spring": (1e-11, 1e-9), "C4-th
                  "C5-chain8": (1e-9, 1e-6), "C5-chain16": (None, None), "C5-chain32": (None, None)}
 
 
+@pytest.mark.parametrize("name,B", [("chain8", 65536), ("chain16", 65536), ("chain32", 16384), ("threeBodyPolar", 262144)])
+def test_adaptive_stepper_at_config_size(api, oracle_lib, name, B):
+    """`stepHam dt` -- the reference's own stepper -- on the C4 / C5 ensembles at their sizes (chain32: a quarter of it),
+    where the parked adaptive kernels fill the CU's LDS on every CU at once: deterministic bit for bit, a sub-range computed
+    alone equals the same lanes of the full launch (same mapping pinned), and a strided sample takes exactly the oracle's
+    sub-steps to the oracle's states."""
+    import torch
+    spec = E.get(name)
+    s = api.system_from_spec(spec, {"mapping": api.system_from_spec(spec).options(B)["mapping"]})
+    assert s.options(B)["rkf_park"] == 1
+    o = oracle_lib.OracleSystem(spec)
+    dt = 2 * spec.dt
+    q, qd = E.sample_config(spec, 0, B)
+    if name.startswith("chain"):
+        qd = 0.3 * np.cos(np.arange(spec.n * B, dtype=np.float64).reshape(spec.n, B) * 0.7)
+    ph0 = api.toPhase(s, api.Config(torch.from_numpy(q).cuda(), torch.from_numpy(qd).cuda()))
+    a = api.stepHam(dt, s, ph0)
+    na, sa = s.last_nsub.clone(), s.last_status.clone()
+    b = api.stepHam(dt, s, ph0)
+    assert torch.equal(a.positions, b.positions) and torch.equal(a.momenta, b.momenta) and torch.equal(s.last_nsub, na)
+    assert int((sa & ~16).count_nonzero()) == 0 and int(na.min()) >= 3
+    lo = B // 3 + 1
+    hi = lo + B // 7 + 3
+    sub = api.stepHam(dt, s, api.Phase(ph0.positions[:, lo:hi].contiguous(), ph0.momenta[:, lo:hi].contiguous()))
+    assert torch.equal(sub.positions, a.positions[:, lo:hi]) and torch.equal(sub.momenta, a.momenta[:, lo:hi])
+    idx = np.arange(0, B, B // 48)[:48]
+    qs, ps = ph0.positions[:, idx].cpu().numpy(), ph0.momenta[:, idx].cpu().numpy()
+    sq, sp, sns = o.step_ham_batch(qs, ps, dt)
+    assert np.array_equal(na[idx].cpu().numpy(), sns)
+    e = max(relerr(a.positions[:, idx].cpu().numpy(), sq), relerr(a.momenta[:, idx].cpu().numpy(), sp))
+    record(test="adaptive_config_size", name=name, B=B, err=e, mean_substeps=float(na.double().mean()))
+    assert e < 1e-9, (name, e)
+
+
 @pytest.mark.parametrize("cid,name,B,nsteps,nsample,DRIFT_TOL", FULL, ids=[f[0] for f in FULL])
 def test_full_size(api, oracle_lib, cid, name, B, nsteps, nsample, DRIFT_TOL):
     import torch
