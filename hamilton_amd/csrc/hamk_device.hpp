@@ -1415,8 +1415,13 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
   __shared__ double rows[NL * D * 256];
   double* py = rows + threadIdx.x;                         // y[j]    at py[j * 256]
   double* pf = rows + D * 256 + threadIdx.x;               // dydt[j] at pf[j * 256]
-  constexpr int YN = 5, E = 6;                             // rows 0..4: k2..k6 (those that are not in LDS)
+  // rows 0..4: k2..k6 (those that are not in LDS), 5: the trial state, 6: the error combination -- unless k2 / k3 wait in
+  // LDS: stage 6 no longer needs k2 and has just read k3, so the trial state and the error combination take over their LDS
+  // rows (two scratch rows less per attempt: chain8-10 +4-5 % stepHam/s; in SCRATCH the same reuse makes the stores wait
+  // for the loads of the same addresses, chain16 -5 %: there they keep rows of their own)
   double v[7][D];
+#define HAMK_RKF_YN(j) ((NL >= 3) ? HAMK_RKF_LROW(2)[(j) * 256] : v[5][j])
+#define HAMK_RKF_E(j) ((NL >= 4) ? HAMK_RKF_LROW(3)[(j) * 256] : v[6][j])
   // k_{2 + KR} at the top of stage KR + 1: the result of the right-hand side just evaluated
   // (one base pointer per LDS row, each "array + constant + lane": offsets from a shared base beyond the 64 KiB a ds
   // instruction can encode make the compiler keep several derived bases alive through the right-hand side -- chain16: 66
@@ -1521,9 +1526,9 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
               ye[j] = hh * ((1.0 / 360.0) * f0 + (-128.0 / 4275.0) * k3 + (-2197.0 / 75240.0) * k4 + (1.0 / 50.0) * k5 + (2.0 / 55.0) * k6);
             }
 #pragma unroll
-            for (int j = 0; j < D; ++j) v[YN][j] = yt[j];
+            for (int j = 0; j < D; ++j) HAMK_RKF_YN(j) = yt[j];
 #pragma unroll
-            for (int j = 0; j < D; ++j) v[E][j] = ye[j];
+            for (int j = 0; j < D; ++j) HAMK_RKF_E(j) = ye[j];
             break;
           }
         }
@@ -1545,9 +1550,9 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
       double rmax = 2.2250738585072014e-308;
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        yn[j] = v[YN][j];
+        yn[j] = HAMK_RKF_YN(j);
         const double D0 = eps_rel * (fabs(yn[j]) + fabs(hh * out[j])) + eps_abs;
-        const double rr = fabs(v[E][j]) / fabs(D0);
+        const double rr = fabs(HAMK_RKF_E(j)) / fabs(D0);
         rmax = (rr > rmax) ? rr : rmax;
       }
       const double tnew = final_step ? ti : t + hh;
@@ -1596,6 +1601,8 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
   if (status) status[i] = st;
   if (nsub) nsub[i] = attempts;
 #undef HAMK_RKF_RECENT
+#undef HAMK_RKF_YN
+#undef HAMK_RKF_E
 #undef HAMK_RKF_K
 #undef HAMK_RKF_LROW
 }

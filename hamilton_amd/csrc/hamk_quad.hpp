@@ -928,8 +928,11 @@ HAMK_DEV void rkf45_body_parked(double* smem, const double* q0, const double* p0
 #define HAMK_RKF_K(KR, j) ((2 + (KR) < NL) ? HAMK_RKF_LROW(2 + (KR))[(j) * 256] : v[KR][j])      /* k_{2 + KR}[j] */
   double* py = rows + threadIdx.x;                         // y[j]    at py[j * 256]: [q of the lane's rows; p of the lane's rows]
   double* pf = rows + D * 256 + threadIdx.x;               // dydt[j] at pf[j * 256]
-  constexpr int YN = 4, E = 5;                             // rows 0..3: k2..k5 (those that are not in LDS)
-  double v[6][D];
+  // rows 0..3: k2..k5 (those that are not in LDS); the trial state and the error combination take over the rows of k2 and
+  // k3 (see hamk::rkf45_body_parked)
+  double v[4][D];
+#define HAMK_RKF_YN(j) HAMK_RKF_K(0, j)
+#define HAMK_RKF_E(j) HAMK_RKF_K(1, j)
   auto put_k = [&](int kr, const double (&x)[D]) {         // k_{2 + kr}; kr: a run-time value (the stage counter)
     if (NL > 2 && 2 + kr < NL) {
 #pragma unroll
@@ -1033,9 +1036,9 @@ HAMK_DEV void rkf45_body_parked(double* smem, const double* q0, const double* p0
                 ye[j] = hh * ((1.0 / 360.0) * f0 + (-128.0 / 4275.0) * k3 + (-2197.0 / 75240.0) * k4 + (1.0 / 50.0) * k5 + (2.0 / 55.0) * k6);
               }
 #pragma unroll
-              for (int j = 0; j < D; ++j) v[YN][j] = yt[j];
+              for (int j = 0; j < D; ++j) HAMK_RKF_YN(j) = yt[j];
 #pragma unroll
-              for (int j = 0; j < D; ++j) v[E][j] = ye[j];
+              for (int j = 0; j < D; ++j) HAMK_RKF_E(j) = ye[j];
               break;
             }
           }
@@ -1052,9 +1055,9 @@ HAMK_DEV void rkf45_body_parked(double* smem, const double* q0, const double* p0
         double rl = 2.2250738585072014e-308;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-          yn[j] = v[YN][j];
+          yn[j] = HAMK_RKF_YN(j);
           if (!w.owns(j < NR ? j : j - NR)) continue;
-          const double rj = fabs(v[E][j]) / fabs(eps_rel * (fabs(yn[j]) + fabs(hh * out[j])) + eps_abs);
+          const double rj = fabs(HAMK_RKF_E(j)) / fabs(eps_rel * (fabs(yn[j]) + fabs(hh * out[j])) + eps_abs);
           rl = (rj > rl) ? rj : rl;
         }
         const double rmax = qmax(rl);
@@ -1108,6 +1111,8 @@ HAMK_DEV void rkf45_body_parked(double* smem, const double* q0, const double* p0
     if (status) status[w.t] = stq;
     if (nsub) nsub[w.t] = attempts;
   }
+#undef HAMK_RKF_YN
+#undef HAMK_RKF_E
 #undef HAMK_RKF_K
 #undef HAMK_RKF_LROW
 }
