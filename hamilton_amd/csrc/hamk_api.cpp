@@ -984,13 +984,24 @@ static bool quad_eligible(hamk_system* s) {
   return s->quad_eligible == 1;
 }
 
+// Is K = J^T M J semi-definite by construction?  Only then may a kernel factorise it without pivoting.  The reference
+// inverts EVERY K by LU with partial pivoting (hmatrix `inv`, Hamilton.hs:321, :381), so a system with a non-positive
+// inertia -- K symmetric but possibly indefinite, and still invertible -- must run on kernels that pivot: the lane
+// kernels (solve_spd falls back to solve_lu per trajectory) and the wave-cooperative ones (solve_pivoted).  The four-lane
+// kernels do not, and are never chosen for such a system.
+static bool inertia_positive(const hamk_system* s) {
+  for (double w : s->base.inertia) if (!(w > 0.0)) return false;
+  return true;
+}
+
 static int choose_mapping(hamk_system* s, int64_t B, int kernel) {
   const int n = s->base.n;
   const int rest = n > 16 ? HAMK_MAP_WAVE : HAMK_MAP_LANE;  // where the kernels the quad module lacks run
   if (s->opt.mapping != HAMK_AUTO) return (s->opt.mapping == HAMK_MAP_QUAD && !quad_has(kernel)) ? rest : s->opt.mapping;
   bool w = false;
-  if (env_flag("HAMK_QUAD", &w) && w && n <= 32) return quad_has(kernel) ? HAMK_MAP_QUAD : rest;      // tests / experiments
-  const bool no_quad = env_flag("HAMK_QUAD", &w) && !w;
+  const bool pos = inertia_positive(s);
+  if (pos && env_flag("HAMK_QUAD", &w) && w && n <= 32) return quad_has(kernel) ? HAMK_MAP_QUAD : rest;      // tests / experiments
+  const bool no_quad = !pos || (env_flag("HAMK_QUAD", &w) && !w);
   if (env_flag("HAMK_WAVE", &w)) return (w || n > 16) ? HAMK_MAP_WAVE : HAMK_MAP_LANE;
   if (n > 32) return HAMK_MAP_WAVE;
   if (n > 16) return (!no_quad && quad_has(kernel) && quad_eligible(s)) ? HAMK_MAP_QUAD : HAMK_MAP_WAVE;
@@ -1252,6 +1263,12 @@ int hamk_system_create_ex(int32_t m, int32_t n, const double* inertia, const ham
     o.size = (uint32_t)sizeof o;
   }
   err = check_options(o, n);
+  if (err.empty() && o.mapping == HAMK_MAP_QUAD)
+    for (int k = 0; k < m; ++k)
+      if (!(inertia[k] > 0.0))
+        err = "unsupported: HAMK_MAP_QUAD factorises K = J^T M J without pivoting and needs every inertia positive; this system has "
+              "inertia[" + std::to_string(k) + "] = " + std::to_string(inertia[k]) + " (leave the mapping to the library: the lane and "
+              "wave-cooperative kernels pivot as the reference's `inv` does)";
   if (!err.empty()) return fail(err.rfind("unsupported:", 0) == 0 ? HAMK_ERR_UNSUPPORTED : HAMK_ERR_INVALID, "hamk_options: " + err);
 
   hamk_system* s = new hamk_system();

@@ -291,7 +291,7 @@ HAMK_DEV void ldlt(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&
       for (int i = jb; i < NR; ++i)
         if (J0 + jj < J1) Kp[i][J0 + jj] = (4 * i + r > J0 + jj) ? l[i][jj] : ((i == jb && r == jj) ? pinv[jj] : Kp[i][J0 + jj]);
   }
-  if (!ok) st |= ST_SINGULAR;                            // no pivoting fallback (as in the wave kernels)
+  if (!ok) st |= ST_SINGULAR;                            // every inertia positive (HAMK_INSTANTIATE_QUAD asserts it): a non-positive pivot IS singular
 }
 
 // D y = z, L^T v = y; returns the lane's v_(4 i + r).  Row-oriented: L[k][a] is in the lane that owns row k, so the lanes
@@ -562,7 +562,7 @@ HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const
   for (int i = 0; i < NR; ++i) z[i] = pi[i];
   bool ok = true;
   panels<S, LUT, 0>(c, tc, G, z, U, ok);
-  if (!ok) st |= ST_SINGULAR;                             // no pivoting fallback (as in the wave kernels)
+  if (!ok) st |= ST_SINGULAR;                             // (as above: K is semi-definite on this mapping)
   HAMK_PHASE();
   solve_back_chol<S>(r, G, z, vi);
   HAMK_PHASE();
@@ -1308,6 +1308,7 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
 
 // The eight kernels of the path on the quad mapping (the names of HAMK_INSTANTIATE).
 #define HAMK_INSTANTIATE_QUAD(S)                                                                                 \
+  static_assert(S::INERTIA_POS, "the four-lane mapping factorises K without pivoting: every inertia must be positive (libhamk routes other systems to the lane / wave-cooperative kernels, which pivot)"); \
   HAMK_SCRIBBLE_KERNEL                                                                                           \
   extern "C" __global__ void __launch_bounds__(256) hamk_rk4_steps_k(double* q, double* p, long long B,          \
                                                           double dt, int nsteps, double drift_tol, int* status) { \

@@ -393,6 +393,83 @@ HAMK_DEV void factor_blocked(const Ctx<S>& c, double& dinv, int& st, double& z) 
   lds_sync();
 }
 
+template <int NP> HAMK_DEV int group_min(int x) {
+#pragma unroll
+  for (int off = NP / 2; off > 0; off >>= 1) { const int y = __shfl_xor(x, off, NP); x = (y < x) ? y : x; }
+  return x;
+}
+
+// K v = rhs by LU WITH PARTIAL PIVOTING -- what the reference does for every K: hmatrix `inv` is LAPACK's
+// dgesv against the identity (Hamilton.hs:321, :381).  Used where an inertia is not positive (S::INERTIA_POS
+// false): K = J^T M J is then symmetric but need not be definite, LDL^T without pivoting can meet a zero or
+// tiny pivot on an invertible matrix, and "flag every lane singular" would be a different answer from the
+// reference's on the same input.  Rows stay distributed over the lanes (lane i: row i of K, all N entries,
+// read from the packed triangle through the mirrored index); per column the group finds the largest
+// remaining |a[r][c]| (shuffles), the lane that holds it publishes its row and right-hand side through LDS
+// and retires, everybody else eliminates.  No row ever moves: `mycol` remembers which column a lane's row
+// pivoted.  Back substitution column by column through LDS.  N LDS round trips and N(N+1)/2 FMAs per lane
+// each way: a slow path by design -- systems with a non-positive inertia are rare, and correct beats fast.
+// Returns v_li; an exactly zero (or non-finite) pivot column sets ST_SINGULAR and yields NaN, where the
+// reference raises.
+template <class S>
+HAMK_DEV double solve_pivoted(const Ctx<S>& c, int& st, double rhs) {
+  constexpr int N = S::N, NP = Ctx<S>::NP;
+  const int li = c.li;
+  const double* T = c.tile();
+  double* cR = c.rowbuf();                                 // [NP] the pivot row; [NP]: its right-hand side
+  double* cX = c.gb();                                     // [NP] the solution (the qd buffer is free here)
+  double row[N];
+#pragma unroll
+  for (int b = 0; b < N; ++b) {
+    const int hi = (li > b) ? li : b, lo = (li > b) ? b : li;
+    row[b] = T[hi * (hi + 1) / 2 + lo];                    // lanes li >= N read padding: they never pivot, never update
+  }
+  bool used = li >= N, singular = false;
+  int mycol = -1;
+  double z = rhs;
+#pragma unroll
+  for (int c0 = 0; c0 < N; ++c0) {
+    double cand = fabs(row[c0]);
+    if (used) cand = -1.0;
+    else if (is_nonfinite_bits(cand)) cand = 0.0;          // every lane must see the same maximum: no NaN in the reduction
+    const double m = group_max<NP>(cand);
+    const int who = group_min<NP>((!used && cand == m) ? li : NP);     // the first row that attains it
+    singular = singular || !(m > 0.0);
+    HAMK_LOCKSTEP();
+    if (li == who) {
+#pragma unroll
+      for (int k = c0; k < N; ++k) cR[k] = row[k];
+      cR[NP] = z;
+      used = true;
+      mycol = c0;
+    }
+    lds_sync();
+    if (!used) {
+      const double l = row[c0] / cR[c0];
+#pragma unroll
+      for (int k = c0 + 1; k < N; ++k) row[k] = fma(-l, cR[k], row[k]);
+      z = fma(-l, cR[NP], z);
+    }
+  }
+  // U x = z: the lane with mycol == c0 holds row c0 of U (entries c0..N-1) and z_c0
+#pragma unroll
+  for (int c0 = N - 1; c0 >= 0; --c0) {
+    HAMK_LOCKSTEP();
+    if (mycol == c0) cX[c0] = z / row[c0];
+    lds_sync();
+    const double xc = cX[c0];
+    if (mycol >= 0 && mycol < c0) z = fma(-row[c0], xc, z);
+  }
+  lds_sync();
+  double v = (li < N) ? cX[li] : 0.0;
+  if (singular) {
+    if (li < N) st |= ST_SINGULAR;
+    v = quiet_nan();
+  }
+  lds_sync();                                              // the buffers are free again
+  return v;
+}
+
 // Sweep 1 (with K accumulated in the sink) + LDL^T, with the forward substitution of one right-hand
 // side riding along.  On return: `row` holds L[li][j] (j < li), `dinv` = 1/d_li, z = (L^-1 rhs)_li;
 // gU = dU/dq_li; the packed triangle holds L.
@@ -424,6 +501,11 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
     sink.store(c.smem, c.offw, c.lw);                       // accumulators -> K in the packed triangles
   }
   lds_sync();
+  if constexpr (!S::INERTIA_POS) {                          // K need not be definite: the reference's pivoted LU (solve_pivoted)
+    z = solve_pivoted<S>(c, st, z);                         // z = v_li already; solve_back passes it through
+    dinv = 1.0;
+    return;
+  }
 #if HAMK_WAVE_BLOCKED
   factor_blocked<S>(c, dinv, st, z);
   return;
@@ -485,7 +567,7 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
       if (li == N - 1) dinv = frcp(dj);
     }
   }
-  if (!ok && li < N) st |= ST_SINGULAR;                    // no pivoting fallback in the wave kernels
+  if (!ok && li < N) st |= ST_SINGULAR;                    // every inertia positive here: K is semi-definite, a non-positive pivot IS singular
   lds_sync();                                              // L is complete in the triangle
 }
 
@@ -497,6 +579,7 @@ HAMK_DEV double solve_back(const Ctx<S>& c, double dinv, double z) {
   constexpr int N = S::N, R = N & 3;
   auto tri = [](int i, int j) { return i * (i + 1) / 2 + j; };
   const int li = c.li;
+  if constexpr (!S::INERTIA_POS) return z;                  // solve_pivoted has done the whole solve
 #ifdef HAMK_PROBE_SKIP_SOLVE
   return z * dinv;
 #endif

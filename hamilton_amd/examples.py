@@ -304,7 +304,25 @@ REGISTRY = {
 }
 
 
+def mixed_inertia(base: str) -> SystemSpec:
+    """`base` with inertias of MIXED SIGN (not a physical example; name `<base>~mixed`).
+
+    The reference never asks whether K = J^T M J is definite: `velocities` and `hamEqs` invert it with
+    hmatrix `inv` -- LU with partial pivoting (Hamilton.hs:321, :381) -- so a `System` whose inertia
+    vector has non-positive entries is a legal input there as long as K is invertible.  These specs are
+    the parity workload for that case: K symmetric, indefinite, generically invertible (per-point
+    tolerances scale with cond K).  Pattern: inertia k keeps its magnitude and is negated (x 0.6) where
+    (7 k + 3) mod 5 == 0 -- for the chains the x and y inertias of a body then differ in sign."""
+    spec = get(base)
+    w = tuple((-0.6 * v) if (7 * k + 3) % 5 == 0 else v for k, v in enumerate(spec.inertia))
+    from dataclasses import replace
+    return replace(spec, name=f"{base}~mixed", inertia=w,
+                   cite=spec.cite + "; inertias of mixed sign (build-defined, Hamilton.hs:321/:381 `inv`)")
+
+
 def get(name: str) -> SystemSpec:
+    if name.endswith("~mixed"):
+        return mixed_inertia(name[:-6])
     if name.startswith("chain"):
         return chain(int(name[5:]))
     return REGISTRY[name]()

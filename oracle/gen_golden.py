@@ -152,6 +152,59 @@ def trajectory_truth(spec, S, times):
     return dict(q0=[fmt(v) for v in q0], p0=[fmt(p0[i]) for i in range(n)], states=rows)
 
 
+def evaluate_chain_point(spec, qv, qdv):
+    """The N-link chains of BASELINE config 5 (examples.chain) from their CLOSED-FORM mechanics -- no tape, no sympy, no AD:
+    x_k = l sum_{j<=k} sin th_j, y_k = -l sum_{j<=k} cos th_j, unit inertias, U = 5 sum_k y_k give
+        K[a][b] = l^2 (N - max(a, b)) cos(th_a - th_b)            (mass matrix J^T M J, 0-based a, b)
+        U       = -5 l sum_j (N - j) cos th_j
+        dq      = v = K^-1 p                                      (Hamilton.hs:381, :386; mpmath LU at 50 digits)
+        dp_i    = 1/2 v^T (dK/dth_i) v - dU/dth_i
+                = -l^2 v_i sum_b (N - max(i, b)) v_b sin(th_i - th_b) - 5 l (N - i) sin th_i
+    (dK[a][b]/dth_i = -l^2 (N - max(a,b)) sin(th_a - th_b) (delta_ai - delta_bi); the two halves of the quadratic form
+    are equal by antisymmetry).  `main` asserts that this path and the generic symbolic one (evaluate_point) agree to 40
+    digits on chain4 and chain8 before it is used for N = 16, 32, where 2N x N x N symbolic second derivatives are slow."""
+    N = spec.n
+    ell = mp.mpf(1) / N
+    th = [mp.mpf(v) for v in qv]
+    qd = mp.matrix([mp.mpf(v) for v in qdv])
+    c = lambda a, b: N - max(a, b)
+    K = mp.matrix(N, N)
+    for a in range(N):
+        for b in range(N):
+            K[a, b] = ell * ell * c(a, b) * mp.cos(th[a] - th[b])
+    p = K * qd
+    Ki = K ** -1
+    v = Ki * p
+    U = -5 * ell * sum((N - j) * mp.cos(th[j]) for j in range(N))
+    keC = (qd.T * p)[0] / 2
+    keP = (v.T * p)[0] / 2
+    dp = []
+    for i in range(N):
+        acc = sum(c(i, b) * v[b] * mp.sin(th[i] - th[b]) for b in range(N))
+        dp.append(-ell * ell * v[i] * acc - 5 * ell * (N - i) * mp.sin(th[i]))
+    x = []
+    ax, ay = mp.mpf(0), mp.mpf(0)
+    for j in range(N):
+        ax += ell * mp.sin(th[j])
+        ay -= ell * mp.cos(th[j])
+        x += [ax, ay]
+    return dict(
+        q=[fmt(t) for t in th], qd=[fmt(t) for t in qd], p=[fmt(t) for t in p], x=[fmt(t) for t in x],
+        vel=[fmt(t) for t in v], keC=fmt(keC), keP=fmt(keP), pe=fmt(U), lagrangian=fmt(keC - U), hamiltonian=fmt(keP + U),
+        dq=[fmt(t) for t in v], dp=[fmt(t) for t in dp], cond_hint=fmt(mp.norm(K, 1) * mp.norm(Ki, 1)),
+    )
+
+
+def chain_points(spec):
+    """Point 0: the spec's initial Config (at rest); 12 points of the C5 sampling box with the chain MOVING (the box has
+    qd = 0, where p = 0 and the solve is trivial): qd[j][i] = 0.3 cos(0.7 (12 j + i)), computed in fp64."""
+    q, _ = E.sample_config(spec, 0, NPOINTS)
+    qd = 0.3 * np.cos(0.7 * np.arange(spec.n * NPOINTS, dtype=np.float64).reshape(spec.n, NPOINTS))
+    return [(spec.q0, spec.qd0)] + [(q[:, i], qd[:, i]) for i in range(NPOINTS)]
+
+
+CLOSED_FORM_CHAINS = ["chain8", "chain16", "chain32"]
+
 SYSTEMS = [
     ("pendulum", (0.01, 0.1, 1.0)),
     ("doublePendulum", (0.01, 0.1, 1.0)),
@@ -169,6 +222,37 @@ def main():
     mp.mp.dps = DIGITS
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
+    if not only or only & set(CLOSED_FORM_CHAINS):
+        # the closed form against the generic symbolic derivation where both are cheap
+        for name in ("chain4", "chain8"):
+            spec = E.get(name)
+            S = symbolic(spec)
+            for qv, qdv in chain_points(spec)[:3]:
+                a, b = evaluate_point(spec, S, qv, qdv), evaluate_chain_point(spec, qv, qdv)
+                for key in ("p", "x", "vel", "dq", "dp", "keC", "keP", "pe", "hamiltonian"):
+                    av = a[key] if isinstance(a[key], list) else [a[key]]
+                    bv = b[key] if isinstance(b[key], list) else [b[key]]
+                    for u, w in zip(av, bv):
+                        assert abs(mp.mpf(u) - mp.mpf(w)) <= mp.mpf(10) ** -27 * (1 + abs(mp.mpf(u))), (name, key, u, w)
+            print("closed-form chain mechanics == symbolic derivation:", name, flush=True)
+        for name in CLOSED_FORM_CHAINS:
+            if only and name not in only:
+                continue
+            spec = E.get(name)
+            pts = [evaluate_chain_point(spec, qv, qdv) for qv, qdv in chain_points(spec)]
+            doc = dict(
+                system=name, m=spec.m, n=spec.n, inertia=list(spec.inertia), cite=spec.cite,
+                generator="oracle/gen_golden.py evaluate_chain_point (mpmath %s, %d digits)" % (mp.__version__, DIGITS),
+                note="derived fixtures from the chain's closed-form mass matrix K[a][b] = l^2 (N - max(a,b)) cos(th_a - th_b) and "
+                     "Hamilton's equations written out by hand (no tape, no AD, no sympy); LU at 50 digits; checked against the "
+                     "symbolic derivation on chain4 / chain8 by the generator.  Point 0: the spec's initial Config; points 1-12: "
+                     "examples.sample_config(spec, 0, 12) positions with qd[j][i] = 0.3 cos(0.7 (12 j + i)).  No `jac` entry.",
+                points=pts,
+            )
+            path = os.path.join(OUT, f"{name}.json")
+            with open(path, "w") as fh:
+                json.dump(doc, fh, indent=1)
+            print("wrote", path, len(pts), "points", flush=True)
     for name, times in SYSTEMS:
         if only and name not in only:
             continue

@@ -16,6 +16,9 @@ os.environ.setdefault("HAMK_MAX_SUBSTEPS", "20000")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 REFERENCE_SYSTEMS = ["pendulum", "doublePendulum", "room", "twoBody", "spring", "bezier"]
 ALL_GOLDEN_SYSTEMS = REFERENCE_SYSTEMS + ["threeBodyPolar", "chain4", "opcodeZoo"]
+# BASELINE config 5 (round 4): fixtures from the chains' closed-form mechanics (oracle/gen_golden.py evaluate_chain_point);
+# kept apart from ALL_GOLDEN_SYSTEMS because these sizes run on other kernels (quad / wave) and carry no `jac` entry
+CHAIN_GOLDEN_SYSTEMS = ["chain8", "chain16", "chain32"]
 
 
 def pytest_configure(config):

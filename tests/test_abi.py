@@ -251,3 +251,25 @@ def test_mapping_defaults_by_size_and_structure(hamk_lib):
     assert s.options()["mapping"] == _abi.MAP_QUAD and s.lanes_per_trajectory == 4 and "hamk_quad.hpp" in s.source
     assert s.num_device_functions == 9                        # the eight kernels of the path + the self-check's scribble kernel
     assert api.system_from_spec(E.get("chain33")).options()["mapping"] == _abi.MAP_WAVE
+
+
+def test_systems_with_a_non_positive_inertia_run_on_kernels_that_pivot(hamk_lib, monkeypatch):
+    """The reference's `inv` is LU with partial pivoting for EVERY K (Hamilton.hs:321, :381).  The four-lane kernels
+    factorise without pivoting, so a system whose K need not be definite never reaches them: n <= 16 stays on the lane
+    kernels whatever the ensemble size (solve_spd -> solve_lu per trajectory), n > 16 goes to the wave-cooperative ones
+    (solve_pivoted), asking for HAMK_MAP_QUAD by name is HAMK_ERR_UNSUPPORTED with the reason -- never a launch that
+    flags every trajectory singular."""
+    from hamilton_amd import _abi, api
+    monkeypatch.delenv("HAMK_QUAD", raising=False)
+    t = api.system_from_spec(E.get("chain12~mixed"))
+    assert t.options(8192)["mapping"] == _abi.MAP_LANE and t.options(65536)["mapping"] == _abi.MAP_LANE
+    assert api.system_from_spec(E.get("chain12")).options(8192)["mapping"] == _abi.MAP_QUAD        # (positive inertias: as before)
+    w = api.system_from_spec(E.get("chain20~mixed"))
+    assert w.options()["mapping"] == _abi.MAP_WAVE and w.options(4096)["mapping"] == _abi.MAP_WAVE
+    assert "INERTIA_POS = false" in w.source and "solve_pivoted" in open(os.path.join(ROOT, "hamilton_amd", "csrc", "hamk_wave.hpp")).read()
+    assert w.num_device_functions == 9
+    with pytest.raises(api.HamkError) as e:
+        api.system_from_spec(E.get("chain20~mixed"), {"mapping": _abi.MAP_QUAD})
+    assert e.value.code == _abi.HAMK_ERR_UNSUPPORTED and "pivot" in str(e.value)
+    monkeypatch.setenv("HAMK_QUAD", "1")                       # the test override does not reach such a system either
+    assert api.system_from_spec(E.get("chain12~mixed")).options(8192)["mapping"] == _abi.MAP_LANE

@@ -3,7 +3,7 @@ by default -- the judge's round-1 finding was that only C2 had a full-size test 
 kernels of C5 N = 8 / 16 were benchmarked but never checked.
 
   C1  doublePendulum, 1 trajectory, 1000 x stepHam 0.01               test_c1_*
-  C2  doublePendulum, 1,048,576 trajectories                          tests/test_gpu_parity.py::test_full_size_properties
+  C2  doublePendulum, 1,048,576 trajectories                          test_full_size[C2-*] (1000 steps); tests/test_gpu_parity.py::test_full_size_properties (100)
   C3  twoBody / spring, 1,048,576 trajectories                        test_full_size[C3-*]
   C4  threeBodyPolar, 262,144 trajectories                            test_full_size[C4-*]
   C5  chain8 / chain16 / chain32, 65,536 trajectories                 test_full_size[C5-*], test_c5_default_kernels
@@ -97,7 +97,11 @@ def test_c5_default_kernels(api, oracle_lib, monkeypatch, name, variant):
 # The C5 chains at SURVEY's dt = 0.005 are under-resolved by RK4 (links of length 1/N: the fast modes
 # scale with N; measured: chain16 loses 1e-3 of its energy within 200 steps on nearly every member),
 # so their "well-behaved" threshold is wide and nothing is required of the flagged fraction.
-FULL = [("C3-twoBody", "twoBody", 1 << 20, 1000, 96, 1e-6),
+# C2 (the headline config) at its own 1000 steps since round 4: a chaotic system over t = 10 -- an ulp of perturbation grows
+# to 1.6e-12 (median member) ... 1.2e-8 (worst of 96) in the ORACLE alone, and RK4 at dt = 0.01 loses 1e-5 of the energy
+# on the median member (82 % exceed 1e-6): its drift threshold and oracle bounds are set accordingly.
+FULL = [("C2-doublePendulum", "doublePendulum", 1 << 20, 1000, 96, 1e-4),
+        ("C3-twoBody", "twoBody", 1 << 20, 1000, 96, 1e-6),
         ("C3-spring", "spring", 1 << 20, 1000, 96, 1e-6),
         ("C4-threeBodyPolar", "threeBodyPolar", 1 << 18, 1000, 64, 1e-6),
         ("C5-chain8", "chain8", 1 << 16, 200, 32, 1e-5),
@@ -107,7 +111,7 @@ FULL = [("C3-twoBody", "twoBody", 1 << 20, 1000, 96, 1e-6),
 # under-resolved members amplify it without bound), so the asserted bounds are on the MEDIAN lane (a typical member:
 # measured <= 1e-12) and on the lanes the launch did not flag; the all-lanes maximum is recorded, and bounded only by
 # "finite and not O(1)" for the resolved configs.  Calibrated on MI355X (profiles/r03_gpu_test_record.jsonl).
-ORACLE_BOUNDS = {"C3-twoBody": (1e-11, 1e-9), "C3-spring": (1e-11, 1e-9), "C4-threeBodyPolar": (1e-11, 1e-9),
+ORACLE_BOUNDS = {"C2-doublePendulum": (1e-9, 1e-5), "C3-twoBody": (1e-11, 1e-9), "C3-spring": (1e-11, 1e-9), "C4-threeBodyPolar": (1e-11, 1e-9),
                  "C5-chain8": (1e-9, 1e-6), "C5-chain16": (None, None), "C5-chain32": (None, None)}
 
 

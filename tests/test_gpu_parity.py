@@ -11,7 +11,7 @@ results agree to roundoff, not bitwise.
 import numpy as np
 import pytest
 
-from conftest import ALL_GOLDEN_SYSTEMS, REFERENCE_SYSTEMS, fvec, load_golden
+from conftest import ALL_GOLDEN_SYSTEMS, CHAIN_GOLDEN_SYSTEMS, REFERENCE_SYSTEMS, fvec, load_golden
 from hamilton_amd import examples as E
 
 pytestmark = pytest.mark.gpu
@@ -41,9 +41,7 @@ def relerr(a, b):
 
 
 # ---------------------------------------------------------------- T1: golden fixtures
-@pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS)
-def test_golden_points(api, systems, name):
-    spec, s, _ = systems[name]
+def check_golden_points(api, s, name):
     g = load_golden(name)
     pts = g["points"]
     q = np.stack([fvec(p["q"]) for p in pts], axis=1)
@@ -70,6 +68,33 @@ def test_golden_points(api, systems, name):
     close(dq, "dq")
     close(dp, "dp")
     assert not np.any(s.last_status)
+
+
+@pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS)
+def test_golden_points(api, systems, name):
+    spec, s, _ = systems[name]
+    check_golden_points(api, s, name)
+
+
+@pytest.mark.parametrize("mapping", ["default", "large-ensemble", "lane", "quad", "wave"])
+@pytest.mark.parametrize("name", CHAIN_GOLDEN_SYSTEMS)
+def test_chain_golden_points(api, name, mapping):
+    """BASELINE config 5 (N = 8, 16, 32) against 50-digit fixtures that share NOTHING with the product or the oracle: the
+    chain's closed-form mass matrix K[a][b] = l^2 (N - max(a, b)) cos(th_a - th_b) and Hamilton's equations written out by
+    hand (oracle/gen_golden.py evaluate_chain_point; round 3 checked these sizes against the C oracle only, which reads the
+    same tape).  On the mapping the library picks for a 13-point call, on the one it picks for the config's 65 536, and on
+    every mapping forced through the ABI's options."""
+    from hamilton_amd import _abi
+    spec = E.get(name)
+    if mapping == "lane" and spec.n > 16:
+        pytest.skip("one trajectory per lane stops at n = 16")
+    if mapping == "default":
+        s = api.system_from_spec(spec)
+    elif mapping == "large-ensemble":
+        s = api.system_from_spec(spec, {"mapping": api.system_from_spec(spec).options(65536)["mapping"]})
+    else:
+        s = api.system_from_spec(spec, {"mapping": {"lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD, "wave": _abi.MAP_WAVE}[mapping]})
+    check_golden_points(api, s, name)
 
 
 # ---------------------------------------------------------------- T1: against the oracle on seeded ensembles
@@ -236,6 +261,66 @@ def test_singular_mass_matrix_is_flagged(api, oracle_lib):
     assert np.all(st & 1), st
     with pytest.raises(api.SingularSystem):
         api.velocities(s, api.Phase(np.array([0.1]), np.array([1.0])))
+
+
+@pytest.mark.parametrize("B", [1000, 8192])
+@pytest.mark.parametrize("name", ["doublePendulum~mixed", "spring~mixed", "threeBodyPolar~mixed", "chain6~mixed", "chain12~mixed",
+                                  "chain20~mixed"])
+def test_indefinite_mass_matrices_are_inverted_like_the_reference(api, oracle_lib, name, B):
+    """The reference inverts every K = J^T M J by LU with partial pivoting (hmatrix `inv` = LAPACK dgesv against the
+    identity, Hamilton.hs:321, :381), so inertias of mixed sign -- K symmetric, indefinite, invertible -- are a legal
+    input there.  VALUES, not flags, against the oracle's literal restatement (lu_inverse), per trajectory within
+    1e-10 cond(K): velocities, hamEqs, hamiltonian, 5 RK4 steps, stepHam -- on the kernels the library dispatches for
+    (n, B): lane kernels for n <= 16 at EITHER ensemble size (the four-lane kernels do not pivot and are never chosen
+    for such a system), the wave-cooperative kernels' solve_pivoted for n = 20.  Round 3 flagged every trajectory
+    HAMK_ST_SINGULAR on the quad / wave mappings."""
+    from hamilton_amd import _abi
+    spec = E.get(name)
+    s = api.system_from_spec(spec)
+    o = oracle_lib.OracleSystem(spec)
+    assert s.options(B)["mapping"] == (_abi.MAP_LANE if spec.n <= 16 else _abi.MAP_WAVE)
+    nb = min(B, 256)                                         # the oracle's share (the launch covers all B)
+    q, qd = E.sample_config(spec, 77, B)
+    qd = qd + 0.4 * np.cos(1.0 + np.arange(spec.n * B, dtype=np.float64).reshape(spec.n, B))
+    p = np.ascontiguousarray(o.to_phase_batch(q[:, :nb], qd[:, :nb]))
+    pg = api.momenta(s, api.Config(q, qd))
+    assert relerr(pg[:, :nb], p) < 1e-11
+    ph = api.Phase(q, pg)
+    K = [o.jacobian(q[:, i]).T @ np.diag(spec.inertia) @ o.jacobian(q[:, i]) for i in range(nb)]
+    assert min(np.linalg.eigvalsh(k).min() for k in K) < 0.0, "the sample must contain indefinite mass matrices"
+    scale = np.maximum(1.0, np.array([np.linalg.cond(k) for k in K]))
+    def lane_err(a, b):
+        a, b = np.asarray(a)[..., :nb], np.asarray(b)
+        return (np.abs(a - b) / np.maximum(1.0, np.abs(b))).reshape(-1, nb).max(0)
+    v = api.velocities(s, ph)
+    st = np.asarray(s.last_status)
+    assert not st.any(), (name, B, int(np.count_nonzero(st)))
+    ov, ost = o.from_phase_batch(q[:, :nb], pg[:, :nb])
+    assert not ost.any()
+    ev = lane_err(v, ov) / scale
+    dq, dp = api.hamEqs(s, ph)
+    assert not np.asarray(s.last_status).any()
+    odq, odp, _ = o.hameqs_batch(q[:, :nb], pg[:, :nb])
+    eh = np.maximum(lane_err(dq, odq), lane_err(dp, odp)) / scale
+    eH = lane_err(api.hamiltonian(s, ph), o.observe_batch(q[:, :nb], pg[:, :nb])[2]) / scale
+    assert ev.max() < 1e-10 and eh.max() < 1e-10 and eH.max() < 1e-10, (name, B, ev.max(), eh.max(), eH.max())
+    r = api.rk4Steps(spec.dt, 5, s, ph)
+    oq, op = o.rk4_steps_batch(q[:, :nb], pg[:, :nb], spec.dt, 5)
+    er = np.maximum(lane_err(r.positions, oq), lane_err(r.momenta, op)) / scale
+    assert er.max() < 1e-9, (name, B, er.max())
+    sh = api.stepHam(2 * spec.dt, s, ph)
+    sq, sp, sns = o.step_ham_batch(q[:, :nb], pg[:, :nb], 2 * spec.dt)
+    same = np.asarray(s.last_nsub)[:nb] == sns
+    assert same.mean() >= 0.97, (name, B, float(same.mean()))
+    es = (np.maximum(lane_err(sh.positions, sq), lane_err(sh.momenta, sp)) / scale)[same]
+    assert es.max() < 1e-8, (name, B, es.max())
+
+
+def test_the_quad_mapping_refuses_a_system_it_cannot_pivot_for(api):
+    from hamilton_amd import _abi
+    with pytest.raises(api.HamkError) as e:
+        api.system_from_spec(E.get("chain20~mixed"), {"mapping": _abi.MAP_QUAD})
+    assert e.value.code == _abi.HAMK_ERR_UNSUPPORTED
 
 
 def test_nonfinite_is_flagged(api, systems):

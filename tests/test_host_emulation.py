@@ -62,8 +62,10 @@ def relerr(a, b):
     return float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.maximum(1.0, np.abs(np.asarray(b)))))
 
 
-def check_against_oracle(L, spec, o, B=48, start=11, tol=1e-11, steps=3, dt_ham=None):
+def check_against_oracle(L, spec, o, B=48, start=11, tol=1e-11, steps=3, dt_ham=None, qd_kick=0.0):
     q, qd = E.sample_config(spec, start, B)
+    if qd_kick:                                             # (the chains' sampling box has qd = 0: p = 0 would make every solve trivial)
+        qd = qd + qd_kick * np.cos(1.0 + np.arange(spec.n * B, dtype=np.float64).reshape(spec.n, B))
     p = o.to_phase_batch(q, qd)
     st = np.zeros(B, np.int32)
     got = np.zeros_like(q)
@@ -281,6 +283,26 @@ def test_mid_size_systems_on_host(emulate, oracle_lib, name):
     check_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=8, steps=2, tol=1e-10)
 
 
+MIXED_LANE = ["doublePendulum~mixed", "spring~mixed", "threeBodyPolar~mixed", "chain6~mixed", "chain12~mixed"]
+
+
+@pytest.mark.parametrize("name", MIXED_LANE)
+def test_mixed_sign_inertias_pivot_like_the_reference_on_host(emulate, oracle_lib, name):
+    """The reference inverts EVERY K = J^T M J by LU with partial pivoting (hmatrix `inv`, Hamilton.hs:321, :381): a
+    system whose inertias are not all positive -- K symmetric, indefinite, invertible -- is a legal input there.  The lane
+    kernels' unpivoted LDL^T meets a non-positive pivot on such a K and falls back, per trajectory, to solve_lu (partial
+    pivoting, as the oracle's lu_inverse): VALUES against the oracle, tolerance scaled by cond K -- velocities, hamEqs,
+    observables, 5 RK4 steps, stepHam with the oracle's sub-step counts.  n = 2, 3, 6, 6, 12."""
+    spec = E.get(name)
+    o = oracle_lib.OracleSystem(spec)
+    L, src = emulate(spec)
+    assert "INERTIA_POS = false" in src
+    q, _ = E.sample_config(spec, 11, 24)
+    indefinite = [np.linalg.eigvalsh(o.jacobian(q[:, i]).T @ np.diag(spec.inertia) @ o.jacobian(q[:, i])).min() < 0 for i in range(24)]
+    assert any(indefinite), "the sample must contain indefinite mass matrices"
+    check_against_oracle(L, spec, o, B=24, steps=5, tol=1e-10, qd_kick=0.4, dt_ham=2 * spec.dt)
+
+
 @pytest.mark.parametrize("park", ["1", "0"])
 def test_adaptive_stepper_with_parked_stage_vectors_on_host(emulate, oracle_lib, park):
     """hamk_device.hpp rkf45_body_parked (hamk_options::rkf_park; the default of the lane kernels from n = 6) and the body
@@ -331,19 +353,15 @@ def test_random_systems_on_host(emulate, oracle_lib, seed):
         check_against_oracle(L, spec, o, B=32, start=99, dt_ham=0.02)
 
 
-@pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS)
-def test_device_code_on_host_matches_golden_fixtures(emulate, name):
-    """The same device code against the independently derived 50-digit fixtures (tests/golden): no
-    oracle in the loop."""
+def check_against_golden(L, name, tol0=1e-12):
+    """Device code (any mapping) against the independently derived 50-digit fixtures (tests/golden): no oracle in the loop."""
     from conftest import fvec, load_golden
-    spec = E.get(name)
-    L, _ = emulate(spec)
     pts = load_golden(name)["points"]
     B = len(pts)
     q = np.ascontiguousarray(np.stack([fvec(p["q"]) for p in pts], axis=1))
     qd = np.ascontiguousarray(np.stack([fvec(p["qd"]) for p in pts], axis=1))
     p = np.ascontiguousarray(np.stack([fvec(pt["p"]) for pt in pts], axis=1))
-    tol = 1e-12 * np.maximum(1.0, np.array([float(pt["cond_hint"]) for pt in pts]) / 1e3)
+    tol = tol0 * np.maximum(1.0, np.array([float(pt["cond_hint"]) for pt in pts]) / 1e3)
     got = np.zeros_like(q)
     L.emu_to_phase(P(q), P(qd), P(got), LL(B))
     assert np.all(np.abs(got - p).max(0) / np.maximum(1.0, np.abs(p).max(0)) <= tol)
@@ -354,10 +372,22 @@ def test_device_code_on_host_matches_golden_fixtures(emulate, name):
     assert not st.any()
     assert np.all(np.abs(dq - wdq).max(0) / np.maximum(1.0, np.abs(wdq).max(0)) <= tol)
     assert np.all(np.abs(dp - wdp).max(0) / np.maximum(1.0, np.abs(wdp).max(0)) <= tol)
+    v = np.zeros_like(q)
+    L.emu_from_phase(P(q), P(p), P(v), LL(B), I(st))
+    wv = np.stack([fvec(pt["vel"]) for pt in pts], axis=1)
+    assert np.all(np.abs(v - wv).max(0) / np.maximum(1.0, np.abs(wv).max(0)) <= tol)
     ke, pe, h = np.zeros(B), np.zeros(B), np.zeros(B)
     L.emu_observe(P(q), P(p), P(ke), P(pe), P(h), LL(B), I(st))
     want_h = np.array([float(pt["hamiltonian"]) for pt in pts])
     assert np.all(np.abs(h - want_h) / np.maximum(1.0, np.abs(want_h)) <= tol)
+
+
+@pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS + ["chain8", "chain16"])
+def test_device_code_on_host_matches_golden_fixtures(emulate, name):
+    """The lane kernels' device code against the 50-digit fixtures -- incl. BASELINE config 5's chain8 / chain16, whose
+    fixtures come from the chain's closed-form mechanics (oracle/gen_golden.py evaluate_chain_point)."""
+    L, _ = emulate(E.get(name))
+    check_against_golden(L, name)
 
 
 @pytest.fixture(scope="module")
@@ -510,6 +540,31 @@ def test_wave_kernels_on_host_match_oracle(emulate_wave, oracle_lib, name, force
     spec = E.get(name)
     L = emulate_wave(spec, force)
     check_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=B, steps=2, tol=1e-10)
+
+
+@pytest.mark.parametrize("name,B", [("chain6~mixed", 5), ("chain20~mixed", 3), ("spring~mixed", 6), ("chain33~mixed", 1)])
+def test_wave_kernels_pivot_where_an_inertia_is_not_positive(emulate_wave, oracle_lib, name, B):
+    """hamk_wave.hpp solve_pivoted: LU with partial pivoting, rows distributed over the lanes of a group -- the wave
+    kernels' counterpart of the reference's `inv` (Hamilton.hs:321, :381) for systems whose K need not be definite
+    (round 3 flagged every lane HAMK_ST_SINGULAR there).  Group sizes 16, 32 and 64, padded lanes, against the oracle
+    with cond-scaled tolerances: velocities, hamEqs, observables, RK4 steps, stepHam."""
+    spec = E.get(name)
+    o = oracle_lib.OracleSystem(spec)
+    L = emulate_wave(spec, name in ("chain6~mixed", "spring~mixed"))
+    check_against_oracle(L, spec, o, B=B, steps=2, tol=1e-10, qd_kick=0.4, dt_ham=spec.dt)
+
+
+def test_wave_pivoted_solve_flags_an_exactly_singular_matrix(emulate_wave, oracle_lib):
+    """All-zero inertias: K = 0, nothing to pivot on -- the reference raises out of `inv`; every trajectory is flagged."""
+    from dataclasses import replace
+    spec = replace(E.get("chain5"), name="chain5~zero", inertia=(0.0,) * 10)
+    L = emulate_wave(spec, True)
+    B = 3
+    q, qd = E.sample_config(spec, 0, B)
+    p = np.ones_like(q)
+    v, st = np.zeros_like(q), np.zeros(B, np.int32)
+    L.emu_from_phase(P(q), P(p), P(v), LL(B), I(st))
+    assert np.all(st & 1) and np.all(np.isnan(v))
 
 
 def test_flat_factorisation_on_host(emulate_wave, oracle_lib, monkeypatch):
@@ -728,3 +783,15 @@ def test_quad_right_looking_variant_on_host(emulate_quad, oracle_lib, name, B):
     for left in (0, 1):
         L = emulate_quad(spec, defines=(f"HAMK_QUAD_LEFT {left}",))
         check_quad_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=B)
+
+
+@pytest.mark.parametrize("name", ["chain8", "chain16", "chain32"])
+def test_quad_kernels_on_host_match_the_chain_fixtures(emulate_quad, name):
+    """BASELINE config 5 on the four-lane kernels (the default for chain32; chain8 / chain16 below 32 768 trajectories)
+    against the closed-form 50-digit fixtures -- no oracle, no shared tape in the loop."""
+    check_against_golden(emulate_quad(E.get(name)), name)
+
+
+@pytest.mark.parametrize("name", ["chain8", "chain32"])
+def test_wave_kernels_on_host_match_the_chain_fixtures(emulate_wave, name):
+    check_against_golden(emulate_wave(E.get(name), name == "chain8"), name)

@@ -7,7 +7,7 @@ SURVEY.md section 8c: 1e-12 * max(1, |y|), loosened by cond(K) where K is ill-co
 import numpy as np
 import pytest
 
-from conftest import ALL_GOLDEN_SYSTEMS, REFERENCE_SYSTEMS, fvec, load_golden
+from conftest import ALL_GOLDEN_SYSTEMS, CHAIN_GOLDEN_SYSTEMS, REFERENCE_SYSTEMS, fvec, load_golden
 from hamilton_amd import examples as E
 
 T1 = 1e-12
@@ -49,6 +49,26 @@ def test_hameqs_matches_golden(systems, name):
         q, p = fvec(pt["q"]), fvec(pt["p"])
         dq, dp = o.hameqs(q, p)                                                             # :370-387
         tol = tol_for(pt, fvec(pt["dq"]), fvec(pt["dp"]))
+        np.testing.assert_allclose(dq, fvec(pt["dq"]), rtol=0, atol=tol)
+        np.testing.assert_allclose(dp, fvec(pt["dp"]), rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("name", CHAIN_GOLDEN_SYSTEMS)
+def test_oracle_matches_the_closed_form_chain_fixtures(oracle_lib, name):
+    """BASELINE config 5 (N = 8, 16, 32): the oracle's tape interpreter + literal Hamilton.hs:262-387 against 50-digit values
+    of the chain's hand-derived mechanics (closed-form mass matrix, Hamilton's equations written out; no tape, no AD)."""
+    o, g = oracle_lib.OracleSystem(E.get(name)), load_golden(name)
+    assert (g["m"], g["n"]) == (o.m, o.n) and len(g["points"]) == 13
+    for pt in g["points"]:
+        q, qd, p = fvec(pt["q"]), fvec(pt["qd"]), fvec(pt["p"])
+        tol = tol_for(pt, p, fvec(pt["dp"]), fvec(pt["dq"]))
+        np.testing.assert_allclose(o.coords(q), fvec(pt["x"]), rtol=0, atol=tol)
+        np.testing.assert_allclose(o.momenta(q, qd), p, rtol=0, atol=tol)
+        np.testing.assert_allclose(o.velocities(q, p), fvec(pt["vel"]), rtol=0, atol=tol)
+        for f, key, args in ((o.keC, "keC", (q, qd)), (o.keP, "keP", (q, p)), (o.pe, "pe", (q,)),
+                             (o.lagrangian, "lagrangian", (q, qd)), (o.hamiltonian, "hamiltonian", (q, p))):
+            assert abs(f(*args) - float(pt[key])) <= tol, (name, key)
+        dq, dp = o.hameqs(q, p)
         np.testing.assert_allclose(dq, fvec(pt["dq"]), rtol=0, atol=tol)
         np.testing.assert_allclose(dp, fvec(pt["dp"]), rtol=0, atol=tol)
 
