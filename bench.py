@@ -91,7 +91,7 @@ def parse():
     return a
 
 
-def cpu_baseline_leg(spec, s, dt, target_seconds):
+def cpu_baseline_leg(spec, s, dt, target_seconds, own_length=None):
     """Oracle (C restatement of the reference algorithm) on this box's host cores, on a bounded
     sample of the same workload -- all cores (`value`) and one thread (`single_thread`), SURVEY.md
     section 8d; also yields the metric's `max |dphase| vs CPU ref`."""
@@ -199,6 +199,25 @@ def cpu_baseline_leg(spec, s, dt, target_seconds):
                                    f"max_abs_dphase_{nsteps}_steps_all_lanes": rep2["max_all_lanes"],
                                    f"max_abs_dphase_{nsteps}_steps": rep2["max_unflagged_lanes"],
                                    f"median_abs_dphase_{nsteps}_steps_all_lanes": rep2["median_all_lanes"]}
+    # ... and at the launch's OWN length (SURVEY 8d nsteps: 1000 for C2-C4, 200 for C5 -- what one timed launch does), on a
+    # small sample: all-lanes figure, the chaotic growth of rounding over the config's whole time span included
+    if own_length and own_length != nsteps:
+        S3 = int(min(S, max(32, S * nsteps // (4 * own_length))))
+        S3 -= S3 % 32
+        q3, p3 = q[:, :S3].copy(), p[:, :S3].copy()
+        t0 = time.perf_counter()
+        r3q, r3p = o.rk4_steps_batch(q3, p3, dt, own_length)
+        el3 = time.perf_counter() - t0
+        ph3 = api.rk4Steps(dt, own_length, s, api.Phase(torch.from_numpy(q3).cuda(), torch.from_numpy(p3).cuda()), drift_tol=1e-6)
+        st3 = s.last_status.cpu().numpy()
+        _, rep3 = lane_report(ph3.positions.cpu().numpy(), ph3.momenta.cpu().numpy(), r3q, r3p, st3)
+        parity["own_length"] = {"steps": own_length, "trajectories": S3, "cpu_seconds": el3,
+                                f"max_abs_dphase_{own_length}_steps_all_lanes": rep3["max_all_lanes"],
+                                f"median_abs_dphase_{own_length}_steps_all_lanes": rep3["median_all_lanes"],
+                                f"p99_abs_dphase_{own_length}_steps_all_lanes": rep3["p99_all_lanes"],
+                                f"max_abs_dphase_{own_length}_steps": rep3["max_unflagged_lanes"],
+                                "unflagged_lanes": rep3["unflagged_lanes"],
+                                "note": "one timed launch's worth of steps; all lanes, then the lanes not flagged at drift 1e-6"}
     return base, parity
 
 
@@ -256,17 +275,18 @@ def c1_leg(spec, s):
     t_it = time.perf_counter() - t0
     same = bool(np.array_equal(it.positions, gq) and np.array_equal(it.momenta, gp))
     return {"workload": "doublePendulum, 1 trajectory, 1000 x stepHam 0.01 (BASELINE.json configs[0])",
-            "gpu_us_per_call": t_it * 1e3, "gpu_us_per_call_separate_launches": t_gpu * 1e3, "cpu_oracle_us_per_call": t_cpu * 1e3,
+            "gpu_us_per_call": t_gpu * 1e3, "gpu_us_per_call_fused": t_it * 1e3, "cpu_oracle_us_per_call": t_cpu * 1e3,
             "one_launch_bit_identical_to_1000_calls": same,
             "max_abs_dphase_after_1000_calls": float(max(np.max(np.abs(gq - oq)), np.max(np.abs(gp - op)))),
-            "note": "gpu_us_per_call: the 1000 calls as one launch of hamk_step_ham_iterate (host-pointer call, pinned arena, one "
-                    "synchronisation); _separate_launches: one launch + one sync per call through the Python mirror of the C ABI"}
+            "note": "gpu_us_per_call: one launch + one synchronisation per call through the Python mirror of the C ABI (what BASELINE "
+                    "config 1 measures; comparable round over round); _fused: the same 1000 calls as ONE launch of hamk_step_ham_iterate"}
 
 
 def stepham_bench(a, s, spec, dt, state, dist, dev, rank, world):
     """Secondary: the reference's OWN stepper over the ensemble -- stepHam(dt) calls/s (GSL-semantics adaptive RKF45 per
     lane, Hamilton.hs:390-402, :443-448).  One bench step = one launch = one stepHam(dt) of every trajectory."""
     ph = state
+    s.describe_batch(ph.positions.shape[1])                  # the specialisation a launch over THIS shard uses (ADVICE r3)
     K = max(1, a.calls_per_launch)
     step = (lambda x: api.stepHam(dt, s, x, inplace=True)) if K == 1 else (lambda x: api.iterateStepHam(dt, K, s, x, inplace=True))
     for _ in range(a.warmup):
@@ -388,9 +408,14 @@ def main():
     else:
         lo, hi = ensemble.weak_bounds(a.batch, rank)
     B = hi - lo
-    q_h, qd_h = examples.sample_config(spec, lo, hi - lo)
-    q = torch.from_numpy(q_h).to(dev)
-    qd = torch.from_numpy(qd_h).to(dev)
+    if a.scaling == "strong":
+        # every shard on the mapping the library picks for the WHOLE ensemble: any G reproduces the 1-GPU bits
+        # (hamk_options::ensemble_size; with the choice left per launch a small shard of a mid-size system changes kernels)
+        ensemble.pin_for_ensemble(s, a.batch)
+    # initial Configs drawn ON THE DEVICE from the global trajectory index (hamk_sample_batch): no host array,
+    # no scatter; the same bits as examples.sample_config(spec, lo, B) on any shard layout
+    cfg0 = api.sampleConfig(s, spec.q_box, spec.qd_box, lo, B, examples.SEED, dev)
+    q, qd = cfg0.positions, cfg0.velocities
     ph = api.toPhase(s, api.Config(q, qd))               # momenta on device (Hamilton.hs:279-284)
     q, p = ph.positions.clone(), ph.momenta.clone()
     h0 = api.hamiltonian(s, api.Phase(q, p)).clone()
@@ -523,8 +548,10 @@ def main():
         }
         if gather_ms is not None:
             out["gather_ms"] = gather_ms
+            out["rccl"] = {"world": dist.get_world_size(), "backend": dist.get_backend(),
+                           "collectives": "barrier + max-over-ranks timing + ONE all_gather of the final state after the timed region; none on the data path"}
         if world == 1 and not a.no_cpu_baseline:
-            base, parity = cpu_baseline_leg(spec, s, dt, a.cpu_seconds)
+            base, parity = cpu_baseline_leg(spec, s, dt, a.cpu_seconds, a.rk4_per_step)
             base["reference_haskell"] = probe_reference_toolchain()
             out["cpu_baseline"] = base
             out["parity"] = parity

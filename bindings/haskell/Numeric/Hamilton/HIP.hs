@@ -51,6 +51,8 @@ module Numeric.Hamilton.HIP
   , DeviceEnsemble
   , setDevice
   , uploadEnsemble
+  , sampleEnsembleDevice
+  , setEnsembleSize
   , downloadEnsemble
   , rk4StepsDevice
   , stepHamDevice
@@ -113,21 +115,27 @@ foreign import ccall safe "hamk_system_create_ex"
 --   (@HAMK_MAP_*@, @HAMK_AD_*@, @HAMK_BODY_*@, @HAMK_TRIG_*@, @HAMK_ON@ = 1 / @HAMK_OFF@ = 2).
 data Options = Options
   { optMapping, optAdMode, optRk4Body, optRkfBody, optTrig, optGslApi, optSelfCheck, optBuild
-  , optWaveBlocked, optRk4MinWaves, optKReassoc, optRk4Park, optMaxSubsteps, optCache :: Int32 }
+  , optWaveBlocked, optRk4MinWaves, optKReassoc, optRk4Park, optMaxSubsteps, optCache :: Int32
+  , optLanesPerTrajectory :: Int32   -- ^ OUTPUT of @hamk_system_get_options@: 1, 4, 16, 32 or 64
+  , optRkfPark :: Int32              -- ^ the adaptive stepper's vectors parked in LDS / a private array (ON / OFF / AUTO)
+  , optEnsembleSize :: Int64         -- ^ size of the WHOLE ensemble the handle's launches are pieces of: the mapping is chosen
+                                     --   for it, so any shard layout reproduces the one-launch bits; 0 = per launch
+  }
 
 defaultOptions :: Options
-defaultOptions = Options 0 0 0 0 0 0 0 0 0 0 0 0 0 0
+defaultOptions = Options 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0
 
 instance Storable Options where
-  sizeOf _ = 128                                   -- uint32 size, 14 choices, lanes_per_trajectory (output), rkf_park (left AUTO), reserved[15]
-  alignment _ = 4
+  sizeOf _ = 128                                   -- uint32 size, 14 choices, lanes_per_trajectory, rkf_park, pad, int64 ensemble_size, reserved[12]
+  alignment _ = 8
   peek p = Options <$> f 4 <*> f 8 <*> f 12 <*> f 16 <*> f 20 <*> f 24 <*> f 28 <*> f 32 <*> f 36 <*> f 40 <*> f 44
-                   <*> f 48 <*> f 52 <*> f 56
+                   <*> f 48 <*> f 52 <*> f 56 <*> f 60 <*> f 64 <*> peekByteOff p 72
     where f = peekByteOff p
-  poke p (Options a b c d e g h i j k l m' n' o') = do
+  poke p (Options a b c d e g h i j k l m' n' o' lanes park ens) = do
     mapM_ (\off -> pokeByteOff p off (0 :: Int32)) [0, 4 .. 124]
     pokeByteOff p 0 (128 :: Word32)
-    mapM_ (\(off, v) -> pokeByteOff p off v) (zip [4, 8 ..] [a, b, c, d, e, g, h, i, j, k, l, m', n', o'])
+    mapM_ (\(off, v) -> pokeByteOff p off v) (zip [4, 8 ..] [a, b, c, d, e, g, h, i, j, k, l, m', n', o', lanes, park])
+    pokeByteOff p 72 ens
 foreign import ccall "&hamk_system_destroy"
   p_system_destroy :: FunPtr (Ptr HamkSystem -> IO ())
 foreign import ccall safe "hamk_to_phase_batch"
@@ -164,6 +172,11 @@ foreign import ccall safe "hamk_memcpy"
   c_memcpy :: Ptr Double -> Ptr Double -> Int64 -> Int32 -> IO CInt
 foreign import ccall safe "hamk_gather_batch"
   c_gather :: Int32 -> Int32 -> Ptr Int64 -> Ptr (Ptr Double) -> Ptr Double -> Int32 -> IO CInt
+foreign import ccall unsafe "hamk_system_set_ensemble_size"
+  c_system_set_ensemble_size :: Ptr HamkSystem -> Int64 -> IO CInt
+foreign import ccall safe "hamk_sample_batch"
+  c_sample_batch :: Ptr HamkSystem -> Int64 -> Int64 -> Word64 -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double
+                 -> Ptr Double -> Ptr Double -> Int32 -> IO CInt
 foreign import ccall unsafe "hamk_system_set_gsl_api"
   c_set_gsl_api :: Ptr HamkSystem -> Int32 -> IO CInt
 foreign import ccall safe "hamk_rk4_steps_checked"
@@ -513,6 +526,30 @@ downloadEnsemble (DeviceEnsemble b dq dp) = do
     c_memcpy pq a (fromIntegral (8 * cnt)) 1 >>= check "download"   -- HAMK_COPY_D2H
     c_memcpy pp c (fromIntegral (8 * cnt)) 1 >>= check "download"
   Ensemble b <$> VS.unsafeFreeze q <*> VS.unsafeFreeze p
+
+-- | Initial conditions of trajectories @first .. first + b - 1@ of an ensemble, drawn ON THE DEVICE from the global
+--   trajectory index (@hamk_sample_batch@: per-index splitmix64, uniform boxes @(lo, hi)@ per coordinate for positions
+--   and velocities), then 'toPhase' there: a shard of a multi-GPU run needs no host array and no scatter, and every
+--   shard layout draws the same bits.  No reference counterpart (one trajectory from a CLI Config, Examples.hs:230-359).
+sampleEnsembleDevice :: forall m n. KnownNat n => HipSystem m n -> [(Double, Double)] -> [(Double, Double)] -> Int -> Int -> Word64
+                     -> IO (DeviceEnsemble n)
+sampleEnsembleDevice (HipSystem h) qBox qdBox first b seed = do
+  let n = fromIntegral (natVal (Proxy @n)) :: Int
+  when (length qBox /= n || length qdBox /= n) $ throwIO (userError "sampleEnsembleDevice: the boxes need n (lo, hi) pairs")
+  dq <- deviceArray (n * b); dv <- deviceArray (n * b); dp <- deviceArray (n * b)
+  withForeignPtr h $ \s -> withForeignPtr dq $ \pq -> withForeignPtr dv $ \pv -> withForeignPtr dp $ \pp ->
+    withArray (map fst qBox) $ \ql -> withArray (map snd qBox) $ \qh -> withArray (map fst qdBox) $ \vl -> withArray (map snd qdBox) $ \vh -> do
+      c_sample_batch s (fromIntegral b) (fromIntegral first) seed ql qh vl vh pq pv memDevice >>= check "sampleEnsemble"
+      c_to_phase s (fromIntegral b) pq pv pp memDevice >>= check "toPhase"
+      c_synchronize s >>= check "synchronize"
+  return (DeviceEnsemble b dq dp)
+
+-- | State the size of the WHOLE ensemble this system's launches are pieces of (@hamk_system_set_ensemble_size@): every
+--   shard is then computed by the mapping the library picks for the whole, and any shard layout -- any number of GPUs, a
+--   run resumed with another -- reproduces the one-launch bits.  0: back to the per-launch choice.
+setEnsembleSize :: HipSystem m n -> Int -> IO ()
+setEnsembleSize (HipSystem h) total = withForeignPtr h $ \s ->
+  c_system_set_ensemble_size s (fromIntegral total) >>= check "setEnsembleSize"
 
 -- | k classic RK4 steps, in place in HBM (the BASELINE.json hot loop).
 rk4StepsDevice :: forall m n. KnownNat n => Double -> Int -> HipSystem m n -> DeviceEnsemble n -> IO ()

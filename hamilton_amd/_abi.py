@@ -50,18 +50,19 @@ class HamkOptions(ctypes.Structure):
                 ("gsl_api", ctypes.c_int32), ("self_check", ctypes.c_int32), ("build", ctypes.c_int32),
                 ("wave_blocked", ctypes.c_int32), ("rk4_min_waves", ctypes.c_int32), ("k_reassoc", ctypes.c_int32),
                 ("rk4_park", ctypes.c_int32), ("max_substeps", ctypes.c_int32), ("cache", ctypes.c_int32),
-                ("lanes_per_trajectory", ctypes.c_int32), ("rkf_park", ctypes.c_int32), ("reserved", ctypes.c_int32 * 15)]
+                ("lanes_per_trajectory", ctypes.c_int32), ("rkf_park", ctypes.c_int32), ("_align", ctypes.c_int32),
+                ("ensemble_size", ctypes.c_int64), ("reserved", ctypes.c_int32 * 12)]
 
     def __init__(self, **kw):
         super().__init__()
         self.size = ctypes.sizeof(HamkOptions)
         for k, v in kw.items():
-            if k not in dict(self._fields_) or k in ("size", "reserved"):
+            if k not in dict(self._fields_) or k in ("size", "reserved", "_align"):
                 raise TypeError(f"hamk_options has no field {k!r}")
             setattr(self, k, int(v))
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k not in ("size", "reserved")}
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k not in ("size", "reserved", "_align")}
 
 
 # name -> (restype, argtypes); mirrors include/hamk.h declaration by declaration
@@ -75,6 +76,7 @@ SIGNATURES = {
     "hamk_options_init": (None, [ctypes.POINTER(HamkOptions)]),
     "hamk_system_get_options": (ctypes.c_int, [_h, _i64, ctypes.POINTER(HamkOptions)]),
     "hamk_system_describe_batch": (ctypes.c_int, [_h, _i64]),
+    "hamk_system_set_ensemble_size": (ctypes.c_int, [_h, _i64]),
     "hamk_system_destroy": (None, [_h]),
     "hamk_system_dims": (ctypes.c_int, [_h, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "hamk_set_stream": (ctypes.c_int, [_h, ctypes.c_void_p]),
@@ -89,6 +91,8 @@ SIGNATURES = {
     "hamk_observe_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _dp, _dp, _dp, _ip, _i32]),
     "hamk_observe_config_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _dp, _dp, _i32]),
     "hamk_hameqs_batch": (ctypes.c_int, [_h, _i64, _dp, _dp, _dp, _dp, _ip, _i32]),
+    "hamk_sample_batch": (ctypes.c_int, [_h, _i64, _i64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _dp, _dp, _i32]),
     "hamk_rk4_steps": (ctypes.c_int, [_h, _i64, _dp, _dp, _f64, _i32, _ip, _i32]),
     "hamk_rk4_steps_checked": (ctypes.c_int, [_h, _i64, _dp, _dp, _f64, _i32, _f64, _ip, _i32]),
     "hamk_system_set_gsl_api": (ctypes.c_int, [_h, _i32]),

@@ -200,6 +200,13 @@ class System:
         _abi.check(_abi.lib().hamk_system_get_options(self._h, int(B), ctypes.byref(o)))
         return o.as_dict()
 
+    def set_ensemble_size(self, total: int):
+        """The size of the WHOLE ensemble this handle's launches are pieces of (hamk_system_set_ensemble_size): the library
+        then picks the mapping for that size instead of each launch's own -- shards, chunks and resumed runs reproduce the
+        one-launch bits whatever the split.  0: back to per-launch choice."""
+        _abi.check(_abi.lib().hamk_system_set_ensemble_size(self._h, int(total)))
+        return self
+
     def describe_batch(self, B: int = -1):
         """`source`, `build_info`, `code_size`, `code_object`, `kernel_bytes` below describe the specialisation a launch
         over B trajectories uses (default: the one built at creation = the large-ensemble one)."""
@@ -400,6 +407,29 @@ def hamEqs(s: System, ph: Phase):
         _abi.check(_abi.lib().hamk_hameqs_batch(s._h, qa.B, qa.ptr, pa.ptr, _ptr(dq), _ptr(dp), _ptr(st), qa.mem))
     s._after(st, qa.single, "hamEqs")
     return _shape_out(dq, qa.single), _shape_out(dp, qa.single)
+
+
+def sampleConfig(s: System, q_box, qd_box, start: int, count: int, seed: int, device=None) -> Config:
+    """Initial Configs of trajectories start .. start + count - 1 of an ensemble, drawn ON THE DEVICE from the global index
+    (hamk_sample_batch): uniform boxes q_box / qd_box = n pairs (lo, hi).  Same bits as
+    `examples.sample_config` for any (start, count): shards need no host array and no scatter.  device: a torch CUDA
+    device (tensors stay in HBM) or None (numpy arrays through the host-staged path)."""
+    n = s.n
+    if len(q_box) != n or len(qd_box) != n:
+        raise ValueError(f"boxes must have {n} (lo, hi) pairs")
+    arr = lambda xs: (ctypes.c_double * n)(*[float(x) for x in xs])
+    qlo, qhi = arr([b[0] for b in q_box]), arr([b[1] for b in q_box])
+    dlo, dhi = arr([b[0] for b in qd_box]), arr([b[1] for b in qd_box])
+    if device is not None:
+        dev = torch.device(device)
+        q = torch.empty((n, int(count)), dtype=torch.float64, device=dev)
+        qd = torch.empty_like(q)
+    else:
+        q, qd = np.empty((n, int(count))), np.empty((n, int(count)))
+    qa = _Arr(q, n, "positions")
+    with s._on(qa):
+        _abi.check(_abi.lib().hamk_sample_batch(s._h, int(count), int(start), int(seed), qlo, qhi, dlo, dhi, _ptr(q), _ptr(qd), qa.mem))
+    return Config(q, qd)
 
 
 # ---------------------------------------------------------------------------------------

@@ -36,6 +36,10 @@ static const char kQuadHeader[] =
 #include "hamk_quad_src.inc"
     ;
 
+static const char kSampleSource[] =
+#include "hamk_sample_src.inc"
+    ;
+
 static thread_local std::string g_last_error;
 
 static int fail(int code, const std::string& msg) {
@@ -113,12 +117,16 @@ struct DevState {
   char* pin = nullptr;          // host address
   char* pin_dev = nullptr;      // the same block as the device sees it
   bool pin_failed = false;
+  // hamk_sample_batch's kernel (hamk_sample.hpp; one module per process, loaded per device on first use)
+  hipModule_t sample_module = nullptr;
+  hipFunction_t sample_fn = nullptr;
   // small device scratch for evolveHam's time grid
   double* d_ts = nullptr;
   size_t d_ts_cap = 0;
   std::vector<double> h_ts;
   void release() {
     for (DevModule& m : mod) m.unload();
+    if (sample_module) { hipModuleUnload(sample_module); sample_module = nullptr; sample_fn = nullptr; }
     if (d_ts) { hipFree(d_ts); d_ts = nullptr; d_ts_cap = 0; }
     for (void*& b : stage_buf) if (b) { hipFree(b); b = nullptr; }
     stage_cap.assign(stage_cap.size(), 0);
@@ -139,6 +147,7 @@ struct hamk_system {
   int max_substeps = 1 << 24;
   bool self_check_on = true, cache_on = true;
   int quad_eligible = -1;      // -1: not analysed yet
+  int64_t ensemble_size = 0;   // hamk_options::ensemble_size: AUTO picks the mapping for THIS size instead of a launch's own B
   DevModule& mod() { return cur->mod[curv->mapping]; }
 };
 
@@ -965,6 +974,7 @@ static std::string check_options(const hamk_options& o, int n) {
     if (!in(v, {HAMK_AUTO, HAMK_ON, HAMK_OFF})) return "switches must be HAMK_AUTO, HAMK_ON or HAMK_OFF";
   if (o.rk4_min_waves < 0 || o.rk4_min_waves > 8) return "rk4_min_waves must be 0 (auto) .. 8";
   if (o.max_substeps < 0) return "max_substeps must be >= 0";
+  if (o.ensemble_size < 0) return "ensemble_size must be >= 0";
   return std::string();
 }
 
@@ -998,6 +1008,7 @@ static int choose_mapping(hamk_system* s, int64_t B, int kernel) {
   const int n = s->base.n;
   const int rest = n > 16 ? HAMK_MAP_WAVE : HAMK_MAP_LANE;  // where the kernels the quad module lacks run
   if (s->opt.mapping != HAMK_AUTO) return (s->opt.mapping == HAMK_MAP_QUAD && !quad_has(kernel)) ? rest : s->opt.mapping;
+  if (s->ensemble_size > 0) B = s->ensemble_size;           // the launch is a piece of a larger ensemble: one mapping for all pieces
   bool w = false;
   const bool pos = inertia_positive(s);
   if (pos && env_flag("HAMK_QUAD", &w) && w && n <= 32) return quad_has(kernel) ? HAMK_MAP_QUAD : rest;      // tests / experiments
@@ -1284,6 +1295,7 @@ int hamk_system_create_ex(int32_t m, int32_t n, const double* inertia, const ham
   s->self_check_on = o.self_check != HAMK_OFF;
   if (o.self_check == HAMK_AUTO) if (const char* e = std::getenv("HAMK_SELFCHECK")) if (e[0] == '0') s->self_check_on = false;
   s->cache_on = o.cache != HAMK_OFF;
+  s->ensemble_size = o.ensemble_size;
   s->max_substeps = o.max_substeps > 0 ? o.max_substeps : (1 << 24);
   if (o.max_substeps == HAMK_AUTO)                          // test suites: a kernel gone wrong must end, not spin through 16M attempts per lane
     if (const char* e = std::getenv("HAMK_MAX_SUBSTEPS")) { const long k = std::atol(e); if (k > 0 && k < (1L << 24)) s->max_substeps = (int)k; }
@@ -1333,6 +1345,7 @@ int hamk_system_get_options(hamk_system* s, int64_t B, hamk_options* r) {
   r->rkf_park = d.rkf_park ? HAMK_ON : HAMK_OFF;
   r->max_substeps = s->max_substeps;
   r->cache = s->cache_on ? HAMK_ON : HAMK_OFF;
+  r->ensemble_size = s->ensemble_size;
   r->lanes_per_trajectory = v->mapping == HAMK_MAP_LANE ? 1 : (v->mapping == HAMK_MAP_QUAD ? 4 : (d.n <= 16 ? 16 : d.n <= 32 ? 32 : 64));
   return HAMK_OK;
 }
@@ -1342,6 +1355,13 @@ int hamk_system_describe_batch(hamk_system* s, int64_t B) {
   Variant* v = nullptr;
   TRY(variant_for(s, B < 0 ? INT64_MAX : B, K_RK4, &v));
   s->info = v;
+  return HAMK_OK;
+}
+
+int hamk_system_set_ensemble_size(hamk_system* s, int64_t B_total) {
+  if (!s) return fail(HAMK_ERR_INVALID, "null system handle");
+  if (B_total < 0) return fail(HAMK_ERR_INVALID, "negative ensemble size");
+  s->ensemble_size = B_total;
   return HAMK_OK;
 }
 
@@ -1495,6 +1515,56 @@ int hamk_hameqs_batch(hamk_system* s, int64_t B, const double* q, const double* 
   long long b = B;
   void* args[] = {&xq, &xp, &xdq, &xdp, &b, &dst};
   TRY(launch(s, K_HAMEQS, B, args));
+  return st.finish();
+}
+
+// ---- initial conditions on the device ----------------------------------------------------------------
+namespace { struct HamkBoxes { double q_lo[64], q_hi[64], qd_lo[64], qd_hi[64]; }; }     // = hamk_sample.hpp
+
+static int sample_code(bool cache_on, const std::vector<char>** out) {     // the sampler's code object: compiled once per process
+  static std::mutex mu;
+  static std::vector<char> code;
+  std::lock_guard<std::mutex> lock(mu);
+  if (code.empty()) {
+    Variant v;
+    v.mapping = HAMK_MAP_LANE;
+    v.source = kSampleSource;
+    TRY0(compile_module(&v, cache_on, false, code));
+  }
+  *out = &code;
+  return HAMK_OK;
+}
+
+int hamk_sample_batch(hamk_system* s, int64_t B, int64_t first_index, uint64_t seed, const double* q_lo, const double* q_hi,
+                      const double* qd_lo, const double* qd_hi, double* q, double* qd, int32_t mem) {
+  TRY(check_call(s, B, mem));
+  if (!q_lo || !q_hi || !qd_lo || !qd_hi || !q || !qd) return fail(HAMK_ERR_INVALID, "null box / q / qd");
+  if (first_index < 0) return fail(HAMK_ERR_INVALID, "negative first_index");
+  if (B == 0) return HAMK_OK;
+  const std::vector<char>* code = nullptr;
+  TRY(sample_code(s->cache_on, &code));                     // (before the device is looked at: hiprtc needs no GPU, so a build
+  TRY(current_device_state(s));                             //  machine without one still proves the kernel compiles for gfx950)
+  DevState* d = s->cur;
+  if (!d->sample_fn) {
+    HIP_TRY(hipModuleLoadData(&d->sample_module, code->data()));
+    HIP_TRY(hipModuleGetFunction(&d->sample_fn, d->sample_module, "hamk_sample_k"));
+  }
+  HamkBoxes bx;
+  std::memset(&bx, 0, sizeof bx);
+  const int n = s->base.n;
+  for (int j = 0; j < n; ++j) { bx.q_lo[j] = q_lo[j]; bx.q_hi[j] = q_hi[j]; bx.qd_lo[j] = qd_lo[j]; bx.qd_hi[j] = qd_hi[j]; }
+  Stager st(s, mem);
+  const size_t cnt = (size_t)n * B;
+  double *xq, *xqd;
+  TRY(st.out(q, cnt, &xq));
+  TRY(st.out(qd, cnt, &xqd));
+  long long b = B, first = first_index;
+  unsigned long long sd = seed;
+  int nn = n;
+  void* args[] = {&xq, &xqd, &b, &first, &sd, &nn, &bx};
+  const int64_t grid = (B + 255) / 256;
+  if (grid > 0x7fffffffLL) return fail(HAMK_ERR_INVALID, "ensemble too large for one launch");
+  HIP_TRY(hipModuleLaunchKernel(d->sample_fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, d->stream, args, nullptr));
   return st.finish();
 }
 

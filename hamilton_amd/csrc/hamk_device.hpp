@@ -1460,11 +1460,10 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
   int budget = max_sub;
   if (!first) { t = ts ? ts[0] : ts0; h = h0; failed = false; }
   {
-    // dydt_in of EVERY call by the instructions a separate launch starts with.  (rkf45_body hands the last dydt_out on
-    // to the next call instead; that is the same number only as long as the compiler contracts this copy of the
-    // right-hand side and the stage loop's copy alike -- measured here: 1 ulp apart on 1 trajectory of 1000 after 7
-    // calls of threeBodyPolar.  Bit-identity of `iterate` with the calls one by one is by construction, for one
-    // right-hand side in ~30 per call.)
+    // dydt_in of EVERY call by the instructions a separate launch starts with (as in rkf45_body; handing the last
+    // dydt_out on instead was measured 1 ulp apart on 1 trajectory of 1000 after 7 calls of threeBodyPolar: two inlined
+    // copies of the right-hand side are contracted into FMAs on the compiler's terms).  Bit-identity of `iterate` with the
+    // calls one by one is by construction, for one right-hand side in ~30 per call.
     double y0[D], f0[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) y0[j] = py[j * 256];
@@ -1640,15 +1639,14 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
   // time grid: ts[0..nt), or -- ts == nullptr, nt == 2: stepHam -- the two kernel arguments
   double t = ts ? ts[0] : ts0, h = h0;
   TrigCache<S::NTRIG_F> tc;
-  // sincos anchors follow dydt_in/dydt_out: the stage points of an attempt sit within h |f| of
-  // the point where dydt_in was evaluated (after a rejection: of the rejected end point, still
-  // close; TRIG_INCR falls back to the full evaluation when it is not)
-  rhs<S, StageTrig<S>::anchor>(y, f0, st, tc);        // dydt_in at the initial state
   // ncalls > 1 (hamk_step_ham_iterate): `iterate (stepHam dt)` (README.md:150, Examples.hs:429) in ONE launch.
   // Every call is a fresh evolveHam over (0, dt), Hamilton.hs:400-402: t back to the grid's start, h back to
-  // h0 = dt/100 (:447), the sub-step budget and a GSL_FAILURE of the previous call forgotten.  dydt_in of the
-  // new call is f at the state the last call returned -- the dydt_out this lane already holds (the right-hand
-  // side is a pure function of the state): same bits as a separate launch, one evaluation saved per call.
+  // h0 = dt/100 (:447), the sub-step budget and a GSL_FAILURE of the previous call forgotten -- and dydt_in of EVERY
+  // call is evaluated by the instructions a separate launch starts with (round 4).  Rounds 2-3 handed the
+  // last dydt_out on to the next call instead: mathematically the same number, but only bitwise so while the compiler
+  // contracts this copy of the right-hand side and the stage loop's copy into FMAs alike -- measured 1 ulp apart on one
+  // trajectory of 1000 (threeBodyPolar, parked body).  hamk.h promises `iterate` == the calls one by one BIT FOR BIT:
+  // that now holds by construction on every mapping, for one extra right-hand side in ~25 per call.
   it_every = park_in_vgpr(it_every);
   int until_frame = it_every;
   int calls_left = park_in_vgpr(ncalls);                  // (loop bookkeeping in vector registers: see park_in_vgpr)
@@ -1656,6 +1654,10 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
   for (bool first = true; calls_left > 0; --calls_left, first = false) {
   int budget = max_sub;
   if (!first) { t = ts ? ts[0] : ts0; h = h0; failed = false; }
+  // sincos anchors follow dydt_in/dydt_out: the stage points of an attempt sit within h |f| of
+  // the point where dydt_in was evaluated (after a rejection: of the rejected end point, still
+  // close; TRIG_INCR falls back to the full evaluation when it is not)
+  rhs<S, StageTrig<S>::anchor>(y, f0, st, tc);        // dydt_in at the state the call starts from
   for (int r = 1; r < nt; ++r) {
     const double ti = ts ? ts[r] : ts1;
     while (sgn * (ti - t) > 0.0 && budget > 0 && !failed) {

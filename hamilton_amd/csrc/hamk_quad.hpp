@@ -1151,13 +1151,13 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
   };
   int st = 0, attempts = 0;
   double t = ts ? ts[0] : ts0, h = h0;
-  rhs(y, f, st);                                           // dydt_in at the initial state
   double* fq = qout; double* fp = pout;                    // iterate: where the next frame goes
   int until_frame = it_every;
 #pragma unroll 1
   for (int call = 0; call < ncalls; ++call) {
     int budget = max_sub;
     if (call > 0) { t = ts ? ts[0] : ts0; h = h0; failed = false; }
+    rhs(y, f, st);                                         // dydt_in of EVERY call by the instructions a separate launch starts with (see hamk::rkf45_body)
     for (int rr = 1; rr < nt; ++rr) {
       const double ti = ts ? ts[rr] : ts1;
       for (;;) {

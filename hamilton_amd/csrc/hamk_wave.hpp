@@ -879,12 +879,12 @@ HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, doubl
   int st = 0, attempts = 0;
   double t = ts ? ts[0] : ts0, h = h0;
   double fq, fp;
-  ham_eqs<S>(w.c, yq, yp, fq, fp, st);                    // dydt_in at the initial state
   // ncalls > 1: `iterate (stepHam dt)` in one launch -- see hamk::rkf45_body
 #pragma unroll 1
   for (int call = 0; call < ncalls; ++call) {
   int budget = max_sub;
   if (call > 0) { t = ts ? ts[0] : ts0; h = h0; failed = false; }
+  ham_eqs<S>(w.c, yq, yp, fq, fp, st);                    // dydt_in of EVERY call by the instructions a separate launch starts with
   for (int r = 1; r < nt; ++r) {
     const double ti = ts ? ts[r] : ts1;
     for (;;) {

@@ -28,6 +28,14 @@ def weak_bounds(per_rank: int, rank: int) -> Tuple[int, int]:
     return rank * per_rank, (rank + 1) * per_rank
 
 
+def pin_for_ensemble(system, total: int):
+    """Every shard of a `total`-member ensemble on the mapping the library picks for the WHOLE ensemble
+    (hamk_options::ensemble_size): with the choice left per launch, a shard of 8 192 of chain16's 65 536 would run the
+    four-lane kernels where the single-GPU run uses the lane kernels -- equal to roundoff, not bitwise.  Call once per
+    handle before the first launch of a sharded or resumed run; returns the handle."""
+    return system.set_ensemble_size(int(total))
+
+
 def gather_state(q, p, dist, world: int):
     """All-gather equally sized shards of (q, p) [n, B] -> [n, world*B] on every rank."""
     import torch

@@ -490,6 +490,26 @@ inline DevicePhase toPhaseDevice(const System& s, const Config& c) {
   check(hamk_synchronize(s.handle()));                      // qd is freed on return
   return d;
 }
+// Initial Configs of trajectories first_index .. first_index + B - 1 drawn ON THE DEVICE from the global trajectory index
+// (hamk_sample_batch), then toPhase there: a shard of an ensemble without a host array or a scatter.
+// box: n (lo, hi) pairs each for positions and velocities.
+struct Box { std::vector<double> q_lo, q_hi, qd_lo, qd_hi; };
+inline DevicePhase samplePhaseDevice(const System& s, const Box& box, int64_t first_index, int64_t B, uint64_t seed) {
+  int32_t m = 0, n = 0;
+  check(hamk_system_dims(s.handle(), &m, &n));
+  if ((int)box.q_lo.size() != n || (int)box.q_hi.size() != n || (int)box.qd_lo.size() != n || (int)box.qd_hi.size() != n)
+    throw std::invalid_argument("samplePhaseDevice: the box needs n (lo, hi) pairs");
+  DevicePhase d(n, B);
+  DeviceArray qd(8 * (int64_t)n * B);
+  check(hamk_sample_batch(s.handle(), B, first_index, seed, box.q_lo.data(), box.q_hi.data(), box.qd_lo.data(), box.qd_hi.data(),
+                          d.positions.as<double>(), qd.as<double>(), HAMK_MEM_DEVICE));
+  check(hamk_to_phase_batch(s.handle(), B, d.positions.as<double>(), qd.as<double>(), d.momenta.as<double>(), HAMK_MEM_DEVICE));
+  check(hamk_synchronize(s.handle()));                      // qd is freed on return
+  return d;
+}
+// The size of the WHOLE ensemble this System's launches are pieces of (hamk_system_set_ensemble_size): every shard on the
+// mapping chosen for the whole, so any shard layout reproduces the one-launch bits.
+inline void setEnsembleSize(System& s, int64_t B_total) { check(hamk_system_set_ensemble_size(s.handle(), B_total)); }
 inline void rk4Steps(double dt, int nsteps, System& s, DevicePhase& d) {      // in place, asynchronous
   check(hamk_rk4_steps(s.handle(), d.B, d.positions.as<double>(), d.momenta.as<double>(), dt, nsteps, d.status.as<int32_t>(), HAMK_MEM_DEVICE));
 }

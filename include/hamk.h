@@ -196,13 +196,21 @@ typedef struct hamk_options {
                               multiplied by their count instead of added up); AUTO: ON                                  */
   int32_t rk4_park;        /* ON | OFF: lane mapping, RK4 stage loop keeps y and the running combination in LDS across
                               the right-hand side; AUTO: n >= 14                                                        */
-  int32_t max_substeps;    /* sub-step budget per stepHam / evolveHam interval and trajectory; AUTO: 2^24               */
+  int32_t max_substeps;    /* sub-step budget per stepHam / evolveHam CALL and trajectory (an evolveHam over nt times
+                              shares one budget across its intervals; every call of `iterate` has its own); AUTO: 2^24  */
   int32_t cache;           /* ON | OFF: on-disk cache of compiled code objects; AUTO: ON                                */
   int32_t lanes_per_trajectory;  /* OUTPUT of hamk_system_get_options: 1, 4, 16, 32 or 64                               */
   int32_t rkf_park;        /* ON | OFF: lane and quad mappings, the adaptive stepper's vectors (y, dydt, k2..k6, trial state)
                               wait in LDS and in a run-time-indexed private array instead of competing with the right-hand
                               side for registers; AUTO: lane n >= 6 (with the stage-loop body), quad n >= 17              */
-  int32_t reserved[15];           /* sizeof(hamk_options) = 128 */
+  int32_t _align;          /* keeps ensemble_size 8-byte aligned; 0                                                     */
+  int64_t ensemble_size;   /* mapping = AUTO only: the size of the WHOLE ensemble this handle's launches are pieces of (a shard
+                              of a multi-GPU run, a chunk of a host loop).  AUTO picks the mapping from the ensemble size, and
+                              two mappings agree to roundoff, not bitwise -- so a host that states the whole ensemble's size
+                              ONCE (here, or hamk_system_set_ensemble_size) gets every piece computed by the mapping chosen
+                              for the whole: any split of the ensemble, over any number of GPUs, reproduces the one-launch
+                              bits.  0 (AUTO): every launch stands for itself (mapping from its own B)                     */
+  int32_t reserved[12];           /* sizeof(hamk_options) = 128 */
 } hamk_options;
 
 /* Zero-fills *opt and sets opt->size.                                                                                 */
@@ -229,6 +237,10 @@ int hamk_system_get_options(hamk_system* s, int64_t B, hamk_options* resolved);
 /* Makes the introspection entry points below (source, code_size, code_object, build_info, kernel_bytes) describe the
  * specialisation a launch over B trajectories uses (default: the one built at creation).                              */
 int hamk_system_describe_batch(hamk_system* s, int64_t B);
+/* hamk_options::ensemble_size after creation (0: back to per-launch choice).  A run sharded over G GPUs, or resumed from
+ * a checkpoint with another G, calls this with the WHOLE ensemble's size on every handle: results are then independent of
+ * the shard layout bit for bit.  No effect where the mapping is fixed by hamk_options::mapping. */
+int hamk_system_set_ensemble_size(hamk_system* s, int64_t B_total);
 void hamk_system_destroy(hamk_system* s);
 int  hamk_system_dims(const hamk_system* s, int32_t* m, int32_t* n);
 
@@ -323,9 +335,9 @@ int hamk_step_ham_batch(hamk_system* s, int64_t B, double* q, double* p, double 
 /* `iterate (stepHam dt)` (README.md:150; the demo's frame loop, app/Examples.hs:429): ncalls consecutive
  * stepHam dt in ONE launch, IN PLACE.  Every call is what a separate hamk_step_ham_batch would do -- a fresh
  * evolveHam over (0, dt): t = 0, h0 = dt/100 (Hamilton.hs:400-402, :447), its own sub-step budget -- and the
- * result is bit-identical to ncalls separate calls; what is saved is ncalls - 1 launches and stream
- * synchronisations (one trajectory is launch-latency bound: BASELINE config 1) and, in the kernels of the small
- * systems, one right-hand side per call (dydt_in of a call is the dydt_out the previous one already holds).
+ * result is bit-identical to ncalls separate calls BY CONSTRUCTION on every mapping (every call starts with the
+ * instructions a separate launch starts with, its own evaluation of dydt_in included); what is saved is
+ * ncalls - 1 launches and stream synchronisations (one trajectory is launch-latency bound: BASELINE config 1).
  * out_every > 0: the state after every out_every-th call goes to qout/pout, [ncalls / out_every][n][B]
  * (the frames an animation shows); out_every == 0: qout/pout may be NULL.  status: OR over the calls;
  * nsub: sub-steps summed over the calls.                                                                 */
@@ -342,6 +354,17 @@ int hamk_evolve_ham_batch(hamk_system* s, int64_t B, const double* q0, const dou
                           int32_t nt, const double* ts, double* qout, double* pout,
                           double h0, double eps_abs, double eps_rel,
                           int32_t* status, int32_t* nsub, int32_t mem);
+
+/* ---- initial conditions of an ensemble, generated on the device ------------------------------------
+ * q[j][i], qd[j][i] of trajectories first_index .. first_index + B - 1: uniform in [q_lo[j], q_hi[j]] and
+ * [qd_lo[j], qd_hi[j]] (host arrays of n entries), from a counter-based generator keyed by (seed, GLOBAL
+ * trajectory index, field) -- splitmix64, hamk_sample.hpp -- so a rank of a sharded run fills its own shard in
+ * HBM without a host array or a scatter, and every shard layout draws bit-identical inputs.
+ * Same bits as the Python sampler the CPU tests use (hamilton_amd/examples.py sample_config).  The reference has no
+ * counterpart: its demo starts one trajectory from a command-line Config (app/Examples.hs:230-359).                */
+int hamk_sample_batch(hamk_system* s, int64_t B, int64_t first_index, uint64_t seed,
+                      const double* q_lo, const double* q_hi, const double* qd_lo, const double* qd_hi,
+                      double* q, double* qd, int32_t mem);
 
 /* ---- devices and device memory ---------------------------------------------
  * For hosts that do not link HIP themselves (the Haskell shim, plain C): with these an ensemble
@@ -372,7 +395,9 @@ int hamk_gather_batch(int32_t nparts, int32_t n, const int64_t* B_parts, const d
  * is staged in 8 MiB pieces.  Written aside and renamed: a crash leaves the previous file.
  * steps_done / seed / t are the caller's bookkeeping (per-index splitmix64 seed of the initial
  * conditions, steps taken, model time) and come back from hamk_checkpoint_info.  Every kernel is a
- * pure function of the state, so a resumed run continues bit-identically.
+ * pure function of the state, so a resumed run continues bit-identically -- on the same mapping: a run
+ * resumed with a different shard layout states the whole ensemble's size (hamk_system_set_ensemble_size)
+ * or pins hamk_options::mapping, as the original run must have.
  * Device state is copied on the NULL stream: hamk_synchronize the handle (or synchronise the stream that
  * produced / will consume q, p) before a write and before using the arrays after a read.  A header that does
  * not match the file's size is rejected before anything is allocated from it.                      */

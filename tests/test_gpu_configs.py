@@ -563,3 +563,62 @@ def test_the_kernel_chosen_for_a_small_shard_is_oracle_exact(api, oracle_lib, na
         e2 = max(relerr(dq[:, idx].cpu().numpy(), odq), relerr(dp[:, idx].cpu().numpy(), odp))
         record(test="small_shard", name=name, B=B, mapping=s.options(B)["mapping"], rk4_20=e, hameqs=e2)
         assert e < 1e-11 and e2 < 1e-11, (name, B, e, e2)
+
+
+@pytest.mark.parametrize("name,B,G", [("chain16", 65536, 8), ("chain12", 65536, 4), ("chain16", 24576, 3)])
+def test_a_sharded_ensemble_reproduces_the_one_launch_bits(api, name, B, G):
+    """any shard layout reproduces the single-GPU result bit for bit.  With the mapping left per
+    launch that fails for 11 <= n <= 16 (65 536 trajectories run the lane kernels, a shard of 8 192 the four-lane ones:
+    equal to roundoff only) -- round 3 had to pin the mapping by hand.  A host now states the WHOLE ensemble's size once
+    (hamk_options::ensemble_size / hamk_system_set_ensemble_size; `ensemble.pin_for_ensemble`) and every shard is computed
+    by the mapping chosen for the whole: RK4, stepHam and hamEqs of G contiguous shards == the same lanes of one launch."""
+    import torch
+    from hamilton_amd import ensemble
+    spec = E.get(name)
+    one = api.system_from_spec(spec)                           # the single-GPU run: mapping from its own B
+    q, qd = E.sample_config(spec, 0, B)
+    qd = 0.3 * np.cos(np.arange(spec.n * B, dtype=np.float64).reshape(spec.n, B) * 0.7)
+    ph0 = api.toPhase(one, api.Config(torch.from_numpy(q).cuda(), torch.from_numpy(qd).cuda()))
+    full = api.rk4Steps(spec.dt, 20, one, ph0)
+    full_h = api.stepHam(2 * spec.dt, one, ph0)
+    full_nsub = one.last_nsub.clone()
+    full_dq, full_dp = api.hamEqs(one, ph0)
+    sharded = ensemble.pin_for_ensemble(api.system_from_spec(spec), B)     # what every rank of a G-GPU run does
+    assert sharded.options(B // G)["mapping"] == one.options(B)["mapping"]
+    assert api.system_from_spec(spec, {"ensemble_size": B}).options(7)["mapping"] == one.options(B)["mapping"]
+    for g in range(G):
+        lo, hi = ensemble.shard_bounds(B, G, g)
+        sub = api.Phase(ph0.positions[:, lo:hi].contiguous(), ph0.momenta[:, lo:hi].contiguous())
+        r = api.rk4Steps(spec.dt, 20, sharded, sub)
+        assert torch.equal(r.positions, full.positions[:, lo:hi]) and torch.equal(r.momenta, full.momenta[:, lo:hi]), (name, g)
+        h = api.stepHam(2 * spec.dt, sharded, sub)
+        assert torch.equal(h.positions, full_h.positions[:, lo:hi]) and torch.equal(h.momenta, full_h.momenta[:, lo:hi])
+        assert torch.equal(sharded.last_nsub, full_nsub[lo:hi])
+        dq, dp = api.hamEqs(sharded, sub)
+        assert torch.equal(dq, full_dq[:, lo:hi]) and torch.equal(dp, full_dp[:, lo:hi])
+    if name == "chain16" and G == 8:                           # ... and without the statement the small shard is on another mapping
+        assert api.system_from_spec(spec).options(B // G)["mapping"] != one.options(B)["mapping"]
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py's multi-GPU code path (torch.distributed over RCCL) on one GPU
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_runs_its_rccl_path(api, tmp_path, scaling):
+    """The first 8-GPU SCALE run must not be this code's first execution: `bench.py --force-dist` initialises
+    torch.distributed with backend nccl (= RCCL) on one rank and goes through everything the N > 1 runs do -- barrier,
+    max-over-ranks timing, the final all_gather of the state, the status reductions.  The JSON line must say so."""
+    import json as _json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--batch", "4096", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-isa", "--scaling", scaling], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = _json.loads(line)
+    assert out["n_gpus"] == 1 and out["scaling"] == scaling and out["gather_ms"] > 0.0
+    assert out["rccl"]["world"] == 1 and out["rccl"]["backend"] == "nccl"
+    assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0 and out["status_flagged"] == out["status_flagged_drift"]
+    record(test="bench_force_dist", scaling=scaling, line=out)

@@ -681,3 +681,26 @@ def test_first_use_self_check_and_recovery(api, oracle_lib, monkeypatch):
     st = api.stepHam(0.01, s, api.Phase(q, p))
     sq, sp, _ = o.step_ham_batch(q, p, 0.01)
     assert relerr(st.positions, sq) < 1e-12
+
+
+def test_initial_conditions_are_drawn_on_the_device_from_the_global_index(api):
+    """hamk_sample_batch (SURVEY.md 8e "inputs generated on-device from the global index -> no scatter needed"): the numpy
+    sampler's bits (examples.sample_config) at BASELINE config 2's 2^20, for a shard that starts anywhere, through device
+    and host pointers -- and G shards drawn separately are the slices of one draw."""
+    import torch
+    from hamilton_amd import ensemble
+    for name, B in (("doublePendulum", 1 << 20), ("threeBodyPolar", 70001), ("chain32", 4099)):
+        spec = E.get(name)
+        s = api.system_from_spec(spec)
+        want_q, want_qd = E.sample_config(spec, 0, B)
+        c = api.sampleConfig(s, spec.q_box, spec.qd_box, 0, B, E.SEED, "cuda")
+        assert np.array_equal(c.positions.cpu().numpy(), want_q) and np.array_equal(c.velocities.cpu().numpy(), want_qd), name
+        for g in range(3):
+            lo, hi = ensemble.shard_bounds(B, 3, g)
+            part = api.sampleConfig(s, spec.q_box, spec.qd_box, lo, hi - lo, E.SEED, "cuda")
+            assert torch.equal(part.positions, c.positions[:, lo:hi]) and torch.equal(part.velocities, c.velocities[:, lo:hi])
+        far = api.sampleConfig(s, spec.q_box, spec.qd_box, 3 << 40, 1000, 12345)          # host arrays, a huge global index, another seed
+        wq, wqd = E.sample_config(spec, 3 << 40, 1000, 12345)
+        assert np.array_equal(far.positions, wq) and np.array_equal(far.velocities, wqd)
+    with pytest.raises(ValueError):
+        api.sampleConfig(s, spec.q_box[:-1], spec.qd_box, 0, 4, 1)

@@ -1,8 +1,8 @@
 // hamk_bench -- the BASELINE.json metric through the C ABI alone, from a compiled host.
 //
 // What a Haskell (or any non-Python) host gets from libhamk.so: double pendulum (System 4 2,
-// /root/reference app/Examples.hs:75-94), an ensemble of B seeded initial conditions resident in
-// HBM (hamk_device_malloc), toPhase on the device, `launches` x hamk_rk4_steps(nsteps) timed with
+// /root/reference app/Examples.hs:75-94), an ensemble of B seeded initial conditions drawn in HBM from the
+// global index (hamk_sample_batch), toPhase on the device, `launches` x hamk_rk4_steps(nsteps) timed with
 // the host clock between hamk_synchronize calls.  No torch, no HIP headers: include/hamk.h and
 // include/hamilton.hpp only.  bench.py is the driver's harness (one process per GPU, RCCL); this
 // one is the single-process form: --gpus G puts one shard on each of the first G devices, one
@@ -20,20 +20,6 @@
 #include "hamilton.hpp"
 
 namespace hm = hamilton;
-
-// per-index counter RNG, identical to hamilton_amd/examples.py (uniform01 / sample_config)
-static uint64_t splitmix64(uint64_t x) {
-  x += 0x9E3779B97F4A7C15ull;
-  uint64_t z = x;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-static double uniform01(uint64_t index, uint64_t fld, uint64_t seed = 20241008ull) {
-  uint64_t key = seed ^ (index * 0xD1342543DE82EF95ull);
-  key = splitmix64(key + fld * 0x2545F4914F6CDD1Dull);
-  return (double)(key >> 11) * (1.0 / 9007199254740992.0);
-}
 
 static hm::System double_pendulum() {                     // Examples.hs:75-94 with m1 = m2 = 1
   return hm::mkSystemP({1, 1, 1, 1}, 2,
@@ -61,18 +47,14 @@ int main(int argc, char** argv) {
     if (hamk_device_count() < gpus) { std::fprintf(stderr, "need %d HIP device(s), see %d\n", gpus, hamk_device_count()); return 3; }
     std::vector<std::unique_ptr<hm::System>> sys;
     std::vector<hm::DevicePhase> state((size_t)gpus);
+    const hm::Box box{{-PI, -PI}, {PI, PI}, {-1.0, -1.0}, {1.0, 1.0}};      // q_box (-pi, pi), qd_box (-1, 1): SURVEY.md 8d C2
     for (int g = 0; g < gpus; ++g) {                        // weak scaling: every device owns B trajectories
       hm::check(hamk_set_device(g));
       sys.emplace_back(new hm::System(double_pendulum()));
-      hm::Config c; c.n = 2; c.B = B; c.positions.resize(2 * (size_t)B); c.velocities.resize(2 * (size_t)B);
-      for (int64_t i = 0; i < B; ++i) {
-        const uint64_t idx = (uint64_t)g * (uint64_t)B + (uint64_t)i;     // global trajectory index
-        for (int j = 0; j < 2; ++j) {                       // q_box (-pi, pi), qd_box (-1, 1): SURVEY.md 8d C2
-          c.positions[(size_t)j * B + i] = -PI + 2.0 * PI * uniform01(idx, 2 * j);
-          c.velocities[(size_t)j * B + i] = -1.0 + 2.0 * uniform01(idx, 2 * j + 1);
-        }
-      }
-      state[(size_t)g] = hm::toPhaseDevice(*sys.back(), c);
+      // one ensemble of gpus x B members: every shard on the mapping chosen for the whole, its initial conditions drawn on
+      // ITS device from the global trajectory index (per-index splitmix64, seed 20241008 = hamilton_amd/examples.py)
+      hm::setEnsembleSize(*sys.back(), (int64_t)gpus * B);
+      state[(size_t)g] = hm::samplePhaseDevice(*sys.back(), box, (int64_t)g * B, B, 20241008ull);
     }
     auto step_all = [&]() {
       for (int g = 0; g < gpus; ++g) { hm::check(hamk_set_device(g)); hm::rk4Steps(dt, nsteps, *sys[(size_t)g], state[(size_t)g]); }
