@@ -54,11 +54,11 @@
 #ifndef HAMK_RKF_PARK
 #define HAMK_RKF_PARK 0       /* RKF45 stage loop: the stepper's nine vectors wait in a run-time-indexed private array (scratch) */
 #endif
-#ifndef HAMK_RKF_REUSE_MAX_N
-#define HAMK_RKF_REUSE_MAX_N 16 /* parked RKF45 stepper: largest n whose stages use the last right-hand side from the registers */
-#endif
 #ifndef HAMK_RKF_LDS_BUDGET
 #define HAMK_RKF_LDS_BUDGET 76 /* doubles of LDS per lane the parked RKF45 stepper may use (hamk::RkfPark) */
+#endif
+#ifndef HAMK_RKF_PREFETCH_ROWS
+#define HAMK_RKF_PREFETCH_ROWS 3 /* parked RKF45 stepper: rows of the next stage combination fetched from scratch INSIDE the right-hand side (0..3) */
 #endif
 #ifndef HAMK_RK4_PARK
 #define HAMK_RK4_PARK 0       /* RK4 stage loop: y and the running combination parked in LDS across the right-hand side */
@@ -76,6 +76,8 @@ template <class T> struct bare<const T> { typedef T type; };
 template <class T> struct bare<T&> { typedef typename bare<T>::type type; };
 template <class T> struct bare<const T&> { typedef T type; };
 template <class T> using bare_t = typename bare<T>::type;
+
+template <int V> struct Int { static constexpr int v = V; };      // a compile-time integer as a value (generic lambdas: hiprtc has no <type_traits>)
 
 HAMK_DEV double quiet_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
 
@@ -917,9 +919,17 @@ template <class S> HAMK_DEV double potential_value(const double (&q)[S::N]) {
 // Both use dT/dq_i = -(M J qd) . ((dJ/dq_i) qd), which equals the reference's
 // -(p . K^-1 J^T M (dJ/dq_i) K^-1 p) because K^-1 is symmetric and qd = K^-1 p.
 // ---------------------------------------------------------------------------
-template <class S, bool MODE_H, int TRIG = TRIG_FULL>
+// A caller's work placed INSIDE a right-hand side, at the point where K, its factor and the first-order jets are dead and
+// the second-derivative sweep has not begun (the register file is at its emptiest there): the parked adaptive stepper
+// issues the loads of the rows its next stage combination needs at that point, so their round trip through the
+// vector-memory pipe runs under the reverse sweep instead of stalling the one wavefront a SIMD has (rkf45_body_parked).
+struct NoMid { static constexpr bool active = false; HAMK_DEV void operator()() const {} };
+template <class F> struct Mid { static constexpr bool active = true; F f; HAMK_DEV void operator()() const { f(); } };
+template <class F> HAMK_DEV Mid<F> make_mid(F f) { return Mid<F>{f}; }
+
+template <class S, bool MODE_H, int TRIG = TRIG_FULL, class MID = NoMid>
 HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (&dq)[S::N], double (&dp)[S::N], int& st,
-                      TrigCache<S::NTRIG_F>& tc) {
+                      TrigCache<S::NTRIG_F>& tc, const MID& mid = MID()) {
   constexpr int N = S::N, M = S::M;
   double K[N][N], gU[N], U, v[N], dT[N];
   if constexpr (MODE_H) {
@@ -941,6 +951,7 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
     mass_matrix<S>(xj, K);
     solve_spd<N, S::INERTIA_POS>(K, p, v, st);
     grad_potential<S>(qj, xj, gU, U, tc);
+    if constexpr (MID::active) mid();
 #pragma unroll
     for (int i = 0; i < N; ++i) dT[i] = 0.0;
 #pragma unroll
@@ -964,6 +975,20 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
     mass_matrix<S>(xj, K);
     solve_spd<N, S::INERTIA_POS>(K, p, v, st);
     grad_potential<S>(qj, xj, gU, U, tc);
+    if constexpr (MID::active) {
+#ifndef HAMK_HOST_EMULATION
+      // the solve's results are pinned in front of the hook: the hook usually branches (which rows the caller wants is a
+      // run-time matter), and IR-level sinking otherwise moves the whole first half of the right-hand side -- pure
+      // arithmetic whose results are only used after the branch -- BELOW it, so that the hook runs first
+#pragma unroll
+      for (int i = 0; i < N; ++i) { asm volatile("" : "+v"(v[i])); asm volatile("" : "+v"(gU[i])); }
+      __builtin_amdgcn_sched_barrier(0);                    // the hook's loads are issued HERE: after the solve, before the second sweep
+#endif
+      mid();
+#ifndef HAMK_HOST_EMULATION
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
     if constexpr (S::MODE_R) {
       // MODE_R: the contraction is a gradient -- one forward (value, tangent along qd) pass and one
       // reverse pass over the tape (generated, S::dT_reverse), O(tape) instead of O(n * tape)
@@ -1022,13 +1047,13 @@ template <class S> struct StageTrig {
   static constexpr int dyn = on ? TRIG_DYN : (lut ? TRIG_LUT : TRIG_FULL);       // the fixed-step loops
 };
 
-template <class S, int TRIG = TRIG_FULL>
-HAMK_DEV void rhs(const double (&y)[2 * S::N], double (&dy)[2 * S::N], int& st, TrigCache<S::NTRIG_F>& tc) {
+template <class S, int TRIG = TRIG_FULL, class MID = NoMid>
+HAMK_DEV void rhs(const double (&y)[2 * S::N], double (&dy)[2 * S::N], int& st, TrigCache<S::NTRIG_F>& tc, const MID& mid = MID()) {
   constexpr int N = S::N;
   double q[N], p[N], dq[N], dp[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) { q[i] = y[i]; p[i] = y[N + i]; }
-  ham_eqs<S, S::MODE_H, TRIG>(q, p, dq, dp, st, tc);
+  ham_eqs<S, S::MODE_H, TRIG, MID>(q, p, dq, dp, st, tc, mid);
 #pragma unroll
   for (int i = 0; i < N; ++i) { dy[i] = dq[i]; dy[N + i] = dp[i]; }
 }
@@ -1392,11 +1417,7 @@ template <int D> HAMK_DEV void probe_pin(double (&x)[D]) {
 template <class S> struct RkfPark {
   static constexpr int D = 2 * S::N;
   static constexpr int BUDGET = HAMK_RKF_LDS_BUDGET;        // doubles per lane; 76: (160 KiB - sincos table - slack) / 256 lanes / 8
-  static constexpr int NL = (BUDGET / D) < 2 ? 2 : ((BUDGET / D) > 5 ? 5 : (BUDGET / D));      // y, dydt, then k2, k3, k4
-  // a right-hand side's result used from the registers by the stage that follows it (k6 is then never stored); measured
-  // against re-reading it from its row (profiles/r03_lane_rkf_park.jsonl): chain13 1.29e8 -> 1.44e8 stepHam/s, chain14
-  // 1.15e8 -> 1.27e8, chain16 a tie
-  static constexpr bool REUSE = HAMK_RKF_REUSE_MAX_N >= S::N;
+  static constexpr int NL = (BUDGET / D) < 2 ? 2 : ((BUDGET / D) > 6 ? 6 : (BUDGET / D));      // y, dydt, then k2, k3, k4, k5 (6 rows: nothing waits in scratch)
 };
 template <class S>
 HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt, const double* __restrict__ ts, double ts0, double ts1,
@@ -1405,7 +1426,6 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
   const int row0 = flags & 1, inplace = (flags >> 8) & 3, gsl_api = (flags >> 16) & 3;
   ts0 = park_in_vgpr(ts0); ts1 = park_in_vgpr(ts1); h0 = park_in_vgpr(h0); eps_abs = park_in_vgpr(eps_abs); eps_rel = park_in_vgpr(eps_rel);
   constexpr int N = S::N, D = 2 * N, NL = RkfPark<S>::NL;
-  constexpr bool REUSE = RkfPark<S>::REUSE;
   if constexpr (StageTrig<S>::lut) lut_load();
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
@@ -1427,8 +1447,9 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
   // instruction can encode make the compiler keep several derived bases alive through the right-hand side -- chain16: 66
   // spilled registers instead of 24, 7.8e7 -> 6.1e7 stepHam/s)
 #define HAMK_RKF_LROW(r) (rows + (r) * D * 256 + threadIdx.x)
-#define HAMK_RKF_K(KR, j) ((2 + (KR) < NL) ? HAMK_RKF_LROW(2 + (KR))[(j) * 256] : v[KR][j])      /* k_{2 + KR}[j] */
-#define HAMK_RKF_RECENT(KR, j) (REUSE ? out[j] : HAMK_RKF_K(KR, j))
+  // k_{2 + KR}[j] where a stage combination reads it: from its LDS row, or -- a row that waits in scratch -- from the slot of
+  // `pre` the previous right-hand side's hook fetched it into (see `prefetch` below)
+#define HAMK_RKF_K(KR, SLOT, j) ((2 + (KR) < NL) ? HAMK_RKF_LROW(2 + (KR))[(j) * 256] : ((SLOT) < HAMK_RKF_PREFETCH_ROWS ? pre[SLOT][j] : v[KR][j]))
   auto put_k = [&](int kr, const double (&x)[D]) {         // k_{2 + kr}; kr: a run-time value (the stage counter)
     if (NL > 2 && 2 + kr < NL) {
 #pragma unroll
@@ -1481,10 +1502,51 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
       bool final_step = false;
       if ((dt >= 0.0 && hh > dt) || (dt < 0.0 && hh < dt)) { hh = dt; final_step = true; }
       double out[D];                                        // the last right-hand side's result: k_{sg + 1} at the top of stage sg
+      // The rows of the NEXT stage combination that wait in scratch memory, fetched by the hook INSIDE the right-hand side
+      // that precedes it (ham_eqs' MID, after the solve: K and its factor are dead there, so the 3 x 2n registers are
+      // free) -- their round trip through the vector-memory pipe runs under the reverse sweep instead of in front of the
+      // combination.  Round 3 loaded them at the top of the stage, and with one wavefront per SIMD nothing else could
+      // run meanwhile: chain16's launch took exactly as long as its 1.35 GB of row traffic at 3 TB/s.  Same rows, same
+      // expressions, same bits; only WHEN the loads are issued changes.
+      double pre[3][D];
 #pragma unroll
-      for (int j = 0; j < D; ++j) out[j] = 0.0;
+      for (int j = 0; j < D; ++j) { out[j] = 0.0; pre[0][j] = pre[1][j] = pre[2][j] = 0.0; }
+      int sg = 0;                                           // (declared outside the loop: the hook reads it)
+      auto fetch = [&](auto slot, auto kr) {                // pre[slot] = k_{2 + kr}, if that row waits in scratch
+        if constexpr (2 + decltype(kr)::v >= NL && decltype(slot)::v < HAMK_RKF_PREFETCH_ROWS) {
+#pragma unroll
+          for (int j = 0; j < D; ++j) pre[decltype(slot)::v][j] = v[decltype(kr)::v][j];
+        }
+      };
+      auto prefetch = make_mid([&]() {                      // what the combination of stage sg + 1 (or the error norm) reads
+#ifndef HAMK_HOST_EMULATION
+        // The loads must be ISSUED HERE.  Left alone, LLVM's load-PRE sees that this switch and the switch of the stage
+        // combinations select on the same value, makes every row "available" in the combination's case block -- i.e. loads
+        // it BEFORE the right-hand side -- and then spills it across the factorisation (first version: 1122 spilled
+        // registers).  The array's address escapes into an opaque statement that may touch memory: no load of it may be
+        // moved above this point.
+        { double* vp = &v[0][0]; asm volatile("" : : "v"(vp) : "memory"); }
+#endif
+        switch (sg) {
+          case 0: break;                                                               // stage 2: f0 and k2 -- k2 comes from `out`
+          case 1: fetch(Int<0>(), Int<0>()); break;                                                        // stage 3: k2 | k3 from `out`
+          case 2: fetch(Int<0>(), Int<0>()); fetch(Int<1>(), Int<1>()); break;                             // stage 4: k2, k3
+          case 3: fetch(Int<0>(), Int<0>()); fetch(Int<1>(), Int<1>()); fetch(Int<2>(), Int<2>()); break;  // stage 5: k2, k3, k4
+          case 4: fetch(Int<0>(), Int<1>()); fetch(Int<1>(), Int<2>()); fetch(Int<2>(), Int<3>()); break;  // stage 6: k3, k4, k5
+          default:                                                                                         // the norm: trial state, error
+            if constexpr (NL < 3 && 0 < HAMK_RKF_PREFETCH_ROWS) {
+#pragma unroll
+              for (int j = 0; j < D; ++j) pre[0][j] = v[5][j];
+            }
+            if constexpr (NL < 4 && 1 < HAMK_RKF_PREFETCH_ROWS) {
+#pragma unroll
+              for (int j = 0; j < D; ++j) pre[1][j] = v[6][j];
+            }
+            break;
+        }
+      });
 #pragma unroll 1
-      for (int sg = 0; sg < 6; ++sg) {
+      for (sg = 0; sg < 6; ++sg) {
         double yt[D];
         switch (sg) {
           case 0:
@@ -1493,31 +1555,31 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
             break;
           case 1:
 #pragma unroll
-            for (int j = 0; j < D; ++j) yt[j] = py[j * 256] + hh * ((3.0 / 32.0) * pf[j * 256] + (9.0 / 32.0) * HAMK_RKF_RECENT(0, j));
+            for (int j = 0; j < D; ++j) yt[j] = py[j * 256] + hh * ((3.0 / 32.0) * pf[j * 256] + (9.0 / 32.0) * out[j]);
             break;
           case 2:
 #pragma unroll
             for (int j = 0; j < D; ++j)
-              yt[j] = py[j * 256] + hh * ((1932.0 / 2197.0) * pf[j * 256] + (-7200.0 / 2197.0) * HAMK_RKF_K(0, j) + (7296.0 / 2197.0) * HAMK_RKF_RECENT(1, j));
+              yt[j] = py[j * 256] + hh * ((1932.0 / 2197.0) * pf[j * 256] + (-7200.0 / 2197.0) * HAMK_RKF_K(0, 0, j) + (7296.0 / 2197.0) * out[j]);
             break;
           case 3:
 #pragma unroll
             for (int j = 0; j < D; ++j)
-              yt[j] = py[j * 256] + hh * ((8341.0 / 4104.0) * pf[j * 256] + (-32832.0 / 4104.0) * HAMK_RKF_K(0, j) +
-                                          (29440.0 / 4104.0) * HAMK_RKF_K(1, j) + (-845.0 / 4104.0) * HAMK_RKF_RECENT(2, j));
+              yt[j] = py[j * 256] + hh * ((8341.0 / 4104.0) * pf[j * 256] + (-32832.0 / 4104.0) * HAMK_RKF_K(0, 0, j) +
+                                          (29440.0 / 4104.0) * HAMK_RKF_K(1, 1, j) + (-845.0 / 4104.0) * out[j]);
             break;
           case 4:
 #pragma unroll
             for (int j = 0; j < D; ++j)
-              yt[j] = py[j * 256] + hh * ((-6080.0 / 20520.0) * pf[j * 256] + (41040.0 / 20520.0) * HAMK_RKF_K(0, j) +
-                                          (-28352.0 / 20520.0) * HAMK_RKF_K(1, j) + (9295.0 / 20520.0) * HAMK_RKF_K(2, j) +
-                                          (-5643.0 / 20520.0) * HAMK_RKF_RECENT(3, j));
+              yt[j] = py[j * 256] + hh * ((-6080.0 / 20520.0) * pf[j * 256] + (41040.0 / 20520.0) * HAMK_RKF_K(0, 0, j) +
+                                          (-28352.0 / 20520.0) * HAMK_RKF_K(1, 1, j) + (9295.0 / 20520.0) * HAMK_RKF_K(2, 2, j) +
+                                          (-5643.0 / 20520.0) * out[j]);
             break;
           default: {
             double ye[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-              const double f0 = pf[j * 256], k3 = HAMK_RKF_K(1, j), k4 = HAMK_RKF_K(2, j), k5 = HAMK_RKF_K(3, j), k6 = HAMK_RKF_RECENT(4, j);
+              const double f0 = pf[j * 256], k3 = HAMK_RKF_K(1, 0, j), k4 = HAMK_RKF_K(2, 1, j), k5 = HAMK_RKF_K(3, 2, j), k6 = out[j];
               const double di = (902880.0 / 7618050.0) * f0 + (3953664.0 / 7618050.0) * k3 +
                                 (3855735.0 / 7618050.0) * k4 + (-1371249.0 / 7618050.0) * k5 +
                                 (277020.0 / 7618050.0) * k6;
@@ -1531,27 +1593,34 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
             break;
           }
         }
+        // `pre` has been consumed: it must not stay live across the first half of the right-hand side, where K wants the whole
+        // register file.  Which slots the hook refills depends on the run-time stage, so without this the compiler has to
+        // assume the old contents are read again and carries 3 x 2n registers through the factorisation (measured on the
+        // first version: 1122 spilled registers at n = 16 instead of 21)
+#pragma unroll
+        for (int j = 0; j < D; ++j) pre[0][j] = pre[1][j] = pre[2][j] = 0.0;
         HAMK_MARK(3);
         HAMK_PIN(yt);
 #ifndef HAMK_HOST_EMULATION
-        __builtin_amdgcn_sched_barrier(0);                  // no row is fetched early into the right-hand side
+        __builtin_amdgcn_sched_barrier(0);                  // no row is fetched early into the first half of the right-hand side
 #endif
-        rhs<S, StageTrig<S>::lut ? TRIG_LUT : TRIG_FULL>(yt, out, st, tc);
+        rhs<S, StageTrig<S>::lut ? TRIG_LUT : TRIG_FULL>(yt, out, st, tc, prefetch);
 #ifndef HAMK_HOST_EMULATION
         __builtin_amdgcn_sched_barrier(0);
 #endif
         HAMK_PIN(out);
         HAMK_MARK(0);
-        if (sg < (REUSE ? 4 : 5)) put_k(sg, out);          // k2..k5, k6 unless it is used from the registers; dydt_out always is
+        if (sg < 4) put_k(sg, out);                         // k2..k5; k6 and dydt_out are used from the registers
       }
       // --- cstd.c: std_control_hadjust, ord = 5 ------------------------------
       double yn[D];
       double rmax = 2.2250738585072014e-308;
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        yn[j] = HAMK_RKF_YN(j);
+        yn[j] = (NL >= 3) ? HAMK_RKF_LROW(2)[j * 256] : (0 < HAMK_RKF_PREFETCH_ROWS ? pre[0][j] : v[5][j]);
+        const double ej = (NL >= 4) ? HAMK_RKF_LROW(3)[j * 256] : (1 < HAMK_RKF_PREFETCH_ROWS ? pre[1][j] : v[6][j]);
         const double D0 = eps_rel * (fabs(yn[j]) + fabs(hh * out[j])) + eps_abs;
-        const double rr = fabs(HAMK_RKF_E(j)) / fabs(D0);
+        const double rr = fabs(ej) / fabs(D0);
         rmax = (rr > rmax) ? rr : rmax;
       }
       const double tnew = final_step ? ti : t + hh;
@@ -1599,7 +1668,6 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
   if (bad) st |= ST_NONFINITE;
   if (status) status[i] = st;
   if (nsub) nsub[i] = attempts;
-#undef HAMK_RKF_RECENT
 #undef HAMK_RKF_YN
 #undef HAMK_RKF_E
 #undef HAMK_RKF_K
@@ -1963,6 +2031,11 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
 #else
 #define HAMK_RK4_BOUNDS __launch_bounds__(256)
 #endif
+#ifdef HAMK_RKF_MIN_WAVES_LANE                             /* the adaptive stepper capped so that this many wavefronts share a SIMD */
+#define HAMK_RKF_BOUNDS_LANE __launch_bounds__(256, HAMK_RKF_MIN_WAVES_LANE)
+#else
+#define HAMK_RKF_BOUNDS_LANE __launch_bounds__(256)
+#endif
 #define HAMK_INSTANTIATE(S)                                                                                      \
   HAMK_SCRIBBLE_KERNEL                                                                                           \
   extern "C" __global__ void HAMK_RK4_BOUNDS hamk_rk4_steps_k(double* q, double* p, long long B, double dt,      \
@@ -1994,7 +2067,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
                                                                            long long B) {                        \
     hamk::observe_config_body<S>(q, qd, ke, lag, B);                                                             \
   }                                                                                                              \
-  extern "C" __global__ void __launch_bounds__(256) hamk_rkf45_k(                                                \
+  extern "C" __global__ void HAMK_RKF_BOUNDS_LANE hamk_rkf45_k(                                                  \
       const double* q0, const double* p0, double* qout, double* pout, long long B, int nt, const double* ts,     \
       double ts0, double ts1, double h0, double eps_abs, double eps_rel, int flags, int max_sub,                 \
       int* status, int* nsub, int ncalls, int it_every) {                                                        \

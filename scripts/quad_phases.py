@@ -19,7 +19,7 @@ import isa_stats
 name = sys.argv[1] if len(sys.argv) > 1 else "chain32"
 s = api.system_from_spec(examples.get(name), {"mapping": _abi.MAP_QUAD})
 info = {l.split()[0]: l for l in s.build_info.splitlines()}
-kern = "hamk_hameqs_k"
+kern = sys.argv[2] if len(sys.argv) > 2 else "hamk_hameqs_k"
 ins = isa_stats.disassemble(s.code_object(1 if "no-machine-licm" in info[kern] else 0))[kern]
 cuts = [i for i, (_, mn, _) in enumerate(ins) if mn == "s_setprio"]
 bounds = [0] + cuts + [len(ins)]

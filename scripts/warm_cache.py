@@ -57,6 +57,12 @@ def jobs():
     out.append(("chain24", {"HAMK_RKF_PARK": "0"}, False))
     for n in ("chain32", "chain20"):
         out.append((n, {"HAMK_HIPRTC_FLAGS": "-DHAMK_QUAD_LEFT=1", "HAMK_QUAD": "1"}, False))      # left-looking Cholesky, K per panel (A/B, GPU parity test)
+    # round 4: systems with a non-positive inertia (lane kernels with the LU fallback, wave kernels with solve_pivoted), the
+    # small-ensemble quad module of chain12, the device sampler
+    for n in ("doublePendulum~mixed", "spring~mixed", "threeBodyPolar~mixed", "chain6~mixed", "chain12~mixed", "chain20~mixed"):
+        out.append((n, {}, False))
+    out.append(("chain12", {"HAMK_QUAD": "1"}, False))
+    out.append(("sampler", {}, False))
     return out
 
 
@@ -70,6 +76,14 @@ def build(job):
     os.environ.update(env)
     from hamilton_amd import api, examples
     try:
+        if name == "sampler":                               # hamk_sample.hpp: compiled before the device is looked at
+            spec = examples.get("pendulum")
+            s = api.system_from_spec(spec)
+            try:
+                api.sampleConfig(s, spec.q_box, spec.qd_box, 0, 4, 1)
+            except api.HamkError:
+                pass
+            return name, env, s.code_size
         if name.startswith("random"):
             from test_gpu_random_systems import random_spec
             spec = random_spec(int(name[6:]))
