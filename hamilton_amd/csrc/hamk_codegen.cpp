@@ -465,9 +465,7 @@ std::string generate_source(const SystemDesc& d) {
   o << "#define HAMK_USE_LUT " << d.use_lut << "\n";
   o << "#define HAMK_K_REASSOC " << (d.k_reassoc ? 1 : 0) << "\n";
   if (d.rk4_park && !d.wave) o << "#define HAMK_RK4_PARK 1\n";
-  if (d.mapping == HAMK_MAP_LANE && d.rkf_park) o << "#define HAMK_RKF_PARK 1\n";
   if (d.mapping == HAMK_MAP_QUAD) o << "#define HAMK_QUAD_RKF_PARK " << (d.rkf_park ? 1 : 0) << "\n";
-  if (d.wave && d.wave_blocked) o << "#define HAMK_WAVE_BLOCKED 1\n";
   // (sin, cos)(i 2pi/512), correctly rounded from 80-bit: the constant data behind sincos_lut's LDS table
   o << "#ifdef HAMK_HOST_EMULATION\nstatic const double hamk_trig_lut_init[1024] = {\n#else\n__device__ const double hamk_trig_lut_init[1024] = {\n#endif\n";
   for (int i = 0; i < 512; ++i) {

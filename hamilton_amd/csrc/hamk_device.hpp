@@ -51,14 +51,8 @@
 #ifndef HAMK_K_REASSOC
 #define HAMK_K_REASSOC 1      /* K = J^T M J summed with re-association allowed (mass_matrix); 0: the round-2 FMA chain */
 #endif
-#ifndef HAMK_RKF_PARK
-#define HAMK_RKF_PARK 0       /* RKF45 stage loop: the stepper's nine vectors wait in a run-time-indexed private array (scratch) */
-#endif
 #ifndef HAMK_RKF_LDS_BUDGET
 #define HAMK_RKF_LDS_BUDGET 76 /* doubles of LDS per lane the parked RKF45 stepper may use (hamk::RkfPark) */
-#endif
-#ifndef HAMK_RKF_PREFETCH_ROWS
-#define HAMK_RKF_PREFETCH_ROWS 3 /* parked RKF45 stepper: rows of the next stage combination fetched from scratch INSIDE the right-hand side (0..3) */
 #endif
 #ifndef HAMK_RK4_PARK
 #define HAMK_RK4_PARK 0       /* RK4 stage loop: y and the running combination parked in LDS across the right-hand side */
@@ -76,8 +70,6 @@ template <class T> struct bare<const T> { typedef T type; };
 template <class T> struct bare<T&> { typedef typename bare<T>::type type; };
 template <class T> struct bare<const T&> { typedef T type; };
 template <class T> using bare_t = typename bare<T>::type;
-
-template <int V> struct Int { static constexpr int v = V; };      // a compile-time integer as a value (generic lambdas: hiprtc has no <type_traits>)
 
 HAMK_DEV double quiet_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
 
@@ -919,17 +911,9 @@ template <class S> HAMK_DEV double potential_value(const double (&q)[S::N]) {
 // Both use dT/dq_i = -(M J qd) . ((dJ/dq_i) qd), which equals the reference's
 // -(p . K^-1 J^T M (dJ/dq_i) K^-1 p) because K^-1 is symmetric and qd = K^-1 p.
 // ---------------------------------------------------------------------------
-// A caller's work placed INSIDE a right-hand side, at the point where K, its factor and the first-order jets are dead and
-// the second-derivative sweep has not begun (the register file is at its emptiest there): the parked adaptive stepper
-// issues the loads of the rows its next stage combination needs at that point, so their round trip through the
-// vector-memory pipe runs under the reverse sweep instead of stalling the one wavefront a SIMD has (rkf45_body_parked).
-struct NoMid { static constexpr bool active = false; HAMK_DEV void operator()() const {} };
-template <class F> struct Mid { static constexpr bool active = true; F f; HAMK_DEV void operator()() const { f(); } };
-template <class F> HAMK_DEV Mid<F> make_mid(F f) { return Mid<F>{f}; }
-
-template <class S, bool MODE_H, int TRIG = TRIG_FULL, class MID = NoMid>
+template <class S, bool MODE_H, int TRIG = TRIG_FULL>
 HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (&dq)[S::N], double (&dp)[S::N], int& st,
-                      TrigCache<S::NTRIG_F>& tc, const MID& mid = MID()) {
+                      TrigCache<S::NTRIG_F>& tc) {
   constexpr int N = S::N, M = S::M;
   double K[N][N], gU[N], U, v[N], dT[N];
   if constexpr (MODE_H) {
@@ -951,7 +935,6 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
     mass_matrix<S>(xj, K);
     solve_spd<N, S::INERTIA_POS>(K, p, v, st);
     grad_potential<S>(qj, xj, gU, U, tc);
-    if constexpr (MID::active) mid();
 #pragma unroll
     for (int i = 0; i < N; ++i) dT[i] = 0.0;
 #pragma unroll
@@ -975,20 +958,6 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
     mass_matrix<S>(xj, K);
     solve_spd<N, S::INERTIA_POS>(K, p, v, st);
     grad_potential<S>(qj, xj, gU, U, tc);
-    if constexpr (MID::active) {
-#ifndef HAMK_HOST_EMULATION
-      // the solve's results are pinned in front of the hook: the hook usually branches (which rows the caller wants is a
-      // run-time matter), and IR-level sinking otherwise moves the whole first half of the right-hand side -- pure
-      // arithmetic whose results are only used after the branch -- BELOW it, so that the hook runs first
-#pragma unroll
-      for (int i = 0; i < N; ++i) { asm volatile("" : "+v"(v[i])); asm volatile("" : "+v"(gU[i])); }
-      __builtin_amdgcn_sched_barrier(0);                    // the hook's loads are issued HERE: after the solve, before the second sweep
-#endif
-      mid();
-#ifndef HAMK_HOST_EMULATION
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
     if constexpr (S::MODE_R) {
       // MODE_R: the contraction is a gradient -- one forward (value, tangent along qd) pass and one
       // reverse pass over the tape (generated, S::dT_reverse), O(tape) instead of O(n * tape)
@@ -1047,13 +1016,13 @@ template <class S> struct StageTrig {
   static constexpr int dyn = on ? TRIG_DYN : (lut ? TRIG_LUT : TRIG_FULL);       // the fixed-step loops
 };
 
-template <class S, int TRIG = TRIG_FULL, class MID = NoMid>
-HAMK_DEV void rhs(const double (&y)[2 * S::N], double (&dy)[2 * S::N], int& st, TrigCache<S::NTRIG_F>& tc, const MID& mid = MID()) {
+template <class S, int TRIG = TRIG_FULL>
+HAMK_DEV void rhs(const double (&y)[2 * S::N], double (&dy)[2 * S::N], int& st, TrigCache<S::NTRIG_F>& tc) {
   constexpr int N = S::N;
   double q[N], p[N], dq[N], dp[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) { q[i] = y[i]; p[i] = y[N + i]; }
-  ham_eqs<S, S::MODE_H, TRIG, MID>(q, p, dq, dp, st, tc, mid);
+  ham_eqs<S, S::MODE_H, TRIG>(q, p, dq, dp, st, tc);
 #pragma unroll
   for (int i = 0; i < N; ++i) { dy[i] = dq[i]; dy[N + i] = dp[i]; }
 }
@@ -1407,9 +1376,16 @@ template <int D> HAMK_DEV void probe_pin(double (&x)[D]) {
 //     run-time row (the stage counter), which keeps it in scratch memory (lane-interleaved: coalesced);
 //   * dydt at the trial state never leaves the registers: it is the last right-hand side's result, consumed by the
 //     error norm and the commit right after it; every right-hand side's result is used from the registers by the stage
-//     that follows it (RkfPark<S>::REUSE; k6 is then never stored); the error combination is formed in stage 6 from the
-//     rows that stage loads anyway.
-// At n = 16, 17 rows of 2n doubles cross the vector-memory pipe per attempt.  That traffic is what bounds this kernel:
+//     that follows it (k6 is then never stored); the error combination is formed in stage 6 from the rows that stage
+//     loads anyway.
+// At n = 16, 17 rows of 2n doubles cross the vector-memory pipe per attempt -- the minimum for this mapping: five vectors
+// must wait across the fourth right-hand side (y, dydt, k2, k3, k4), the CU's LDS holds two of them next to 256 lanes, and
+// a lane's registers are K's.  Round 4 tried to hide the round trips instead: the next stage's rows fetched INSIDE the
+// right-hand side, after the solve, where K is dead (one to three rows; it took an escaping asm barrier and pinned solve
+// results to keep LLVM from hoisting the loads back out).  Measured on MI355X (profiles/r04_rkf_prefetch_ab.jsonl,
+// stepHam dt, B = 65 536): chain16 1.68e8 -> 1.15e8 calls/s (three rows: 386 spilled registers under the reverse sweep),
+// 1.29e8 with one row; chain14 -10 %, chain12 -10 %, chain8 -5 %.  The reverse sweep has no registers to lend.  Removed.
+// That traffic is what bounds this kernel:
 // a first version with all nine vectors in scratch moved 44 rows -- chain16 3.6 GB of HBM traffic per launch, 4.4 TB/s,
 // VALU 22 % busy (profiles/r03f_chain16_stepham_summary.json); with 23 rows: 1.7 GB, 3.6 TB/s, 36 % (r03g).  The statements of
 // rkf45_body below otherwise (same GSL semantics, same flags; the compiler contracts the combinations into FMAs on its
@@ -1417,7 +1393,7 @@ template <int D> HAMK_DEV void probe_pin(double (&x)[D]) {
 template <class S> struct RkfPark {
   static constexpr int D = 2 * S::N;
   static constexpr int BUDGET = HAMK_RKF_LDS_BUDGET;        // doubles per lane; 76: (160 KiB - sincos table - slack) / 256 lanes / 8
-  static constexpr int NL = (BUDGET / D) < 2 ? 2 : ((BUDGET / D) > 6 ? 6 : (BUDGET / D));      // y, dydt, then k2, k3, k4, k5 (6 rows: nothing waits in scratch)
+  static constexpr int NL = (BUDGET / D) < 2 ? 2 : ((BUDGET / D) > 6 ? 6 : (BUDGET / D));      // y, dydt, then k2, k3, k4, k5 (6 rows, n = 6: nothing waits in scratch)
 };
 template <class S>
 HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt, const double* __restrict__ ts, double ts0, double ts1,
@@ -1447,9 +1423,8 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
   // instruction can encode make the compiler keep several derived bases alive through the right-hand side -- chain16: 66
   // spilled registers instead of 24, 7.8e7 -> 6.1e7 stepHam/s)
 #define HAMK_RKF_LROW(r) (rows + (r) * D * 256 + threadIdx.x)
-  // k_{2 + KR}[j] where a stage combination reads it: from its LDS row, or -- a row that waits in scratch -- from the slot of
-  // `pre` the previous right-hand side's hook fetched it into (see `prefetch` below)
-#define HAMK_RKF_K(KR, SLOT, j) ((2 + (KR) < NL) ? HAMK_RKF_LROW(2 + (KR))[(j) * 256] : ((SLOT) < HAMK_RKF_PREFETCH_ROWS ? pre[SLOT][j] : v[KR][j]))
+#define HAMK_RKF_K(KR, j) ((2 + (KR) < NL) ? HAMK_RKF_LROW(2 + (KR))[(j) * 256] : v[KR][j])      /* k_{2 + KR}[j] */
+#define HAMK_RKF_RECENT(KR, j) (out[j])                  /* a right-hand side's result is used from the registers by the stage that follows it */
   auto put_k = [&](int kr, const double (&x)[D]) {         // k_{2 + kr}; kr: a run-time value (the stage counter)
     if (NL > 2 && 2 + kr < NL) {
 #pragma unroll
@@ -1502,51 +1477,10 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
       bool final_step = false;
       if ((dt >= 0.0 && hh > dt) || (dt < 0.0 && hh < dt)) { hh = dt; final_step = true; }
       double out[D];                                        // the last right-hand side's result: k_{sg + 1} at the top of stage sg
-      // The rows of the NEXT stage combination that wait in scratch memory, fetched by the hook INSIDE the right-hand side
-      // that precedes it (ham_eqs' MID, after the solve: K and its factor are dead there, so the 3 x 2n registers are
-      // free) -- their round trip through the vector-memory pipe runs under the reverse sweep instead of in front of the
-      // combination.  Round 3 loaded them at the top of the stage, and with one wavefront per SIMD nothing else could
-      // run meanwhile: chain16's launch took exactly as long as its 1.35 GB of row traffic at 3 TB/s.  Same rows, same
-      // expressions, same bits; only WHEN the loads are issued changes.
-      double pre[3][D];
 #pragma unroll
-      for (int j = 0; j < D; ++j) { out[j] = 0.0; pre[0][j] = pre[1][j] = pre[2][j] = 0.0; }
-      int sg = 0;                                           // (declared outside the loop: the hook reads it)
-      auto fetch = [&](auto slot, auto kr) {                // pre[slot] = k_{2 + kr}, if that row waits in scratch
-        if constexpr (2 + decltype(kr)::v >= NL && decltype(slot)::v < HAMK_RKF_PREFETCH_ROWS) {
-#pragma unroll
-          for (int j = 0; j < D; ++j) pre[decltype(slot)::v][j] = v[decltype(kr)::v][j];
-        }
-      };
-      auto prefetch = make_mid([&]() {                      // what the combination of stage sg + 1 (or the error norm) reads
-#ifndef HAMK_HOST_EMULATION
-        // The loads must be ISSUED HERE.  Left alone, LLVM's load-PRE sees that this switch and the switch of the stage
-        // combinations select on the same value, makes every row "available" in the combination's case block -- i.e. loads
-        // it BEFORE the right-hand side -- and then spills it across the factorisation (first version: 1122 spilled
-        // registers).  The array's address escapes into an opaque statement that may touch memory: no load of it may be
-        // moved above this point.
-        { double* vp = &v[0][0]; asm volatile("" : : "v"(vp) : "memory"); }
-#endif
-        switch (sg) {
-          case 0: break;                                                               // stage 2: f0 and k2 -- k2 comes from `out`
-          case 1: fetch(Int<0>(), Int<0>()); break;                                                        // stage 3: k2 | k3 from `out`
-          case 2: fetch(Int<0>(), Int<0>()); fetch(Int<1>(), Int<1>()); break;                             // stage 4: k2, k3
-          case 3: fetch(Int<0>(), Int<0>()); fetch(Int<1>(), Int<1>()); fetch(Int<2>(), Int<2>()); break;  // stage 5: k2, k3, k4
-          case 4: fetch(Int<0>(), Int<1>()); fetch(Int<1>(), Int<2>()); fetch(Int<2>(), Int<3>()); break;  // stage 6: k3, k4, k5
-          default:                                                                                         // the norm: trial state, error
-            if constexpr (NL < 3 && 0 < HAMK_RKF_PREFETCH_ROWS) {
-#pragma unroll
-              for (int j = 0; j < D; ++j) pre[0][j] = v[5][j];
-            }
-            if constexpr (NL < 4 && 1 < HAMK_RKF_PREFETCH_ROWS) {
-#pragma unroll
-              for (int j = 0; j < D; ++j) pre[1][j] = v[6][j];
-            }
-            break;
-        }
-      });
+      for (int j = 0; j < D; ++j) out[j] = 0.0;
 #pragma unroll 1
-      for (sg = 0; sg < 6; ++sg) {
+      for (int sg = 0; sg < 6; ++sg) {
         double yt[D];
         switch (sg) {
           case 0:
@@ -1555,31 +1489,31 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
             break;
           case 1:
 #pragma unroll
-            for (int j = 0; j < D; ++j) yt[j] = py[j * 256] + hh * ((3.0 / 32.0) * pf[j * 256] + (9.0 / 32.0) * out[j]);
+            for (int j = 0; j < D; ++j) yt[j] = py[j * 256] + hh * ((3.0 / 32.0) * pf[j * 256] + (9.0 / 32.0) * HAMK_RKF_RECENT(0, j));
             break;
           case 2:
 #pragma unroll
             for (int j = 0; j < D; ++j)
-              yt[j] = py[j * 256] + hh * ((1932.0 / 2197.0) * pf[j * 256] + (-7200.0 / 2197.0) * HAMK_RKF_K(0, 0, j) + (7296.0 / 2197.0) * out[j]);
+              yt[j] = py[j * 256] + hh * ((1932.0 / 2197.0) * pf[j * 256] + (-7200.0 / 2197.0) * HAMK_RKF_K(0, j) + (7296.0 / 2197.0) * HAMK_RKF_RECENT(1, j));
             break;
           case 3:
 #pragma unroll
             for (int j = 0; j < D; ++j)
-              yt[j] = py[j * 256] + hh * ((8341.0 / 4104.0) * pf[j * 256] + (-32832.0 / 4104.0) * HAMK_RKF_K(0, 0, j) +
-                                          (29440.0 / 4104.0) * HAMK_RKF_K(1, 1, j) + (-845.0 / 4104.0) * out[j]);
+              yt[j] = py[j * 256] + hh * ((8341.0 / 4104.0) * pf[j * 256] + (-32832.0 / 4104.0) * HAMK_RKF_K(0, j) +
+                                          (29440.0 / 4104.0) * HAMK_RKF_K(1, j) + (-845.0 / 4104.0) * HAMK_RKF_RECENT(2, j));
             break;
           case 4:
 #pragma unroll
             for (int j = 0; j < D; ++j)
-              yt[j] = py[j * 256] + hh * ((-6080.0 / 20520.0) * pf[j * 256] + (41040.0 / 20520.0) * HAMK_RKF_K(0, 0, j) +
-                                          (-28352.0 / 20520.0) * HAMK_RKF_K(1, 1, j) + (9295.0 / 20520.0) * HAMK_RKF_K(2, 2, j) +
-                                          (-5643.0 / 20520.0) * out[j]);
+              yt[j] = py[j * 256] + hh * ((-6080.0 / 20520.0) * pf[j * 256] + (41040.0 / 20520.0) * HAMK_RKF_K(0, j) +
+                                          (-28352.0 / 20520.0) * HAMK_RKF_K(1, j) + (9295.0 / 20520.0) * HAMK_RKF_K(2, j) +
+                                          (-5643.0 / 20520.0) * HAMK_RKF_RECENT(3, j));
             break;
           default: {
             double ye[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-              const double f0 = pf[j * 256], k3 = HAMK_RKF_K(1, 0, j), k4 = HAMK_RKF_K(2, 1, j), k5 = HAMK_RKF_K(3, 2, j), k6 = out[j];
+              const double f0 = pf[j * 256], k3 = HAMK_RKF_K(1, j), k4 = HAMK_RKF_K(2, j), k5 = HAMK_RKF_K(3, j), k6 = HAMK_RKF_RECENT(4, j);
               const double di = (902880.0 / 7618050.0) * f0 + (3953664.0 / 7618050.0) * k3 +
                                 (3855735.0 / 7618050.0) * k4 + (-1371249.0 / 7618050.0) * k5 +
                                 (277020.0 / 7618050.0) * k6;
@@ -1593,34 +1527,27 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
             break;
           }
         }
-        // `pre` has been consumed: it must not stay live across the first half of the right-hand side, where K wants the whole
-        // register file.  Which slots the hook refills depends on the run-time stage, so without this the compiler has to
-        // assume the old contents are read again and carries 3 x 2n registers through the factorisation (measured on the
-        // first version: 1122 spilled registers at n = 16 instead of 21)
-#pragma unroll
-        for (int j = 0; j < D; ++j) pre[0][j] = pre[1][j] = pre[2][j] = 0.0;
         HAMK_MARK(3);
         HAMK_PIN(yt);
 #ifndef HAMK_HOST_EMULATION
-        __builtin_amdgcn_sched_barrier(0);                  // no row is fetched early into the first half of the right-hand side
+        __builtin_amdgcn_sched_barrier(0);                  // no row is fetched early into the right-hand side
 #endif
-        rhs<S, StageTrig<S>::lut ? TRIG_LUT : TRIG_FULL>(yt, out, st, tc, prefetch);
+        rhs<S, StageTrig<S>::lut ? TRIG_LUT : TRIG_FULL>(yt, out, st, tc);
 #ifndef HAMK_HOST_EMULATION
         __builtin_amdgcn_sched_barrier(0);
 #endif
         HAMK_PIN(out);
         HAMK_MARK(0);
-        if (sg < 4) put_k(sg, out);                         // k2..k5; k6 and dydt_out are used from the registers
+        if (sg < 4) put_k(sg, out);                         // k2..k5; k6 and dydt_out are used from the registers and never stored
       }
       // --- cstd.c: std_control_hadjust, ord = 5 ------------------------------
       double yn[D];
       double rmax = 2.2250738585072014e-308;
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        yn[j] = (NL >= 3) ? HAMK_RKF_LROW(2)[j * 256] : (0 < HAMK_RKF_PREFETCH_ROWS ? pre[0][j] : v[5][j]);
-        const double ej = (NL >= 4) ? HAMK_RKF_LROW(3)[j * 256] : (1 < HAMK_RKF_PREFETCH_ROWS ? pre[1][j] : v[6][j]);
+        yn[j] = HAMK_RKF_YN(j);
         const double D0 = eps_rel * (fabs(yn[j]) + fabs(hh * out[j])) + eps_abs;
-        const double rr = fabs(ej) / fabs(D0);
+        const double rr = fabs(HAMK_RKF_E(j)) / fabs(D0);
         rmax = (rr > rmax) ? rr : rmax;
       }
       const double tnew = final_step ? ti : t + hh;
@@ -1668,6 +1595,7 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
   if (bad) st |= ST_NONFINITE;
   if (status) status[i] = st;
   if (nsub) nsub[i] = attempts;
+#undef HAMK_RKF_RECENT
 #undef HAMK_RKF_YN
 #undef HAMK_RKF_E
 #undef HAMK_RKF_K
@@ -1683,7 +1611,11 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
   //   bits 8-9   0: rows go to qout/pout + r N B (evolveHam); 1: the final state overwrites qout/pout (stepHam in place);
   //              2: iterate -- the final state overwrites q0/p0, qout/pout receive every it_every-th state
   //   bits 16-17 which binding of gsl-ode.c (1 | 2)
-  if constexpr (S::RKF_STAGE_LOOP && HAMK_RKF_PARK) {
+  // Two bodies: THIS one with the six evaluations of an attempt unrolled and everything in registers (small systems), and
+  // the stage loop -- one inlined right-hand side run six times through a wave-uniform stage switch -- whose vectors are
+  // parked (rkf45_body_parked above; until round 4 an unparked stage loop existed too: it tied for n = 4, 5 and lost from
+  // n = 6, profiles/r03_lane_rkf_park.jsonl)
+  if constexpr (S::RKF_STAGE_LOOP) {
     rkf45_body_parked<S>(q0, p0, qout, pout, B, nt, ts, ts0, ts1, h0, eps_abs, eps_rel, flags, max_sub, status, nsub, ncalls, it_every);
     return;
   }
@@ -1737,87 +1669,10 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
       bool final_step = false;
       if ((dt >= 0.0 && hh > dt) || (dt < 0.0 && hh < dt)) { hh = dt; final_step = true; }
       // --- rkf45.c -----------------------------------------------------------
-      // RKF_STAGE_LOOP: one inlined copy of the right-hand side, run for the six evaluations of an
-      // attempt (k2..k6 and dydt_out) through a wave-uniform stage switch -- far less code for
-      // large systems; otherwise the six evaluations are unrolled (fewer registers for small n).
       double k2[D], k3[D], k4[D], k5[D], k6[D], yn[D], fn[D];
 #pragma unroll
       for (int j = 0; j < D; ++j) { k2[j] = k3[j] = k4[j] = k5[j] = k6[j] = 0.0; yn[j] = y[j]; fn[j] = 0.0; }
-      if constexpr (S::RKF_STAGE_LOOP) {
-#pragma unroll 1
-      for (int sg = 0; sg < 6; ++sg) {
-        double yt[D], out[D];
-        switch (sg) {
-          case 0:
-#pragma unroll
-            for (int j = 0; j < D; ++j) yt[j] = y[j] + (1.0 / 4.0) * hh * f0[j];
-            break;
-          case 1:
-#pragma unroll
-            for (int j = 0; j < D; ++j) yt[j] = y[j] + hh * ((3.0 / 32.0) * f0[j] + (9.0 / 32.0) * k2[j]);
-            break;
-          case 2:
-#pragma unroll
-            for (int j = 0; j < D; ++j)
-              yt[j] = y[j] + hh * ((1932.0 / 2197.0) * f0[j] + (-7200.0 / 2197.0) * k2[j] + (7296.0 / 2197.0) * k3[j]);
-            break;
-          case 3:
-#pragma unroll
-            for (int j = 0; j < D; ++j)
-              yt[j] = y[j] + hh * ((8341.0 / 4104.0) * f0[j] + (-32832.0 / 4104.0) * k2[j] +
-                                   (29440.0 / 4104.0) * k3[j] + (-845.0 / 4104.0) * k4[j]);
-            break;
-          case 4:
-#pragma unroll
-            for (int j = 0; j < D; ++j)
-              yt[j] = y[j] + hh * ((-6080.0 / 20520.0) * f0[j] + (41040.0 / 20520.0) * k2[j] +
-                                   (-28352.0 / 20520.0) * k3[j] + (9295.0 / 20520.0) * k4[j] +
-                                   (-5643.0 / 20520.0) * k5[j]);
-            break;
-          default:
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-              const double di = (902880.0 / 7618050.0) * f0[j] + (3953664.0 / 7618050.0) * k3[j] +
-                                (3855735.0 / 7618050.0) * k4[j] + (-1371249.0 / 7618050.0) * k5[j] +
-                                (277020.0 / 7618050.0) * k6[j];
-              yn[j] = y[j] + hh * di;
-              yt[j] = yn[j];
-            }
-            break;
-        }
-        HAMK_MARK(3);
-        HAMK_PIN(yt);
-        rhs<S, StageTrig<S>::lut ? TRIG_LUT : TRIG_FULL>(yt, out, st, tc);
-        HAMK_PIN(out);
-        HAMK_MARK(0);
-        switch (sg) {
-          case 0:
-#pragma unroll
-            for (int j = 0; j < D; ++j) k2[j] = out[j];
-            break;
-          case 1:
-#pragma unroll
-            for (int j = 0; j < D; ++j) k3[j] = out[j];
-            break;
-          case 2:
-#pragma unroll
-            for (int j = 0; j < D; ++j) k4[j] = out[j];
-            break;
-          case 3:
-#pragma unroll
-            for (int j = 0; j < D; ++j) k5[j] = out[j];
-            break;
-          case 4:
-#pragma unroll
-            for (int j = 0; j < D; ++j) k6[j] = out[j];
-            break;
-          default:
-#pragma unroll
-            for (int j = 0; j < D; ++j) fn[j] = out[j];                  // dydt_out
-            break;
-        }
-      }
-      } else {
+      {
         double yt[D];
 #pragma unroll
         for (int j = 0; j < D; ++j) yt[j] = y[j] + (1.0 / 4.0) * hh * f0[j];
@@ -2031,11 +1886,6 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
 #else
 #define HAMK_RK4_BOUNDS __launch_bounds__(256)
 #endif
-#ifdef HAMK_RKF_MIN_WAVES_LANE                             /* the adaptive stepper capped so that this many wavefronts share a SIMD */
-#define HAMK_RKF_BOUNDS_LANE __launch_bounds__(256, HAMK_RKF_MIN_WAVES_LANE)
-#else
-#define HAMK_RKF_BOUNDS_LANE __launch_bounds__(256)
-#endif
 #define HAMK_INSTANTIATE(S)                                                                                      \
   HAMK_SCRIBBLE_KERNEL                                                                                           \
   extern "C" __global__ void HAMK_RK4_BOUNDS hamk_rk4_steps_k(double* q, double* p, long long B, double dt,      \
@@ -2067,7 +1917,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
                                                                            long long B) {                        \
     hamk::observe_config_body<S>(q, qd, ke, lag, B);                                                             \
   }                                                                                                              \
-  extern "C" __global__ void HAMK_RKF_BOUNDS_LANE hamk_rkf45_k(                                                  \
+  extern "C" __global__ void __launch_bounds__(256) hamk_rkf45_k(                                                \
       const double* q0, const double* p0, double* qout, double* pout, long long B, int nt, const double* ts,     \
       double ts0, double ts1, double h0, double eps_abs, double eps_rel, int flags, int max_sub,                 \
       int* status, int* nsub, int ncalls, int it_every) {                                                        \

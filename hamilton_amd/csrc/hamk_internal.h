@@ -4,7 +4,11 @@
 #include <string>
 #include <vector>
 
+// libhamk.so is built with -fvisibility=hidden: what it exports is exactly the C ABI of include/hamk.h (the host code is three
+// translation units since round 4, and their shared C++ symbols are nobody else's business)
+#pragma GCC visibility push(default)
 #include "hamk.h"
+#pragma GCC visibility pop
 
 namespace hamk_host {
 

@@ -331,189 +331,13 @@ template <class S, bool LUT> struct Trig {
   static constexpr int mode1 = shared ? TRIG_REUSE : (LUT ? TRIG_LUT : TRIG_FULL);
 };
 
-// Which factorisation ships (both are kept, both are tested on the host and on the GPU):
-//   0  K assembled whole by ONE sweep, LDL^T right-looking in rank-4 panels (ldlt below).  The fewest instructions (8.4 k per
-//      lane and right-hand side at n = 32), but K + the sweep's working set + a panel's multipliers exceed the 512
-//      registers: 160 spilled, ~50 scratch instructions per right-hand side.
-//   1  left-looking Cholesky, K assembled panel by panel by eight sweeps (panel<JB>): the trailing matrix is never
-//      materialised, no scratch in the stepping loop, HBM traffic 1.5 x the state -- at 9.5 k instructions (the selects
-//      "row 4 i + r" and the sincos loads are repeated per panel).
-// Measured on one MI355X, same box, back to back (profiles/r03_quad_ab.jsonl): chain32 2.51e8 vs 2.15e8 steps/s, chain24
-// 4.86e8 vs 3.85e8, chain16 at B = 16 384 9.0e8 vs 7.2e8: the instruction count decides, not the scratch traffic.
-#ifndef HAMK_QUAD_LEFT
-#define HAMK_QUAD_LEFT 0
-#endif
-
-// 1 / sqrt(d): hardware estimate + two Newton steps (d > 0; a non-positive pivot yields NaN and is flagged by the caller)
-HAMK_DEV double frsq(double d) {
-  double r = __builtin_amdgcn_rsq(d);
-  r = fma(r * 0.5, fma(-(d * r), r, 1.0), r);
-  r = fma(r * 0.5, fma(-(d * r), r, 1.0), r);
-  return r;
-}
-
-// Columns [4 JB, 4 JB + 4) of K for the lane's rows of slots >= JB, accumulated by one sweep (what the sweep computes for
-// the other columns is dead code and is not generated).
-template <class S, int JB> struct SinkPanel {
-  static constexpr int N = S::N, NR = Geo<N>::NR;
-  double C[NR][4];
-  int r;
-  HAMK_DEV void init(int r_) {
-    r = r_;
-#pragma unroll
-    for (int i = 0; i < NR; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) C[i][jj] = 0.0;
-  }
-  template <int K, int SEQ> HAMK_DEV void put(const Jet1<N>& x) {
-#pragma clang fp reassociate(on)
-#pragma unroll
-    for (int i = JB; i < NR; ++i) {
-      const double xs = S::inertia(K) * sel4(r, dget<N>(x.d, 4 * i), dget<N>(x.d, 4 * i + 1), dget<N>(x.d, 4 * i + 2), dget<N>(x.d, 4 * i + 3));
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-        if (4 * JB + jj < N) C[i][jj] += xs * x.d[(4 * JB + jj < N) ? 4 * JB + jj : 0];
-    }
-  }
-};
-
-// LEFT-LOOKING CHOLESKY, K = G G^T, one panel of four columns at a time -- and K itself assembled panel by panel, each
-// by its own sweep: the trailing matrix of a right-looking factorisation is never materialised, so what a lane holds is
-// the finished part of G (growing to its 144 doubles at n = 32 only at the end) plus ONE panel (32 doubles), instead of all
-// of K plus the sweep's working set at once.  (Whole-K-then-factorise needs ~740 registers at n = 32: 230 spilled, 56 GB of
-// scratch stores per launch against 67 MB of state -- profiles/r03_chain32_summary.json.)  Cholesky rather than LDL^T:
-// the update K[a][k] -= G[a][j] G[k][j] needs no pivot values of earlier panels on either side.
-//   per panel JB:  sweep -> C = K[:, panel] (own rows);  C -= sum over finished columns j: G[own rows][j] x G[panel rows][j]
-//   (the four panel-row values of column j broadcast by DPP);  the 4 x 4 diagonal block and the panel's columns factored
-//   pivot by pivot with the forward substitution of the right-hand side riding along.
-// A sweep costs a few hundred instructions for the systems this mapping serves (sparse Jacobians), 8 sweeps at n = 32.
-template <class S, bool LUT, int JB, class TC>
-HAMK_DEV void panel(const Ctx<S>& c0, TC& tc, double (&G)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], double& U, bool& ok) {
-  // z[i]: the right-hand side of the lane's row of slot i until that slot's panel is done, (G^-1 rhs) of that row afterwards;
-  // G[i][4 i + r] (the lane's diagonal entry) holds 1 / G_aa -- what both substitutions divide by -- instead of G_aa.
-  constexpr int N = S::N, NR = Geo<N>::NR, J0 = 4 * JB, J1 = (J0 + 4 < N) ? J0 + 4 : N;
-  HAMK_PHASE();
-#ifndef HAMK_QUAD_LAUNDER_EVERY
-#define HAMK_QUAD_LAUNDER_EVERY 1
-#endif
-  const Ctx<S> c = (JB % HAMK_QUAD_LAUNDER_EVERY == 0) ? c0.launder() : c0;   // fresh addresses per panel: what a sweep needs of q and the sincos pairs is re-read
-  const int r = c.r;                        // from LDS instead of all 2n pairs being kept in registers across the factorisation
-  SinkPanel<S, JB> sink;
-  sink.init(r);
-  {
-    InJet1<N> in{c.q()};
-    constexpr int mode = (JB == 0) ? Trig<S, LUT>::mode1 : TRIG_REUSE;
-    if constexpr (JB == 0) {
-      TrigCache<S::NTRIG_U> tu;
-      Jet1<N> u;
-      if constexpr (Trig<S, LUT>::shared) { TrigLdsQ<S> tl = c.trig(); u = S::template coords_sink_u<Jet1<N>, mode>(in, tl, tu, sink); }
-      else u = S::template coords_sink_u<Jet1<N>, mode>(in, tc, tu, sink);
-      U = u.v;
-#pragma unroll
-      for (int i = 0; i < NR; ++i)
-        c.gu()[(4 * i + r) * 64] = sel4(r, dget<N>(u.d, 4 * i), dget<N>(u.d, 4 * i + 1), dget<N>(u.d, 4 * i + 2), dget<N>(u.d, 4 * i + 3));
-    } else {
-      if constexpr (Trig<S, LUT>::shared) { TrigLdsQ<S> tl = c.trig(); S::template coords_sink<Jet1<N>, mode>(in, tl, sink); }
-      else S::template coords_sink<Jet1<N>, mode>(in, tc, sink);
-    }
-  }
-  double (&C)[NR][4] = sink.C;
-  // rows >= N (n not a multiple of four): identity
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr)
-    if (J0 + rr >= N) C[JB][rr] = (r == rr) ? 1.0 : C[JB][rr];
-  HAMK_PHASE();
-  // the finished columns
-#pragma unroll
-  for (int j = 0; j < J0; ++j) {
-    double ck[4];
-    ck[0] = qbcast<0>(G[JB][j]); ck[1] = qbcast<1>(G[JB][j]); ck[2] = qbcast<2>(G[JB][j]); ck[3] = qbcast<3>(G[JB][j]);
-#pragma unroll
-    for (int i = JB; i < NR; ++i) {
-      const double g = G[i][j];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-        if (J0 + kk < N) C[i][kk] = fma(-g, ck[kk], C[i][kk]);
-    }
-  }
-  HAMK_PHASE();
-  // the panel itself
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int j = J0 + jj;
-    if (j >= J1) continue;
-    double d, zj;
-    switch (jj) {
-      case 0: d = qbcast<0>(C[JB][0]); zj = qbcast<0>(z[JB]); break;
-      case 1: d = qbcast<1>(C[JB][1]); zj = qbcast<1>(z[JB]); break;
-      case 2: d = qbcast<2>(C[JB][2]); zj = qbcast<2>(z[JB]); break;
-      default: d = qbcast<3>(C[JB][3]); zj = qbcast<3>(z[JB]); break;
-    }
-    ok = ok && (d > 0.0);
-    const double rs = frsq(d);
-    const double yj = zj * rs;                            // G y = rhs: y_j
-    double g[NR], gl[NR];                                 // column j of G for the lane's rows (gl: strictly below the pivot)
-#pragma unroll
-    for (int i = JB; i < NR; ++i) {
-      const double t = C[i][jj] * rs;
-      g[i] = (4 * i + r >= j) ? t : 0.0;
-      gl[i] = (4 * i + r > j) ? t : 0.0;
-      z[i] = fma(-gl[i], yj, z[i]);
-    }
-    z[JB] = (r == jj) ? yj : z[JB];                       // (gl is 0 for this row: untouched above)
-#pragma unroll
-    for (int kk = jj + 1; kk < 4; ++kk) {
-      if (J0 + kk >= J1) continue;
-      double gk;
-      switch (kk) {
-        case 1: gk = qbcast<1>(g[JB]); break;
-        case 2: gk = qbcast<2>(g[JB]); break;
-        default: gk = qbcast<3>(g[JB]); break;
-      }
-#pragma unroll
-      for (int i = JB; i < NR; ++i) C[i][kk] = fma(-gl[i], gk, C[i][kk]);
-    }
-#pragma unroll
-    for (int i = JB; i < NR; ++i) G[i][j] = g[i];
-    G[JB][j] = (r == jj) ? rs : G[JB][j];
-  }
-}
-
-template <class S, bool LUT, int JB, class TC>
-HAMK_DEV void panels(const Ctx<S>& c, TC& tc, double (&G)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], double& U, bool& ok) {
-  if constexpr (JB < Geo<S::N>::NR) {
-    panel<S, LUT, JB>(c, tc, G, z, U, ok);
-    panels<S, LUT, JB + 1>(c, tc, G, z, U, ok);
-  }
-}
-
-// G^T v = y; returns the lane's v_(4 i + r).  Row-oriented: G[k][a] is in the lane that owns row k, so the lanes accumulate
-// partial sums s[a] = sum over their own solved rows k > a of G[k][a] v_k and the four partial sums meet in a quad
-// reduction when v_a is due.
-template <class S>
-HAMK_DEV void solve_back_chol(int r, const double (&G)[Geo<S::N>::NR][Geo<S::N>::NP4], const double (&y)[Geo<S::N>::NR], double (&v)[Geo<S::N>::NR]) {
-  constexpr int N = S::N, NR = Geo<N>::NR, NP4 = Geo<N>::NP4;
-  double s[NP4];
-#pragma unroll
-  for (int a = 0; a < NP4; ++a) s[a] = 0.0;
-#pragma unroll
-  for (int i = NR - 1; i >= 0; --i) {
-    HAMK_PHASE();
-    double vi = 0.0;
-#pragma unroll
-    for (int rr = 3; rr >= 0; --rr) {
-      const int a = 4 * i + rr;
-      if (a >= N) continue;
-      const double va = (y[i] - qsum(s[a])) * G[i][a];    // meaningful in lane rr, whose G[i][a] is 1 / G_aa
-      if (r == rr) vi = va;
-#pragma unroll
-      for (int a2 = 4 * i; a2 < a; ++a2) s[a2] = fma((r == rr) ? G[i][a2] : 0.0, va, s[a2]);
-    }
-    v[i] = vi;
-#pragma unroll
-    for (int a2 = 0; a2 < 4 * i; ++a2) s[a2] = fma(G[i][a2], vi, s[a2]);
-  }
-}
+// One factorisation ships: K assembled whole by ONE sweep, LDL^T right-looking in rank-4 panels (ldlt above) -- the fewest
+// instructions (8.4 k per lane and right-hand side at n = 32), at the price of 160 spilled registers (~50 scratch instructions
+// per right-hand side: K + the sweep's working set + a panel's multipliers exceed the 512 registers).  The alternative built
+// and measured in round 3 -- left-looking Cholesky with K assembled panel by panel by eight sweeps: no scratch in the
+// stepping loop, HBM traffic 1.5 x the state, but 9.5 k instructions -- lost on the same box, back to back
+// (profiles/r03_quad_ab.jsonl: chain32 2.51e8 vs 2.15e8 steps/s, chain24 4.86e8 vs 3.85e8, chain16 at B = 16 384 9.0e8 vs
+// 7.2e8: the instruction count decides, not the scratch traffic) and was removed in round 4 (git history: 70845bd).
 
 // q of the quad's trajectory to LDS and, when every sincos site of f takes an input as operand, the pairs of the lane's
 // own coordinates with it (each lane evaluates its n/4 angles once; all sweeps of the evaluation read them).
@@ -556,19 +380,6 @@ HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const
   constexpr int N = S::N, NR = Geo<N>::NR;
   const int r = c.r;
   stage_inputs<S, LUT>(c, qi);
-#if HAMK_QUAD_LEFT
-  double G[NR][Geo<N>::NP4], z[NR];
-#pragma unroll
-  for (int i = 0; i < NR; ++i) z[i] = pi[i];
-  bool ok = true;
-  panels<S, LUT, 0>(c, tc, G, z, U, ok);
-  if (!ok) st |= ST_SINGULAR;                             // (as above: K is semi-definite on this mapping)
-  HAMK_PHASE();
-  solve_back_chol<S>(r, G, z, vi);
-  HAMK_PHASE();
-#pragma unroll
-  for (int i = 0; i < NR; ++i) gUi[i] = 0.0;              // (dU/dq waits in LDS: Ctx::gu)
-#else
   SinkK<S> sink;
   sink.init(r);
   InJet1<N> in{c.q()};
@@ -587,7 +398,6 @@ HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const
   HAMK_PHASE();
   solve_back<S>(r, sink.acc, z, vi);
   HAMK_PHASE();
-#endif
 }
 
 // hamEqs for the quad's trajectory: the lane returns (dq, dp) of its coordinates.         Hamilton.hs:370-387

@@ -7,8 +7,8 @@
 // Bit-identical to hamilton_amd/examples.py sample_config / uniform01 (numpy, the CPU tests' sampler):
 //   key = seed ^ (index * 0xD1342543DE82EF95);  z = splitmix64(key + field * 0x2545F4914F6CDD1D);
 //   u = (z >> 11) * 2^-53;  value = lo + (hi - lo) * u            -- field 2j: q_j, field 2j + 1: qd_j
-// The last line is three separately rounded IEEE operations in numpy, so it is spelled with __dsub_rn / __dmul_rn /
-// __dadd_rn here: the module is built with -ffp-contract=fast and a fused multiply-add would differ in the last bit.
+// The last line is three separately rounded IEEE operations in numpy: lerp_unfused below keeps the compiler from fusing
+// the multiply and the add (the module is built with -ffp-contract=fast).
 // One thread per trajectory, component-major stores q[j * B + i]: a wavefront writes 512 contiguous bytes per
 // component.  Pure HBM-write work: 16 n bytes per trajectory.
 #pragma once
@@ -30,6 +30,18 @@ __device__ __forceinline__ double uniform01(unsigned long long key, int field) {
   const unsigned long long z = splitmix64(key + (unsigned long long)field * 0x2545F4914F6CDD1Dull);
   return (double)(z >> 11) * 0x1p-53;                       // 53 bits: the conversion and the scaling are exact
 }
+// lo + (hi - lo) * u as numpy evaluates it: three separately rounded operations.  HIP's __dmul_rn / __dadd_rn are plain
+// `*` and `+` to the compiler, and the module is built with -ffp-contract=fast: the first GPU run of this kernel differed
+// from numpy in the last bit on some trajectories (a fused multiply-add).  Contraction is switched off for this function
+// AND the product goes through an opaque statement, so no later pass can fuse it either.
+__device__ __forceinline__ double lerp_unfused(double lo, double hi, double u) {
+#pragma clang fp contract(off)
+  double t = (hi - lo) * u;
+#ifndef HAMK_HOST_EMULATION
+  asm volatile("" : "+v"(t));
+#endif
+  return lo + t;
+}
 }  // namespace hamk
 
 extern "C" __global__ void __launch_bounds__(256) hamk_sample_k(double* q, double* qd, long long B, long long first_index,
@@ -39,7 +51,7 @@ extern "C" __global__ void __launch_bounds__(256) hamk_sample_k(double* q, doubl
   const unsigned long long key = seed ^ ((unsigned long long)(first_index + i) * 0xD1342543DE82EF95ull);
   for (int j = 0; j < n; ++j) {
     const double u = hamk::uniform01(key, 2 * j), w = hamk::uniform01(key, 2 * j + 1);
-    q[(long long)j * B + i] = __dadd_rn(bx.q_lo[j], __dmul_rn(__dsub_rn(bx.q_hi[j], bx.q_lo[j]), u));
-    qd[(long long)j * B + i] = __dadd_rn(bx.qd_lo[j], __dmul_rn(__dsub_rn(bx.qd_hi[j], bx.qd_lo[j]), w));
+    q[(long long)j * B + i] = hamk::lerp_unfused(bx.q_lo[j], bx.q_hi[j], u);
+    qd[(long long)j * B + i] = hamk::lerp_unfused(bx.qd_lo[j], bx.qd_hi[j], w);
   }
 }

@@ -12,11 +12,11 @@
 //   K        K = J^T M J on the f64 matrix cores: four rows are staged in LDS and consumed by
 //            v_mfma_f64_16x16x4_f64 (SinkK) -- one 8-byte LDS read per lane per 16-column block per
 //            four rows.  No J tile, no second pass over it.
-//   solve    LDL^T with rows distributed over lanes: per pivot, every lane drops its entry of the
-//            pivot column into an LDS buffer and reads what it needs back as broadcast loads; the
-//            forward substitution rides along; back substitution reads L^T from the packed triangle.
-//            For n > 16 in panels of 16 pivots, the trailing blocks updated on the matrix cores
-//            (factor_blocked): the broadcast stops at the panel's edge.
+//   solve    LDL^T with rows distributed over lanes, in panels of 16 pivots (factor_blocked): inside a panel every lane
+//            drops its entry of the pivot column into an LDS buffer and reads what it needs back as broadcast loads,
+//            the forward substitution riding along; the trailing blocks are updated on the matrix cores; back
+//            substitution reads L^T from the packed triangle.  Systems with a non-positive inertia: LU with partial
+//            pivoting instead (solve_pivoted), as the reference's `inv`.
 //   sweep 2  Jet2<1> along the common runtime direction qd with own e_i: lane i accumulates
 //            dT/dq_i = -sum_k m_k (J qd)_k ((dJ/dq_i) qd)_k directly in the sink -- the m x n x n
 //            Hessian tensor of the reference (Hamilton.hs:222, 512 KiB per point at N = 32)
@@ -50,10 +50,7 @@ template <class S> struct Lds {
   // contiguous.  The first 4*NP doubles double as the staging rows of sweep 1.
   static constexpr int TILE = NP * (NP + 1) / 2;
   HAMK_DEV static constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
-#ifndef HAMK_WAVE_BLOCKED
-#define HAMK_WAVE_BLOCKED 0
-#endif
-  static constexpr int NPIV = HAMK_WAVE_BLOCKED ? NP : 0;   // the pivots d_j of the blocked factorisation
+  static constexpr int NPIV = NP;                           // the pivots d_j (factor_blocked)
   static constexpr int PER_TRAJ = TILE + 4 * NP + 2 * NT + NPIV;   // + 2*NP scratch row (sincos exchange, pivot column + z) + two all-gather buffers + sincos pairs
 };
 
@@ -470,19 +467,14 @@ HAMK_DEV double solve_pivoted(const Ctx<S>& c, int& st, double rhs) {
   return v;
 }
 
-// Sweep 1 (with K accumulated in the sink) + LDL^T, with the forward substitution of one right-hand
-// side riding along.  On return: `row` holds L[li][j] (j < li), `dinv` = 1/d_li, z = (L^-1 rhs)_li;
+// Sweep 1 (with K accumulated in the sink) + the solve's first half: LDL^T in panels of 16 pivots with the forward
+// substitution of one right-hand side riding along (factor_blocked; a system of n <= 16 is one panel) -- or, where an
+// inertia is not positive, the whole pivoted solve (solve_pivoted).  On return: dinv = 1/d_li, z = (L^-1 rhs)_li,
 // gU = dU/dq_li; the packed triangle holds L.
-//
-// Rows are distributed over lanes and only the lower triangle is kept (lane i: K[i][k], k <= i).
-// The update of pivot j, K[i][k] -= l_ij K[k][j], needs column j as every lane k holds it in its
-// own row -- so before the pivot each lane drops its current K[li][j] (and its z) into a column
-// buffer in LDS and all lanes read what they need back as BROADCAST loads with immediate offsets:
-// one write and (N-1-j)/2 wide reads per pivot, against two ds_bpermute per element before (992 of
-// them at N = 32, 56 % of the evaluation's time).  DS operations of a wave execute in order, so the
-// buffer needs no double-buffering.
+// (Until round 4 a flat, unblocked column-broadcast LDL^T lived here as the alternative for n > 16 -- measured behind the
+// panel version, chain32 5.06e7 vs 5.66e7 and chain64 4.6e6 vs 7.6e6 RK4 steps/s, profiles/r02_wave_blocked.jsonl -- removed.)
 template <class S>
-HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& dinv, double& gU, double& U, int& st,
+HAMK_DEV void factor(const Ctx<S>& c, double qi, double& dinv, double& gU, double& U, int& st,
                      double& z) {
   constexpr int N = S::N, NP = Ctx<S>::NP;
   constexpr int TRIG1 = (S::TRIG_ALL_INPUTS && S::NTRIG_F > 0) ? TRIG_REUSE : TRIG_FULL;
@@ -506,69 +498,7 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double (&row)[S::N], double& di
     dinv = 1.0;
     return;
   }
-#if HAMK_WAVE_BLOCKED
   factor_blocked<S>(c, dinv, st, z);
-  return;
-#endif
-#pragma unroll
-  for (int b = 0; b < N; ++b) row[b] = c.tile()[li * (li + 1) / 2 + b];   // each lane takes its row (entries b > li: never used)
-  // LDL^T, right-looking, TWO pivots per LDS round trip: the serial chain (write column, read it
-  // back, reciprocal, update) is what bounds this phase, not its flops.  With a = K[j][j],
-  // b = K[j+1][j], c = K[j+1][j+1] (all before pivot j), l = b/a:
-  //   d_j = a, d_j+1 = c - l b = det/a;   l_i,j = K[i][j]/a;   l_i,j+1 = (K[i][j+1] - l_i,j b)/d_j+1;
-  //   K[i][k] -= l_i,j K[k][j] + l_i,j+1 (K[k][j+1] - l K[k][j])  =  (l_i,j - l_i,j+1 l) K[k][j] + l_i,j+1 K[k][j+1]
-  // -- the same L and D as the scalar recurrence, the same number of FMAs, on the columns as they
-  // were before the pair; the two reciprocals (1/a, 1/det) are independent.
-  bool ok = true;
-  dinv = 0.0;
-  // L[li][j] goes to the packed triangle the moment it is final (row[j] is dead from then on: fewer
-  // live registers); lanes at or above the pivot store to their own diagonal slot instead -- L has a
-  // unit diagonal, nobody reads that slot -- so the store needs no exec-mask round trip.
-  double* Lrow = c.tile() + li * (li + 1) / 2;
-  double* cA = c.rowbuf();                                 // [NP] column j   (the exchange buffer is free here,
-  double* cB = c.rowbuf() + NP;                            // [NP] column j+1   and so is the qd gather buffer)
-  double* cZ = c.gb();                                     // [NP] z
-#ifdef HAMK_PROBE_SKIP_FACTOR
-  dinv = frcp(row[0] + 2.0);
-  if (0)
-#endif
-  {
-#pragma unroll
-    for (int j = 0; j + 1 < N; j += 2) {
-      HAMK_LOCKSTEP();
-      cA[li] = row[j];
-      cB[li] = row[j + 1];
-      cZ[li] = z;
-      lds_sync();
-      const double a = cA[j], b = cA[j + 1], cc = cB[j + 1], zj = cZ[j], zj1 = cZ[j + 1];
-      const double det = fma(a, cc, -(b * b));
-      ok = ok && (a > 0.0) && (det > 0.0);                  // d_j > 0 and d_j+1 = det/a > 0
-      const double inv_a = frcp(a), inv_det = frcp(det);
-      const double inv_c = a * inv_det;                      // 1/d_j+1
-      const double l = b * inv_a;                            // L[j+1][j]
-      const double zj1p = fma(-l, zj, zj1);                  // z_j+1 once pivot j is applied
-      const double l0 = (li > j) ? row[j] * inv_a : 0.0;     // 0: lanes at or above the pivot do not update
-      const double l1 = (li > j + 1) ? fma(-l0, b, row[j + 1]) * inv_c : 0.0;
-      if (li == j) dinv = inv_a;
-      if (li == j + 1) dinv = inv_c;
-      z = fma(-l1, zj1p, fma(-l0, zj, z));                   // L z = rhs, two terms per pair
-      const double al = fma(-l1, l, l0);
-#pragma unroll
-      for (int k = j + 2; k < N; ++k) row[k] = fma(-al, cA[k], fma(-l1, cB[k], row[k]));   // (entries k > li are never read)
-      Lrow[(li > j) ? j : li] = l0;
-      Lrow[(li > j + 1) ? j + 1 : li] = l1;
-    }
-    if constexpr ((N & 1) != 0) {                            // last pivot of an odd N: nothing below it
-      HAMK_LOCKSTEP();
-      cA[li] = row[N - 1];
-      lds_sync();
-      const double dj = cA[N - 1];
-      ok = ok && (dj > 0.0);
-      if (li == N - 1) dinv = frcp(dj);
-    }
-  }
-  if (!ok && li < N) st |= ST_SINGULAR;                    // every inertia positive here: K is semi-definite, a non-positive pivot IS singular
-  lds_sync();                                              // L is complete in the triangle
 }
 
 // Finish K v = rhs after `factor` (which left z = L^-1 rhs): D y = z, L^T v = y; returns v_li.
@@ -622,12 +552,12 @@ template <class S>
 HAMK_DEV void ham_eqs(const Ctx<S>& c0, double qi, double pi, double& dqi, double& dpi, int& st) {
   constexpr int N = S::N;
   const Ctx<S> c = c0.launder();
-  double row[N], dinv, gU, U;
+  double dinv, gU, U;
   lds_sync();
   c.ga()[c.li] = qi;                                        // all-gather q through LDS; it stays there
   lds_sync();
   double z = pi;
-  factor<S>(c, qi, row, dinv, gU, U, st, z);
+  factor<S>(c, qi, dinv, gU, U, st, z);
   const double vi = solve_back<S>(c, dinv, z);
   lds_sync();
   c.gb()[c.li] = vi;                                        // ... and qd
@@ -766,12 +696,12 @@ template <class S>
 HAMK_DEV double velocity(const Ctx<S>& c0, double qi, double pi, double& U, int& st) {
   const Ctx<S> c = c0.launder();
   constexpr int N = S::N, NP = Ctx<S>::NP;
-  double row[N], dinv, gU;
+  double dinv, gU;
   lds_sync();
   c.ga()[c.li] = qi;
   lds_sync();
   double z = pi;
-  factor<S>(c, qi, row, dinv, gU, U, st, z);
+  factor<S>(c, qi, dinv, gU, U, st, z);
   return solve_back<S>(c, dinv, z);
 }
 

@@ -63,7 +63,7 @@
  *
  * First use of a handle on a device runs a short self-check of its stepping
  * kernels against its hamEqs kernel (a JIT product does not take the code
- * generator's word for it; DESIGN.md section 6b); HAMK_SELFCHECK=0 skips it.
+ * generator's word for it; DESIGN.md section 8); HAMK_SELFCHECK=0 skips it.
  */
 #ifndef HAMK_H
 #define HAMK_H
@@ -150,7 +150,7 @@ typedef struct hamk_system hamk_system;   /* opaque */
 /* ---- options of a system (hamk_system_create_ex) -----------------------------------------------------
  * Everything the library decides for itself when it specialises its kernels for a system can be fixed by the host
  * instead.  HAMK_AUTO (0) in a field leaves that decision to the library; a zero-filled struct with `size` set is
- * "all defaults".  The environment variables of DESIGN.md section 6c are TEST overrides: they apply only where the
+ * "all defaults".  The environment variables of DESIGN.md section 7 are TEST overrides: they apply only where the
  * field is HAMK_AUTO.  hamk_system_get_options reports what was actually chosen.                                  */
 #define HAMK_AUTO 0
 #define HAMK_ON   1
@@ -162,14 +162,14 @@ typedef struct hamk_system hamk_system;   /* opaque */
 #define HAMK_MAP_QUAD 3   /* four lanes per trajectory: every lane runs the sparse per-trajectory AD sweeps, the rows of
                              K are dealt out over the four lanes and factorised in registers with DPP exchanges
                              (17 <= n <= 32 when the coordinate map's Jacobian is sparse enough; also usable for n <= 16) */
-/* second-order AD strategy (DESIGN.md section 2.1) */
+/* second-order AD strategy (DESIGN.md section 2) */
 #define HAMK_AD_H 1       /* one sweep of full second-order jets                        */
 #define HAMK_AD_D 2       /* first-order sweep, then a directional second-order sweep   */
 #define HAMK_AD_R 3       /* first-order sweep, then a generated reverse sweep          */
 /* stepping-loop bodies */
 #define HAMK_BODY_UNROLLED   1
 #define HAMK_BODY_STAGE_LOOP 2
-/* sincos of the stepping kernels (DESIGN.md section 2.2) */
+/* sincos of the stepping kernels (DESIGN.md section 3) */
 #define HAMK_TRIG_DIRECT       1   /* sincos_f64, no table                              */
 #define HAMK_TRIG_TABLE        2   /* every evaluation through the 512-pair table in LDS */
 #define HAMK_TRIG_TABLE_ROTATE 3   /* one table evaluation per step, stages 2-4 by rotation */
@@ -190,7 +190,8 @@ typedef struct hamk_options {
   int32_t gsl_api;         /* 1 | 2 (hamk_system_set_gsl_api); AUTO: 2                                                  */
   int32_t self_check;      /* ON | OFF: first-use self-check of the stepping kernels; AUTO: ON                          */
   int32_t build;           /* HAMK_BUILD_*; AUTO: per kernel, the build that spills fewer SGPRs                         */
-  int32_t wave_blocked;    /* ON | OFF: wave mapping, LDL^T in panels of 16 with MFMA trailing updates; AUTO: n > 16    */
+  int32_t wave_blocked;    /* ignored since round 4 (kept for layout): the wave mapping's LDL^T always runs in panels of 16
+                              with MFMA trailing updates; hamk_system_get_options reports ON                            */
   int32_t rk4_min_waves;   /* __launch_bounds__ waves per SIMD of the RK4 kernel; AUTO: measured default                */
   int32_t k_reassoc;       /* ON | OFF: K = J^T M J summed with re-association allowed (repeated Jacobian entries are
                               multiplied by their count instead of added up); AUTO: ON                                  */
@@ -200,9 +201,10 @@ typedef struct hamk_options {
                               shares one budget across its intervals; every call of `iterate` has its own); AUTO: 2^24  */
   int32_t cache;           /* ON | OFF: on-disk cache of compiled code objects; AUTO: ON                                */
   int32_t lanes_per_trajectory;  /* OUTPUT of hamk_system_get_options: 1, 4, 16, 32 or 64                               */
-  int32_t rkf_park;        /* ON | OFF: lane and quad mappings, the adaptive stepper's vectors (y, dydt, k2..k6, trial state)
-                              wait in LDS and in a run-time-indexed private array instead of competing with the right-hand
-                              side for registers; AUTO: lane n >= 6 (with the stage-loop body), quad n >= 17              */
+  int32_t rkf_park;        /* ON | OFF: QUAD mapping, the adaptive stepper's vectors (y, dydt, k2..k6, trial state) wait in
+                              LDS and in a run-time-indexed private array instead of competing with the right-hand side
+                              for registers; AUTO: n >= 17.  Lane mapping: follows rkf_body (the stage-loop body IS the
+                              parked one since round 4); reported, not settable                                          */
   int32_t _align;          /* keeps ensemble_size 8-byte aligned; 0                                                     */
   int64_t ensemble_size;   /* mapping = AUTO only: the size of the WHOLE ensemble this handle's launches are pieces of (a shard
                               of a multi-GPU run, a chunk of a host loop).  AUTO picks the mapping from the ensemble size, and

@@ -24,11 +24,6 @@ def jobs():
         out.append((n, {"HAMK_WAVE": "1"}, False))
     for n in ("chain8", "chain16"):
         out.append((n, {"HAMK_WAVE": "0"}, False))
-    for n in ("chain17", "chain18", "chain20", "chain32", "chain33", "chain40", "chain48", "chain64"):
-        out.append((n, {"HAMK_WAVE_BLOCKED": "1"}, True))       # LDL^T in panels (hamk_wave.hpp factor_blocked)
-        out.append((n, {"HAMK_WAVE_BLOCKED": "0"}, True))
-    for n in ("chain33", "chain40", "chain48", "chain64"):
-        out.append((n, {"HAMK_RK4_WAVES": "2"}, False))          # n > 32 at two wavefronts per SIMD (256 VGPRs, spills)
     for n in ("opcodeZoo", "doublePendulum", "spring", "threeBodyPolar"):
         for mode in "HDR":
             for loop in (None, "1"):
@@ -48,15 +43,11 @@ def jobs():
     out.append(("chain24", {}, False))
     for n in ("chain16", "chain8", "threeBodyPolar", "spring", "opcodeZoo"):
         out.append((n, {"HAMK_QUAD": "1"}, False))
-    for n in ("chain12", "chain16"):
-        out.append((n, {"HAMK_RK4_PARK": "0"}, False))
-    # the adaptive stepper with and without its parked stage vectors (tests/test_gpu_wave.py)
-    for n in ("chain8", "threeBodyPolar", "chain13"):
-        out.append((n, {"HAMK_WAVE": "0", "HAMK_QUAD": "0"}, False))
-        out.append((n, {"HAMK_WAVE": "0", "HAMK_QUAD": "0", "HAMK_RKF_PARK": "0"}, False))
+    # the adaptive stepper's two lane bodies (stage loop = parked, unrolled) and the quad kernels without parking (tests/test_gpu_wave.py)
+    for n in ("chain4", "chain8", "threeBodyPolar", "chain13"):
+        out.append((n, {"HAMK_WAVE": "0", "HAMK_QUAD": "0", "HAMK_RKF_LOOP": "1"}, False))
+        out.append((n, {"HAMK_WAVE": "0", "HAMK_QUAD": "0", "HAMK_RKF_LOOP": "0"}, False))
     out.append(("chain24", {"HAMK_RKF_PARK": "0"}, False))
-    for n in ("chain32", "chain20"):
-        out.append((n, {"HAMK_HIPRTC_FLAGS": "-DHAMK_QUAD_LEFT=1", "HAMK_QUAD": "1"}, False))      # left-looking Cholesky, K per panel (A/B, GPU parity test)
     # round 4: systems with a non-positive inertia (lane kernels with the LU fallback, wave kernels with solve_pivoted), the
     # small-ensemble quad module of chain12, the device sampler
     for n in ("doublePendulum~mixed", "spring~mixed", "threeBodyPolar~mixed", "chain6~mixed", "chain12~mixed", "chain20~mixed"):

@@ -1,11 +1,8 @@
 // TEST INFRASTRUCTURE -- never part of libhamk.so.
 // hamilton_amd/csrc/hamk_sample.hpp (the device sampler behind hamk_sample_batch) compiled for the host: the CPU suite
 // checks its bits against the numpy sampler (hamilton_amd/examples.py) without a GPU.  Built with -ffp-contract=off;
-// the three rounding-explicit device intrinsics are plain IEEE operations here.
+// lerp_unfused's opaque statement is left out (HAMK_HOST_EMULATION).
 #include "hip_shim.hpp"
-static inline double __dadd_rn(double a, double b) { return a + b; }
-static inline double __dsub_rn(double a, double b) { return a - b; }
-static inline double __dmul_rn(double a, double b) { return a * b; }
 #include "hamk_sample.hpp"
 
 extern "C" void emu_sample(double* q, double* qd, long long B, long long first, unsigned long long seed, int n,

@@ -79,17 +79,18 @@ def test_sizes_beyond_the_kernels_are_refused(hamk_lib):
 
 
 def test_defaults_of_the_wave_kernels(hamk_lib, monkeypatch):
-    """What the library chooses for n > 16 (each choice measured on MI355X): LDL^T in panels
-    of 16 with MFMA trailing updates; beyond n = 32 the RK4 kernel capped for two wavefronts per SIMD; a forced
-    wave build of a small system (one panel) keeps the flat factorisation."""
+    """What the library chooses for n > 16 on the wave mapping (each choice measured on MI355X): LDL^T in panels of 16
+    with MFMA trailing updates -- the only factorisation since round 4, a small forced system being one panel --; beyond
+    n = 32 the RK4 kernel capped for two wavefronts per SIMD."""
     from hamilton_amd import _abi, api
-    mid = api.system_from_spec(E.get("chain20"), {"mapping": _abi.MAP_WAVE}).source
-    assert "hamk_wave.hpp" in mid and "#define HAMK_WAVE_BLOCKED 1" in mid and "HAMK_RK4_MIN_WAVES_BIG" not in mid
+    mid = api.system_from_spec(E.get("chain20"), {"mapping": _abi.MAP_WAVE})
+    assert "hamk_wave.hpp" in mid.source and "HAMK_RK4_MIN_WAVES_BIG" not in mid.source and mid.options()["wave_blocked"] == _abi.ON
     big = api.system_from_spec(E.get("chain33")).source
-    assert "#define HAMK_WAVE_BLOCKED 1" in big and "#define HAMK_RK4_MIN_WAVES_BIG 2" in big
+    assert "#define HAMK_RK4_MIN_WAVES_BIG 2" in big
     monkeypatch.setenv("HAMK_WAVE", "1")
-    small = api.system_from_spec(E.get("chain8")).source
-    assert "hamk_wave.hpp" in small and "HAMK_WAVE_BLOCKED" not in small
+    small = api.system_from_spec(E.get("chain8"))
+    assert "hamk_wave.hpp" in small.source and small.lanes_per_trajectory == 16
+    assert "HAMK_WAVE_BLOCKED" not in small.source + big
 
 
 def test_calls_fail_loudly_without_a_gpu(hamk_lib):
@@ -106,7 +107,7 @@ def test_calls_fail_loudly_without_a_gpu(hamk_lib):
 def test_kernels_come_from_the_build_that_spills_fewer_scalar_registers(hamk_lib, monkeypatch, name):
     """Every kernel is taken from whichever of the two builds (default options / without
     MachineLICM) spills fewer SGPRs, the default build on a tie (hamk_api.cpp::build_code).  The
-    one kernel ever seen to give run-to-run different results spilled 101 (DESIGN.md section 6b);
+    one kernel ever seen to give run-to-run different results spilled 101 (DESIGN.md section 8);
     the headline RK4 kernel spills none either way and stays on the default build."""
     from hamilton_amd import api
 
@@ -242,11 +243,12 @@ def test_mapping_defaults_by_size_and_structure(hamk_lib):
         assert t.options(65536)["rk4_park"] == park, name
     # the adaptive stepper's vectors parked in LDS / a run-time-indexed private array: lane kernels from n = 6 (with the
     # stage loop), quad kernels from n = 17 (profiles/r03_lane_rkf_park.jsonl, r03_quad_rkf_park.jsonl); never the wave kernels
-    for name, want in (("chain4", _abi.OFF), ("threeBodyPolar", _abi.ON), ("chain8", _abi.ON), ("chain16", _abi.ON), ("chain20", _abi.ON), ("chain33", _abi.OFF)):
+    # (lane kernels: the stage-loop body -- from n = 4 -- IS the parked one since round 4, the option does not apply there)
+    for name, want in (("spring", _abi.OFF), ("chain4", _abi.ON), ("threeBodyPolar", _abi.ON), ("chain8", _abi.ON), ("chain16", _abi.ON), ("chain20", _abi.ON), ("chain33", _abi.OFF)):
         assert api.system_from_spec(E.get(name)).options(65536)["rkf_park"] == want, name
     assert api.system_from_spec(E.get("chain14")).options(8192)["rkf_park"] == _abi.OFF          # (the quad module of a small ensemble: n < 17)
-    t = api.system_from_spec(E.get("chain8"), {"rkf_park": _abi.OFF})
-    assert t.options()["rkf_park"] == _abi.OFF and "HAMK_RKF_PARK 1" not in t.source
+    assert api.system_from_spec(E.get("chain8"), {"rkf_park": _abi.OFF}).options()["rkf_park"] == _abi.ON
+    assert api.system_from_spec(E.get("chain20"), {"rkf_park": _abi.OFF}).options()["rkf_park"] == _abi.OFF
     s = api.system_from_spec(E.get("chain20"))
     assert s.options()["mapping"] == _abi.MAP_QUAD and s.lanes_per_trajectory == 4 and "hamk_quad.hpp" in s.source
     assert s.num_device_functions == 9                        # the eight kernels of the path + the self-check's scribble kernel

@@ -111,7 +111,7 @@ FULL = [("C2-doublePendulum", "doublePendulum", 1 << 20, 1000, 96, 1e-4),
 # under-resolved members amplify it without bound), so the asserted bounds are on the MEDIAN lane (a typical member:
 # measured <= 1e-12) and on the lanes the launch did not flag; the all-lanes maximum is recorded, and bounded only by
 # "finite and not O(1)" for the resolved configs.  Calibrated on MI355X (profiles/r03_gpu_test_record.jsonl).
-ORACLE_BOUNDS = {"C2-doublePendulum": (1e-9, 1e-5), "C3-twoBody": (1e-11, 1e-9), "C3-spring": (1e-11, 1e-9), "C4-threeBodyPolar": (1e-11, 1e-9),
+ORACLE_BOUNDS = {"C2-doublePendulum": (1e-9, 1e-4), "C3-twoBody": (1e-11, 1e-9), "C3-spring": (1e-11, 1e-9), "C4-threeBodyPolar": (1e-11, 1e-9),
                  "C5-chain8": (1e-9, 1e-6), "C5-chain16": (None, None), "C5-chain32": (None, None)}
 
 

@@ -452,7 +452,7 @@ def test_small_host_calls_see_fresh_inputs(api, systems):
 def test_steppers_are_deterministic(api, systems, name):
     """Every lane is independent, so two runs on the same input must agree bit for bit -- for both
     steppers, after other kernels have run (they leave other register contents behind).  An unrolled
-    RKF45 body that spilled 101 SGPRs once failed exactly this (DESIGN.md section 6b)."""
+    RKF45 body that spilled 101 SGPRs once failed exactly this (DESIGN.md section 8)."""
     import torch
     spec, s, o = systems[name]
     B = 1 << 16

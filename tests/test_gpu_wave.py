@@ -70,29 +70,6 @@ def test_wave_path_vs_oracle(api, oracle_lib, monkeypatch, name, force):
         assert not np.any(s.last_status)
 
 
-def test_flat_and_panel_factorisation_agree(api, oracle_lib, monkeypatch):
-    """n > 16: LDL^T in panels of 16 with the trailing blocks on the matrix cores (default) against the flat
-    column-broadcast factorisation it replaced (HAMK_WAVE_BLOCKED=0) and the oracle."""
-    from hamilton_amd import _abi
-    spec = E.get("chain32")
-    panel = api.system_from_spec(spec, {"mapping": _abi.MAP_WAVE})
-    assert "#define HAMK_WAVE_BLOCKED 1" in panel.source
-    flat = api.system_from_spec(spec, {"mapping": _abi.MAP_WAVE, "wave_blocked": _abi.OFF})
-    assert "#define HAMK_WAVE_BLOCKED 1" not in flat.source
-    o = oracle_lib.OracleSystem(spec)
-    B = 70
-    q, _ = E.sample_config(spec, 3, B)
-    qd = 0.3 * np.cos(np.arange(spec.n * B).reshape(spec.n, B) * 0.7)
-    p = o.to_phase_batch(q, qd)
-    odq, odp, _ = o.hameqs_batch(q, p)
-    for s in (panel, flat):
-        dq, dp = api.hamEqs(s, api.Phase(q, p))
-        assert relerr(dq, odq) < 1e-10 and relerr(dp, odp) < 1e-10
-    a = api.rk4Steps(spec.dt, 20, panel, api.Phase(q, p))
-    b = api.rk4Steps(spec.dt, 20, flat, api.Phase(q, p))
-    assert relerr(a.positions, b.positions) < 1e-10 and relerr(a.momenta, b.momenta) < 1e-10
-
-
 def test_wave_path_matches_golden_and_lane_path(api, monkeypatch):
     spec = E.get("threeBodyPolar")
     lane = api.system_from_spec(spec)
@@ -213,17 +190,22 @@ def test_quad_path_vs_oracle(api, oracle_lib, name, force):
         record(test="quad_vs_oracle", name=name, B=B, hameqs=e1, rk4_5=e5)
 
 
-@pytest.mark.parametrize("name,quad", [("chain8", False), ("threeBodyPolar", False), ("chain13", False), ("chain24", True)])
+@pytest.mark.parametrize("name,quad", [("chain4", False), ("chain8", False), ("threeBodyPolar", False), ("chain13", False), ("chain24", True)])
 def test_parked_adaptive_stepper_takes_the_reference_steps(api, oracle_lib, name, quad):
-    """hamk_options::rkf_park: the adaptive stepper whose stage vectors wait in LDS / a run-time-indexed private array
-    (the default of the lane kernels from n = 6 and the quad kernels from n = 17) against the body that leaves them to the
-    register allocator and against the oracle: the same sub-step counts on every trajectory, states to roundoff; `iterate
-    (stepHam dt)` in one launch == the calls one by one, bitwise; evolveHam over a grid under the old GSL binding too."""
+    """The adaptive stepper whose stage vectors wait in LDS / a run-time-indexed private array -- the lane kernels' stage-loop
+    body (from n = 4; the only one since round 4) and the quad kernels' default from n = 17 (hamk_options::rkf_park) --
+    against the body that keeps them in registers (lane: the unrolled body; quad: rkf_park OFF) and against the oracle: the
+    same sub-step counts on every trajectory, states to roundoff; `iterate (stepHam dt)` in one launch == the calls one by
+    one, bitwise."""
     from hamilton_amd import _abi
     spec = E.get(name)
     mp = _abi.MAP_QUAD if quad else _abi.MAP_LANE
-    on = api.system_from_spec(spec, {"mapping": mp, "rkf_park": _abi.ON})
-    off = api.system_from_spec(spec, {"mapping": mp, "rkf_park": _abi.OFF})
+    if quad:
+        on = api.system_from_spec(spec, {"mapping": mp, "rkf_park": _abi.ON})
+        off = api.system_from_spec(spec, {"mapping": mp, "rkf_park": _abi.OFF})
+    else:
+        on = api.system_from_spec(spec, {"mapping": mp, "rkf_body": _abi.BODY_STAGE_LOOP})
+        off = api.system_from_spec(spec, {"mapping": mp, "rkf_body": _abi.BODY_UNROLLED})
     assert on.options()["rkf_park"] == _abi.ON and off.options()["rkf_park"] == _abi.OFF
     assert api.system_from_spec(spec, {"mapping": mp}).options()["rkf_park"] == _abi.ON          # what AUTO picks
     o = oracle_lib.OracleSystem(spec)
@@ -280,22 +262,3 @@ def test_dense_jacobians_stay_on_the_wave_kernels(api):
     assert api.system_from_spec(spec).options()["mapping"] == _abi.MAP_WAVE
 
 
-def test_quad_left_looking_variant_vs_oracle(api, oracle_lib, monkeypatch):
-    """The factorisation that does NOT ship by default (left-looking Cholesky, K assembled panel by panel: no scratch,
-    more instructions) stays correct on the GPU: chain20 and chain32 against the oracle."""
-    from hamilton_amd import _abi
-    monkeypatch.setenv("HAMK_HIPRTC_FLAGS", "-DHAMK_QUAD_LEFT=1")
-    for name in ("chain20", "chain32"):
-        spec = E.get(name)
-        s = api.system_from_spec(spec, {"mapping": _abi.MAP_QUAD})
-        o = oracle_lib.OracleSystem(spec)
-        B = 70
-        q, _ = E.sample_config(spec, 3, B)
-        qd = 0.3 * np.cos(np.arange(spec.n * B).reshape(spec.n, B) * 0.7)
-        p = o.to_phase_batch(q, qd)
-        odq, odp, _ = o.hameqs_batch(q, p)
-        dq, dp = api.hamEqs(s, api.Phase(q, p))
-        assert relerr(dq, odq) < 1e-10 and relerr(dp, odp) < 1e-10
-        ph = api.rk4Steps(spec.dt, 5, s, api.Phase(q, p))
-        oq, op = o.rk4_steps_batch(q, p, spec.dt, 5)
-        assert relerr(ph.positions, oq) < 1e-10 and relerr(ph.momenta, op) < 1e-10

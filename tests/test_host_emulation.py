@@ -303,15 +303,15 @@ def test_mixed_sign_inertias_pivot_like_the_reference_on_host(emulate, oracle_li
     check_against_oracle(L, spec, o, B=24, steps=5, tol=1e-10, qd_kick=0.4, dt_ham=2 * spec.dt)
 
 
-@pytest.mark.parametrize("park", ["1", "0"])
-def test_adaptive_stepper_with_parked_stage_vectors_on_host(emulate, oracle_lib, park):
-    """hamk_device.hpp rkf45_body_parked (hamk_options::rkf_park; the default of the lane kernels from n = 6) and the body
-    it replaces, chain8: an evolveHam time grid under both GSL bindings with the oracle's sub-step counts on every
-    trajectory, and `iterate (stepHam dt)` in one launch == the calls one by one, bitwise."""
+@pytest.mark.parametrize("body", ["stage-loop (parked)", "unrolled"])
+def test_adaptive_stepper_with_parked_stage_vectors_on_host(emulate, oracle_lib, body):
+    """hamk_device.hpp rkf45_body_parked (the lane kernels' stage-loop body: the default from n = 4) and the unrolled body
+    with everything in registers, chain8: an evolveHam time grid under both GSL bindings with the oracle's sub-step counts
+    on every trajectory, and `iterate (stepHam dt)` in one launch == the calls one by one, bitwise."""
     spec = E.get("chain8")
     o = oracle_lib.OracleSystem(spec)
-    L, src = emulate(spec, {"HAMK_RKF_PARK": park})
-    assert ("#define HAMK_RKF_PARK 1" in src) == (park == "1")
+    L, src = emulate(spec, {"HAMK_RKF_LOOP": "1" if body.startswith("stage") else "0"})
+    assert ("RKF_STAGE_LOOP = true" in src) == body.startswith("stage")
     B = 9
     q, qd = E.sample_config(spec, 3, B)
     qd = qd + 0.4 * np.cos(np.arange(spec.n * B).reshape(spec.n, B))
@@ -569,15 +569,6 @@ def test_wave_pivoted_solve_flags_an_exactly_singular_matrix(emulate_wave, oracl
     assert np.all(st & 1) and np.all(np.isnan(v))
 
 
-def test_flat_factorisation_on_host(emulate_wave, oracle_lib, monkeypatch):
-    """n > 16 factorises in panels of 16 by default (trailing blocks on the matrix cores: chain17/18/32/33
-    above); the flat column-broadcast LDL^T it replaced stays selectable (HAMK_WAVE_BLOCKED=0) and correct."""
-    monkeypatch.setenv("HAMK_WAVE_BLOCKED", "0")
-    spec = E.get("chain18")
-    L = emulate_wave(spec, False)
-    check_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=2, steps=2, tol=1e-10)
-
-
 @pytest.mark.parametrize("name,env", [("doublePendulum", None), ("spring", None), ("threeBodyPolar", None),
                                        ("doublePendulum", {"HAMK_RKF_LOOP": "1", "HAMK_TRIG_LUT": "0"})])
 def test_iterate_stepham_is_the_calls_one_by_one(emulate, oracle_lib, name, env):
@@ -774,17 +765,6 @@ def test_quad_adaptive_stepper_on_host(emulate_quad, oracle_lib, api, name):
             assert relerr(qb, oqb) < 1e-9 and relerr(pb, opb) < 1e-9
     finally:
         L.emu_set_gsl_api(2)
-
-
-@pytest.mark.parametrize("name,B", [("chain32", 5), ("chain18", 3), ("chain5", 4), ("opcodeZoo", 5)])
-def test_quad_right_looking_variant_on_host(emulate_quad, oracle_lib, name, B):
-    """The other factorisation of the quad kernels (HAMK_QUAD_LEFT = 0 / 1: K assembled whole and LDL^T right-looking in
-    rank-4 panels, or left-looking Cholesky with K assembled panel by panel; DESIGN.md section 2.7 says which one ships
-    and why): both stay correct."""
-    spec = E.get(name)
-    for left in (0, 1):
-        L = emulate_quad(spec, defines=(f"HAMK_QUAD_LEFT {left}",))
-        check_quad_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=B)
 
 
 @pytest.mark.parametrize("name", ["chain8", "chain16", "chain32"])

@@ -1,5 +1,5 @@
 """GPU: one table of measured parity (HIP path through the C ABI vs the CPU oracle and vs the
-high-precision fixtures) per system -- the evidence behind the tolerance ladder of DESIGN.md section 4."""
+high-precision fixtures) per system -- the evidence behind the tolerance ladder of DESIGN.md section 5."""
 import json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
