@@ -134,7 +134,7 @@ def _default_cache_dir():
     scripts/warm_cache.py or __graft_entry__.build(); hiprtc cross-compiles without a GPU) is used when
     the caller has not chosen a location: a fresh GPU box then measures instead of compiling.  Entries
     are verified (SHA-256 of key material and payload) and the directory must be owner-only, or
-    libhamk ignores it (hamk_api.cpp)."""
+    libhamk ignores it (hamk_build.cpp)."""
     if "HAMK_CACHE_DIR" in os.environ:
         return
     d = os.path.join(os.path.dirname(_HERE), ".hamk_cache")
@@ -143,7 +143,7 @@ def _default_cache_dir():
     except OSError:
         return
     import stat
-    # the same test libhamk applies (hamk_api.cpp private_dir): a real directory of ours nobody else can touch.  A tree
+    # the same test libhamk applies (hamk_build.cpp private_dir): a real directory of ours nobody else can touch.  A tree
     # unpacked by another user or with group/other bits fails it -- and libhamk has no fallback once HAMK_CACHE_DIR names
     # a rejected directory: then leave it unset, so the per-user cache ($XDG_CACHE_HOME/hamk, ~/.cache/hamk) applies.
     if stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0:

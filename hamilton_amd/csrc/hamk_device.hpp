@@ -54,6 +54,9 @@
 #ifndef HAMK_RKF_LDS_BUDGET
 #define HAMK_RKF_LDS_BUDGET 76 /* doubles of LDS per lane the parked RKF45 stepper may use (hamk::RkfPark) */
 #endif
+#ifndef HAMK_RKF_STAGGER
+#define HAMK_RKF_STAGGER 0    /* parked RKF45 stepper: start-up delay per (blockIdx & 3), in units of s_sleep 127 (~3.9 us at 2.1 GHz) */
+#endif
 #ifndef HAMK_RK4_PARK
 #define HAMK_RK4_PARK 0       /* RK4 stage loop: y and the running combination parked in LDS across the right-hand side */
 #endif
@@ -1337,7 +1340,7 @@ template <int ORD> HAMK_DEV double rpow_inv(double r) {
 // A wave-uniform value the compiler would keep in scalar registers for the whole kernel, moved to a vector register:
 // the adaptive stepper is short of SGPRs (its argument block alone is 31 of the 102, and every fp64 literal of the
 // Butcher tableau is an SGPR pair on gfx9), never of VGPRs -- and SGPR spilling is what the one miscompiled kernel of
-// DESIGN.md section 6b had in excess.
+// DESIGN.md section 8 had in excess.
 HAMK_DEV double park_in_vgpr(double x) {
 #ifndef HAMK_HOST_EMULATION
   asm volatile("" : "+v"(x));
@@ -1403,6 +1406,13 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
   ts0 = park_in_vgpr(ts0); ts1 = park_in_vgpr(ts1); h0 = park_in_vgpr(h0); eps_abs = park_in_vgpr(eps_abs); eps_rel = park_in_vgpr(eps_rel);
   constexpr int N = S::N, D = 2 * N, NL = RkfPark<S>::NL;
   if constexpr (StageTrig<S>::lut) lut_load();
+#if HAMK_RKF_STAGGER > 0 && !defined(HAMK_HOST_EMULATION)
+  // Blocks start a fraction of a right-hand side apart (s_sleep: HAMK_RKF_STAGGER x 127 x 64 clocks per step of blockIdx & 3).
+  // With one block per CU every wavefront otherwise runs the same code at the same pace: all of them compute, then all of
+  // them fetch their scratch rows at once -- the memory system idles during the right-hand sides and saturates between
+  // them.  Out of phase, one group's rows move while the others compute.  A pure delay: results are unaffected.
+  for (int k = (int)(blockIdx.x & 3) * HAMK_RKF_STAGGER; k > 0; --k) __builtin_amdgcn_s_sleep(127);
+#endif
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const bool api2 = gsl_api != 1;

@@ -1,4 +1,4 @@
-// hamk_internal.h -- shared between hamk_codegen.cpp and hamk_api.cpp (host side of libhamk.so)
+// hamk_internal.h -- shared between hamk_codegen.cpp and the rest of the host side (hamk_host.h) of libhamk.so
 #pragma once
 #include <cstdint>
 #include <string>

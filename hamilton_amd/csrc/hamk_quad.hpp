@@ -14,7 +14,7 @@
 // sparse: a few hundred instructions), and only the storage and factorisation of K are shared -- row a of K lives in
 // lane a % 4 (register slot a / 4), 144 doubles per lane at n = 32 -- with the pivot column exchanged by DPP
 // quad_perm broadcasts: no LDS in the factorisation at all, no dependent memory round trips, pure VALU.
-//   per lane and right-hand side at n = 32 (counted from the code object):
+//   per lane and right-hand side at n = 32 (counted from the code object, docs/NOTEBOOK.md section 2.7):
 //     sincos of the lane's 8 angles + exchange      ~0.3 k instructions
 //     sweep 1 + the lane's rows of K                ~1 k
 //     LDL^T (1.7 k FMAs + 1 k DPP moves + 32 rcp)   ~3 k

@@ -5,6 +5,13 @@
 set -u
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
+timeout 600 python scripts/rkf_stagger_ab.py > gpurun_out/r04_rkf_stagger_ab.jsonl 2> gpurun_out/r04_rkf_stagger_ab.err
+python - <<'PY'
+import json
+for l in open("gpurun_out/r04_rkf_stagger_ab.jsonl"):
+    r = json.loads(l)
+    print(r["system"], "stagger", r["stagger"], "x", r["dt_mult"], "%.3e" % r["calls_per_s"], r.get("bit_identical_to_stagger_0"))
+PY
 export HAMK_TEST_RECORD=$PWD/gpurun_out/r04_gpu_test_record.jsonl
 rm -f $HAMK_TEST_RECORD
 timeout 2400 python -m pytest tests -m gpu -q --durations=12 > gpurun_out/gputest_r04b.log 2>&1; echo "pytest rc=$?" >> gpurun_out/gputest_r04b.log

@@ -8,7 +8,7 @@ Why: BASELINE.json's configs 3 and 4 shard a FIXED ensemble over 1 -> 8 GPUs (SU
 [g B/G, (g+1) B/G)), so at G = 8 a GPU holds 32 768 (C4) or 8 192 (C5) trajectories -- 512 / 128 wavefronts of the
 one-trajectory-per-lane kernels for 1024 SIMDs.  This measures steps/s at B = 2^13 ... 2^20 on the lane and the
 wave-cooperative kernels (hamk_options::mapping), from which (a) the library's per-launch choice of the mapping
-(hamk_api.cpp lane_wave_crossover) and (b) the predicted strong-scaling curve of each fixed-size config follow.
+(hamk_dispatch.cpp choose_mapping) and (b) the predicted strong-scaling curve of each fixed-size config follow.
 """
 from __future__ import annotations
 

@@ -106,7 +106,7 @@ def test_calls_fail_loudly_without_a_gpu(hamk_lib):
 @pytest.mark.parametrize("name", ["doublePendulum", "room", "opcodeZoo", "chain8"])
 def test_kernels_come_from_the_build_that_spills_fewer_scalar_registers(hamk_lib, monkeypatch, name):
     """Every kernel is taken from whichever of the two builds (default options / without
-    MachineLICM) spills fewer SGPRs, the default build on a tie (hamk_api.cpp::build_code).  The
+    MachineLICM) spills fewer SGPRs, the default build on a tie (hamk_build.cpp build_code).  The
     one kernel ever seen to give run-to-run different results spilled 101 (DESIGN.md section 8);
     the headline RK4 kernel spills none either way and stays on the default build."""
     from hamilton_amd import api
@@ -171,7 +171,7 @@ def test_argument_checks(hamk_lib):
 @pytest.mark.parametrize("name", ALL_GOLDEN_SYSTEMS + ["chain8"])
 def test_kernels_stay_within_branch_reach(hamk_lib, name):
     """Every kernel's machine code stays well inside the +-128 KiB reach of a SOPP branch
-    (libhamk falls back to the stage-loop bodies above 64 KiB; see hamk_api.cpp)."""
+    (libhamk falls back to the stage-loop bodies above 64 KiB; see hamk_dispatch.cpp variant_for)."""
     from hamilton_amd import api
     s = api.system_from_spec(E.get(name))
     for k in ("hamk_rk4_steps_k", "hamk_rkf45_k", "hamk_hameqs_k"):

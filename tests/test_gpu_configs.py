@@ -540,7 +540,7 @@ def test_iterate_on_device_ensembles(api, oracle_lib, monkeypatch, name, force_w
 def test_the_kernel_chosen_for_a_small_shard_is_oracle_exact(api, oracle_lib, name):
     """BASELINE configs 3 / 4 shard a FIXED ensemble over up to 8 GPUs: 65 536 / 8 = 8 192 trajectories per GPU of the C5
     chains.  The library then leaves the one-trajectory-per-lane kernels where the measurement says so (chain16: four
-    lanes per trajectory below 32 768; chain8: lane throughout -- hamk_api.cpp quad_below); whatever it picks must be
+    lanes per trajectory below 32 768; chain8: lane throughout -- hamk_dispatch.cpp quad_below); whatever it picks must be
     oracle-exact at that size, and the same handle serves both sizes."""
     import torch
     from hamilton_amd import _abi
