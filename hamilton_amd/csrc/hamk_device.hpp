@@ -35,7 +35,7 @@
 // else lives in VGPRs, except the read-only sincos table of the stepping kernels
 // (8 KiB of LDS per block).  The kernels are FP64-VALU bound.
 //
-// Compiled per system by hiprtc (hamk_api.cpp) with
+// Compiled per system by hiprtc (hamk_build.cpp) with
 //   -O3 -ffp-contract=fast -fno-honor-nans -fno-signed-zeros
 // The last two let the compiler delete the structural zeros of the AD seeds
 // (d q_j / d q_i = delta_ij, second-order seeds = 0) -- x*0 -> 0, x+0 -> x --
@@ -53,9 +53,6 @@
 #endif
 #ifndef HAMK_RKF_LDS_BUDGET
 #define HAMK_RKF_LDS_BUDGET 76 /* doubles of LDS per lane the parked RKF45 stepper may use (hamk::RkfPark) */
-#endif
-#ifndef HAMK_RKF_STAGGER
-#define HAMK_RKF_STAGGER 0    /* parked RKF45 stepper: start-up delay per (blockIdx & 3), in units of s_sleep 127 (~3.9 us at 2.1 GHz) */
 #endif
 #ifndef HAMK_RK4_PARK
 #define HAMK_RK4_PARK 0       /* RK4 stage loop: y and the running combination parked in LDS across the right-hand side */
@@ -1388,6 +1385,9 @@ template <int D> HAMK_DEV void probe_pin(double (&x)[D]) {
 // results to keep LLVM from hoisting the loads back out).  Measured on MI355X (profiles/r04_rkf_prefetch_ab.jsonl,
 // stepHam dt, B = 65 536): chain16 1.68e8 -> 1.15e8 calls/s (three rows: 386 spilled registers under the reverse sweep),
 // 1.29e8 with one row; chain14 -10 %, chain12 -10 %, chain8 -5 %.  The reverse sweep has no registers to lend.  Removed.
+// So was a second attempt at the same stall: blocks started a fraction of a right-hand side apart (s_sleep), so that one
+// group's rows move while the others compute -- chain16 1.64e8 -> 1.53e8, everything else -3 ... -15 %
+// (profiles/r04_rkf_stagger_ab.jsonl): the wavefronts are not waiting for each other's bandwidth.
 // That traffic is what bounds this kernel:
 // a first version with all nine vectors in scratch moved 44 rows -- chain16 3.6 GB of HBM traffic per launch, 4.4 TB/s,
 // VALU 22 % busy (profiles/r03f_chain16_stepham_summary.json); with 23 rows: 1.7 GB, 3.6 TB/s, 36 % (r03g).  The statements of
@@ -1406,13 +1406,6 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
   ts0 = park_in_vgpr(ts0); ts1 = park_in_vgpr(ts1); h0 = park_in_vgpr(h0); eps_abs = park_in_vgpr(eps_abs); eps_rel = park_in_vgpr(eps_rel);
   constexpr int N = S::N, D = 2 * N, NL = RkfPark<S>::NL;
   if constexpr (StageTrig<S>::lut) lut_load();
-#if HAMK_RKF_STAGGER > 0 && !defined(HAMK_HOST_EMULATION)
-  // Blocks start a fraction of a right-hand side apart (s_sleep: HAMK_RKF_STAGGER x 127 x 64 clocks per step of blockIdx & 3).
-  // With one block per CU every wavefront otherwise runs the same code at the same pace: all of them compute, then all of
-  // them fetch their scratch rows at once -- the memory system idles during the right-hand sides and saturates between
-  // them.  Out of phase, one group's rows move while the others compute.  A pure delay: results are unaffected.
-  for (int k = (int)(blockIdx.x & 3) * HAMK_RKF_STAGGER; k > 0; --k) __builtin_amdgcn_s_sleep(127);
-#endif
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const bool api2 = gsl_api != 1;
@@ -1776,7 +1769,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
 }  // namespace hamk
 
 // Leaves launch-dependent garbage in every VGPR (v2-v255) of the SIMDs it runs on.  The first-use
-// self-check (hamk_api.cpp) runs it between repeated launches of the stepping kernels: a kernel whose
+// self-check (hamk_dispatch.cpp) runs it between repeated launches of the stepping kernels: a kernel whose
 // result depends on what its predecessor left in the registers -- exactly the defect once met on this
 // toolchain, scripts/probes/sgpr_spill_repro -- agrees with itself when launched back to back and is
 // only caught when something else used the registers in between.

@@ -525,6 +525,11 @@ static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4,
     const double width = d.mode_h ? 1.0 + n + 0.5 * n * (n + 1) : 3.0 * n + 3.0;      // jet components carried per tape value
     const double est_rhs = (f_nops + u_nops) * width + 2.0 * m * n * n + n * n * n / 3.0;
     d.use_lut = (sites >= 1 && sites <= 4 && est_rhs / sites < 100.0) ? 2 : 1;
+    // the four-lane kernels from n = 14: no table.  Their register file is K's, the table costs 8 KiB of an LDS that is nearly
+    // full and a handful of registers: chain32 2.50e8 steps/s without it, 2.28e8 with (Scratch_Size 372 -> 488 B, HBM traffic
+    // per launch 233 -> 788 MB; profiles/r03e_chain32_summary.json vs the first r04 pass, where this rule had been dropped
+    // by mistake together with the lane-kernel rule it used to share a line with)
+    if (n >= 14 && mapping == HAMK_MAP_QUAD) d.use_lut = 0;
   }
   if (o.trig != HAMK_AUTO) d.use_lut = o.trig == HAMK_TRIG_DIRECT ? 0 : (o.trig == HAMK_TRIG_TABLE ? 1 : 2);
   else if (const char* e = std::getenv("HAMK_TRIG_LUT")) { if (e[0] >= '0' && e[0] <= '2') d.use_lut = e[0] - '0'; }

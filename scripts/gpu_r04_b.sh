@@ -28,7 +28,7 @@ for sys in doublePendulum twoBody spring threeBodyPolar chain8 chain16; do
   tail -1 gpurun_out/r04_bench_stepham.jsonl | head -c 200; echo
 done
 timeout 300 python bench.py --integrator stepham --system chain32 --batch 16384 --dt 0.02 --steps 10 --warmup 2 2>> gpurun_out/bench_r04b_stepham_chain32.err | tail -1 >> gpurun_out/r04_bench_stepham.jsonl
-MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python bench.py --force-dist --steps 20 --warmup 5 --no-cpu-baseline 2> gpurun_out/bench_r04b_dist.err | tail -1 > gpurun_out/r04_bench_force_dist.json
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python bench.py --force-dist --steps 20 --warmup 5 --no-cpu-baseline 2> gpurun_out/bench_r04b_dist.err | grep "^{" | tail -1 > gpurun_out/r04_bench_force_dist.json
 head -c 200 gpurun_out/r04_bench_force_dist.json; echo
 timeout 600 bash scripts/profile.sh r04 doublePendulum > /dev/null 2>&1
 timeout 600 bash scripts/profile.sh r04 chain16 > /dev/null 2>&1

@@ -304,15 +304,30 @@ def test_indefinite_mass_matrices_are_inverted_like_the_reference(api, oracle_li
     eh = np.maximum(lane_err(dq, odq), lane_err(dp, odp)) / scale
     eH = lane_err(api.hamiltonian(s, ph), o.observe_batch(q[:, :nb], pg[:, :nb])[2]) / scale
     assert ev.max() < 1e-10 and eh.max() < 1e-10 and eH.max() < 1e-10, (name, B, ev.max(), eh.max(), eH.max())
+    # Stepping: an indefinite "kinetic energy" does not confine the motion -- a trajectory can run into a surface det K = 0
+    # within a few steps, where both implementations produce garbage (the first GPU run of this test: NaN on a few lanes,
+    # 1e3 on others, with velocities / hamEqs / hamiltonian above exact on all of them).  The comparison is made on the lanes
+    # the ORACLE ITSELF finds well-behaved over the span: its result moves by less than 1e4 x a 1e-9 relative perturbation
+    # of the start.  Most lanes must qualify (measured: 76 % of the 20-link chain's, 91-100 % of the others').
+    def regular(step):
+        a = step(q[:, :nb], pg[:, :nb])
+        b = step(q[:, :nb] * (1 + 1e-9), pg[:, :nb] * (1 - 1e-9))
+        with np.errstate(invalid="ignore", over="ignore"):
+            sens = np.maximum(np.abs(a[0] - b[0]).max(0), np.abs(a[1] - b[1]).max(0)) / 1e-9
+        return a, np.isfinite(sens) & (sens < 1e4)
+    (oq, op), keep = regular(lambda x, y: o.rk4_steps_batch(x, y, spec.dt, 5))
+    assert keep.mean() > 0.5, (name, B, float(keep.mean()))
     r = api.rk4Steps(spec.dt, 5, s, ph)
-    oq, op = o.rk4_steps_batch(q[:, :nb], pg[:, :nb], spec.dt, 5)
-    er = np.maximum(lane_err(r.positions, oq), lane_err(r.momenta, op)) / scale
+    with np.errstate(invalid="ignore", over="ignore"):
+        er = (np.maximum(lane_err(r.positions, oq), lane_err(r.momenta, op)) / scale)[keep]
     assert er.max() < 1e-9, (name, B, er.max())
+    (sq, sp, sns), keep = regular(lambda x, y: o.step_ham_batch(x, y, 2 * spec.dt))
+    assert keep.mean() > 0.5, (name, B, float(keep.mean()))
     sh = api.stepHam(2 * spec.dt, s, ph)
-    sq, sp, sns = o.step_ham_batch(q[:, :nb], pg[:, :nb], 2 * spec.dt)
-    same = np.asarray(s.last_nsub)[:nb] == sns
-    assert same.mean() >= 0.97, (name, B, float(same.mean()))
-    es = (np.maximum(lane_err(sh.positions, sq), lane_err(sh.momenta, sp)) / scale)[same]
+    same = (np.asarray(s.last_nsub)[:nb] == sns) & keep
+    assert same[keep].mean() >= 0.97, (name, B, float(same[keep].mean()))
+    with np.errstate(invalid="ignore", over="ignore"):
+        es = (np.maximum(lane_err(sh.positions, sq), lane_err(sh.momenta, sp)) / scale)[same]
     assert es.max() < 1e-8, (name, B, es.max())
 
 
