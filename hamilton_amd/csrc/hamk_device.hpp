@@ -54,6 +54,10 @@
 #ifndef HAMK_RKF_LDS_BUDGET
 #define HAMK_RKF_LDS_BUDGET 76 /* doubles of LDS per lane the parked RKF45 stepper may use (hamk::RkfPark) */
 #endif
+#ifndef HAMK_RKF_ROWS_IN_REGS
+#define HAMK_RKF_ROWS_IN_REGS 0 /* parked RKF45 stepper: the rows beyond the LDS share in registers (static indices) instead of scratch;
+                                   set by the generator together with HAMK_RKF_MIN_WAVES_LANE 2 and HAMK_RKF_LDS_BUDGET 36 for n <= 7 */
+#endif
 #ifndef HAMK_RK4_PARK
 #define HAMK_RK4_PARK 0       /* RK4 stage loop: y and the running combination parked in LDS across the right-hand side */
 #endif
@@ -1433,8 +1437,31 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
 #pragma unroll
       for (int j = 0; j < D; ++j) HAMK_RKF_LROW(2 + kr)[j * 256] = x[j];
     } else {
+#if HAMK_RKF_ROWS_IN_REGS
+      // small systems at two wavefronts per SIMD: the rows that do not fit the (halved) LDS share stay in REGISTERS -- every
+      // index of `v` is then a literal, so the array is promoted -- instead of scratch; y and dydt still wait in LDS
+      switch (kr) {
+        case 0:
+#pragma unroll
+          for (int j = 0; j < D; ++j) v[0][j] = x[j];
+          break;
+        case 1:
+#pragma unroll
+          for (int j = 0; j < D; ++j) v[1][j] = x[j];
+          break;
+        case 2:
+#pragma unroll
+          for (int j = 0; j < D; ++j) v[2][j] = x[j];
+          break;
+        default:
+#pragma unroll
+          for (int j = 0; j < D; ++j) v[3][j] = x[j];
+          break;
+      }
+#else
 #pragma unroll
       for (int j = 0; j < D; ++j) v[kr][j] = x[j];
+#endif
     }
   };
   int st = 0, attempts = 0;
@@ -1889,6 +1916,11 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
 #else
 #define HAMK_RK4_BOUNDS __launch_bounds__(256)
 #endif
+#ifdef HAMK_RKF_MIN_WAVES_LANE                             /* the adaptive stepper capped so that this many wavefronts share a SIMD */
+#define HAMK_RKF_BOUNDS_LANE __launch_bounds__(256, HAMK_RKF_MIN_WAVES_LANE)
+#else
+#define HAMK_RKF_BOUNDS_LANE __launch_bounds__(256)
+#endif
 #define HAMK_INSTANTIATE(S)                                                                                      \
   HAMK_SCRIBBLE_KERNEL                                                                                           \
   extern "C" __global__ void HAMK_RK4_BOUNDS hamk_rk4_steps_k(double* q, double* p, long long B, double dt,      \
@@ -1920,7 +1952,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
                                                                            long long B) {                        \
     hamk::observe_config_body<S>(q, qd, ke, lag, B);                                                             \
   }                                                                                                              \
-  extern "C" __global__ void __launch_bounds__(256) hamk_rkf45_k(                                                \
+  extern "C" __global__ void HAMK_RKF_BOUNDS_LANE hamk_rkf45_k(                                                  \
       const double* q0, const double* p0, double* qout, double* pout, long long B, int nt, const double* ts,     \
       double ts0, double ts1, double h0, double eps_abs, double eps_rel, int flags, int max_sub,                 \
       int* status, int* nsub, int ncalls, int it_every) {                                                        \

@@ -506,6 +506,16 @@ static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4,
     else if (env_flag("HAMK_RKF_PARK", &b)) d.rkf_park = b;
   }
   if (mapping == HAMK_MAP_LANE) d.rkf_park = d.rkf_stage_loop;
+  // Small systems (n <= 7): the parked stepper at TWO wavefronts per SIMD.  With every waiting vector in LDS (round 3; 144 KiB
+  // per block at n = 6) a CU holds one block, and a right-hand side of a few hundred dependent instructions cannot keep a
+  // SIMD busy alone (VALU issue 0.37).  Here the block takes half the LDS -- 36 doubles per lane: y, dydt and one or two
+  // more rows -- the other rows are REGISTERS (the private array is indexed by literals and promoted; 256 VGPRs at n = 6,
+  // two spilled), and the kernel is capped for two wavefronts.  Measured on MI355X, stepHam dt at B = 262 144, one
+  // wavefront / two (profiles/r04_rkf_hybrid_ab.jsonl): chain4 1.57e9 / 2.01e9, chain5 1.27e9 / 1.62e9, chain6 1.05e9 /
+  // 1.32e9, threeBodyPolar 1.15e9 / 1.41e9, chain7 8.8e8 / 9.4e8; states equal to 4e-16, sub-step counts identical.  (Without
+  // the sincos table to make room: 1.34e9; two LDS rows: 1.19e9; three wavefronts: 8.5e8.  From n = 8 the right-hand side
+  // alone needs more than 256 registers.)
+  d.rkf_two_waves = mapping == HAMK_MAP_LANE && d.rkf_stage_loop && n <= 7;
   d.k_reassoc = true;
   if (o.k_reassoc != HAMK_AUTO) d.k_reassoc = o.k_reassoc == HAMK_ON;
   {
