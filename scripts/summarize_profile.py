@@ -25,7 +25,7 @@ if os.path.exists(bj) and os.path.getsize(bj):
     summary["rocprof_vs_hip_events"] = float(stats[KERNEL]["AverageNs"]) * 1e-6 / bench["roofline"]["kernel_ms"]
 
 pmc = {}
-for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds", "pmc_mfma"):
+for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds", "pmc_mfma", "pmc_vmem", "pmc_ifetch"):
     path = os.path.join(src, name, f"{tag}_counter_collection.csv")
     if not os.path.exists(path):
         continue
@@ -67,6 +67,9 @@ if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc and K:
         summary["valu_pipe_busy_frac_of_1024_simds"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (pmc["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     if "SQ_WAIT_INST_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc:
         summary["wait_frac_of_wave_cycles"] = pmc["SQ_WAIT_INST_ANY"] / pmc["SQ_WAVE_CYCLES"]
+for k_wait in ("SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_ANY"):
+    if k_wait in pmc and "SQ_WAVE_CYCLES" in pmc:
+        summary[k_wait.lower() + "_frac_of_wave_cycles"] = pmc[k_wait] / pmc["SQ_WAVE_CYCLES"]
 if "SQ_LDS_IDX_ACTIVE" in pmc and "GRBM_GUI_ACTIVE" in pmc:
     # LDS-array cycles summed over the 256 CUs against the kernel's cycles x 256 LDS units
     summary["lds_busy_frac_of_256_units"] = pmc["SQ_LDS_IDX_ACTIVE"] / (pmc["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)
