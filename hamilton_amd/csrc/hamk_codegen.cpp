@@ -466,6 +466,7 @@ std::string generate_source(const SystemDesc& d) {
   o << "#define HAMK_K_REASSOC " << (d.k_reassoc ? 1 : 0) << "\n";
   if (d.rk4_park && !d.wave) o << "#define HAMK_RK4_PARK 1\n";
   if (d.mapping == HAMK_MAP_QUAD) o << "#define HAMK_QUAD_RKF_PARK " << (d.rkf_park ? 1 : 0) << "\n";
+  if (d.mapping == HAMK_MAP_LANE && d.trig_const_vgpr && d.use_lut != 0) o << "#define HAMK_TRIG_CONST_VGPR 1\n";
   if (d.mapping == HAMK_MAP_LANE && d.rkf_two_waves)
     o << "#define HAMK_RKF_MIN_WAVES_LANE 2\n#define HAMK_RKF_LDS_BUDGET 36\n#define HAMK_RKF_ROWS_IN_REGS 1\n";
   // (sin, cos)(i 2pi/512), correctly rounded from 80-bit: the constant data behind sincos_lut's LDS table

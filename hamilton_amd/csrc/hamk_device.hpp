@@ -429,28 +429,64 @@ HAMK_DEV void lut_load() {
   __syncthreads();
 #endif
 }
-HAMK_DEV void sincos_lut_fast(double x, double& s, double& c) {     // |x| < 1.6e6
-  const double k = rint(x * 0x1.45f306dc9c883p+6);               // 512 / 2pi
-  double r = fma(-k, 0x1.921fb58p-7, x);                         // 2pi/512 bits  0..25
-  r = fma(-k, -0x1.dde974p-34, r);                               //              26..51
-  r = fma(-k, 0x1.1a62633145c07p-61, r);                         //              52..
+// The nine fp64 literals of sincos_lut.  gfx950 has no 64-bit literal operands: each one is an SGPR pair filled by two
+// s_mov_b32, and a kernel whose scalar registers are short (every RKF45 kernel: its modules are built without MachineLICM,
+// DESIGN.md section 8) re-materialises them at EVERY evaluation -- 8 sites x 9 literals x 2 = 144 scalar moves per
+// right-hand side of chain8, a seventh of the adaptive kernel's issue slots at one wavefront per SIMD (PMC: 4.4 k SALU per
+// wave-call against 21 k VALU; the RK4 kernel of the same system, built with the hoisting, executes 49 per right-hand
+// side).  LutK keeps them in VECTOR registers instead (18 VGPRs, filled once per kernel behind an opaque statement);
+// kernels with registers to spare take their operands from there (HAMK_TRIG_CONST_VGPR, set by the generator).
+struct LutK {
+  double inv_step, w0, w1, w2, s5, s3, c6, c4, lim;
+  HAMK_DEV LutK() {
+    inv_step = park_const(0x1.45f306dc9c883p+6);          // 512 / 2pi
+    w0 = park_const(0x1.921fb58p-7);                      // 2pi/512 bits  0..25
+    w1 = park_const(-0x1.dde974p-34);                     //              26..51
+    w2 = park_const(0x1.1a62633145c07p-61);               //              52..
+    s5 = park_const(8.33333333333333321769e-03);
+    s3 = park_const(-1.66666666666666657415e-01);
+    c6 = park_const(-1.38888888888888894189e-03);
+    c4 = park_const(4.16666666666666643537e-02);
+    lim = park_const(1.6e6);
+  }
+  static HAMK_DEV double park_const(double x) {
+#ifndef HAMK_HOST_EMULATION
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+  }
+};
+struct LutLiterals {                                      // the same numbers as literals (the compiler decides where they live)
+  static constexpr double inv_step = 0x1.45f306dc9c883p+6, w0 = 0x1.921fb58p-7, w1 = -0x1.dde974p-34, w2 = 0x1.1a62633145c07p-61,
+                          s5 = 8.33333333333333321769e-03, s3 = -1.66666666666666657415e-01, c6 = -1.38888888888888894189e-03,
+                          c4 = 4.16666666666666643537e-02, lim = 1.6e6;
+};
+template <class KC> HAMK_DEV void sincos_lut_fast(double x, double& s, double& c, const KC& kc) {     // |x| < 1.6e6
+  const double k = rint(x * kc.inv_step);
+  double r = fma(-k, kc.w0, x);
+  r = fma(-k, kc.w1, r);
+  r = fma(-k, kc.w2, r);
   const int idx = ((int)k) & (HAMK_LUT_N - 1);
   const double sa = HAMK_LUT[2 * idx], ca = HAMK_LUT[2 * idx + 1];
   const double z = r * r;
-  const double ps = fma(8.33333333333333321769e-03, z, -1.66666666666666657415e-01);
+  const double ps = fma(kc.s5, z, kc.s3);
   const double sd = fma(r * z, ps, r);                           // sin r
-  double pc = fma(-1.38888888888888894189e-03, z, 4.16666666666666643537e-02);
+  double pc = fma(kc.c6, z, kc.c4);
   pc = fma(pc, z, -0.5);
   const double cm1 = z * pc;                                     // cos r - 1
   s = sa + fma(sa, cm1, ca * sd);
   c = ca + fma(ca, cm1, -(sa * sd));
 }
-HAMK_DEV void sincos_lut(double x, double& s, double& c) {
-  sincos_lut_fast(x, s, c);
+template <class KC> HAMK_DEV void sincos_lut(double x, double& s, double& c, const KC& kc) {
+  sincos_lut_fast(x, s, c, kc);
 #ifndef HAMK_PROBE_NO_SLOWPATH
-  if (!(fabs(x) < 1.6e6)) { s = ::sin(x); c = ::cos(x); }        // huge, NaN, Inf: library path
+  if (!(fabs(x) < kc.lim)) { s = ::sin(x); c = ::cos(x); }        // huge, NaN, Inf: library path
 #endif
 }
+HAMK_DEV void sincos_lut(double x, double& s, double& c) { sincos_lut(x, s, c, LutLiterals()); }
+// the constants a sincos site takes: the cache's own (TrigCache with HAMK_TRIG_CONST_VGPR) or the literals
+template <class TC> HAMK_DEV auto lut_consts(const TC& tc, int) -> decltype(tc.kc) { return tc.kc; }
+template <class TC> HAMK_DEV LutLiterals lut_consts(const TC&, long) { return LutLiterals(); }
 
 // sin and cos of one argument always come as a pair (codegen fuses the tape's
 // SIN/COS of a shared operand): one fp64 sincos feeds value, gradient and Hessian.
@@ -489,10 +525,16 @@ HAMK_DEV void sincos_lut(double x, double& s, double& c) {
 enum : int { TRIG_FULL = 0, TRIG_REUSE = 1, TRIG_ANCHOR = 2, TRIG_INCR = 3, TRIG_DYN = 4, TRIG_LUT = 5 };
 enum : int { DYN_FULL_ANCHOR = 0, DYN_NARROW_ANCHOR = 1, DYN_NARROW = 2, DYN_SHORT = 3 };
 
+#ifndef HAMK_TRIG_CONST_VGPR
+#define HAMK_TRIG_CONST_VGPR 0
+#endif
 template <int NS> struct TrigCache {
   double s[NS > 0 ? NS : 1], c[NS > 0 ? NS : 1];                           // current point
   double ax[NS > 0 ? NS : 1], as[NS > 0 ? NS : 1], ac[NS > 0 ? NS : 1];    // anchor
   int mode = DYN_FULL_ANCHOR;                                              // TRIG_DYN: wave-uniform
+#if HAMK_TRIG_CONST_VGPR
+  LutK kc;                                                                 // sincos_lut's literals, in vector registers (see LutK)
+#endif
   HAMK_DEV TrigCache() {                                                   // a defined anchor (0, sin 0, cos 0) from the start
 #pragma unroll
     for (int k = 0; k < (NS > 0 ? NS : 1); ++k) { ax[k] = 0.0; as[k] = 0.0; ac[k] = 1.0; }
@@ -555,7 +597,7 @@ template <int MODE, class TC> HAMK_DEV void trig_pair(double x, TC& tc, int k) {
   if constexpr (MODE == TRIG_FULL) {
     sincos_f64(x, tc.s[k], tc.c[k]);
   } else if constexpr (MODE == TRIG_LUT) {
-    sincos_lut(x, tc.s[k], tc.c[k]);
+    sincos_lut(x, tc.s[k], tc.c[k], lut_consts(tc, 0));
   } else if constexpr (MODE == TRIG_ANCHOR) {
     sincos_f64(x, tc.s[k], tc.c[k]);
     tc.ax[k] = x; tc.as[k] = tc.s[k]; tc.ac[k] = tc.c[k];
@@ -578,9 +620,9 @@ template <int MODE, class TC> HAMK_DEV void trig_pair(double x, TC& tc, int k) {
     }
     // (with the LDS table loaded -- HAMK_USE_LUT -- the full evaluation is sincos_lut: 22 instructions)
 #ifdef HAMK_PROBE_NO_SLOWPATH
-    if (mode == DYN_FULL_ANCHOR) { if constexpr (HAMK_USE_LUT != 0) sincos_lut(x, tc.s[k], tc.c[k]); else sincos_f64(x, tc.s[k], tc.c[k]); }
+    if (mode == DYN_FULL_ANCHOR) { if constexpr (HAMK_USE_LUT != 0) sincos_lut(x, tc.s[k], tc.c[k], lut_consts(tc, 0)); else sincos_f64(x, tc.s[k], tc.c[k]); }
 #else
-    if (full) { if constexpr (HAMK_USE_LUT != 0) sincos_lut(x, tc.s[k], tc.c[k]); else sincos_f64(x, tc.s[k], tc.c[k]); }
+    if (full) { if constexpr (HAMK_USE_LUT != 0) sincos_lut(x, tc.s[k], tc.c[k], lut_consts(tc, 0)); else sincos_f64(x, tc.s[k], tc.c[k]); }
 #endif
     if (mode == DYN_FULL_ANCHOR || mode == DYN_NARROW_ANCHOR) { tc.ax[k] = x; tc.as[k] = tc.s[k]; tc.ac[k] = tc.c[k]; }
   }

@@ -541,6 +541,14 @@ static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4,
     // by mistake together with the lane-kernel rule it used to share a line with)
     if (n >= 14 && mapping == HAMK_MAP_QUAD) d.use_lut = 0;
   }
+  // sincos_lut's nine fp64 literals in VECTOR registers for the mid-size lane kernels (hamk_device.hpp LutK): every RKF45 kernel is
+  // taken from the build without MachineLICM, which re-materialises them -- two s_mov_b32 each -- at every evaluation: 144
+  // scalar moves per right-hand side of chain8, a seventh of the issue slots of a kernel that has one wavefront per SIMD.  With
+  // the literals gone the RK4 kernels of n = 10..16 also stop spilling SGPRs in the default build and are taken from it.
+  // Measured on MI355X (profiles/r04_trig_const_vgpr_ab.jsonl; stepHam calls/s, RK4 steps/s): chain8 +6 % / 0, chain10 +4 % /
+  // +4 %, chain12 +4 % / +5 %, chain14 +5 % / +1 %; chain16 +3 % / -2 %, chain6 and threeBodyPolar +-1 %, doublePendulum
+  // -6 % / -6 % (18 more registers where occupancy pays) -- so: 8 <= n <= 14.
+  d.trig_const_vgpr = mapping == HAMK_MAP_LANE && n >= 8 && n <= 14;
   if (o.trig != HAMK_AUTO) d.use_lut = o.trig == HAMK_TRIG_DIRECT ? 0 : (o.trig == HAMK_TRIG_TABLE ? 1 : 2);
   else if (const char* e = std::getenv("HAMK_TRIG_LUT")) { if (e[0] >= '0' && e[0] <= '2') d.use_lut = e[0] - '0'; }
   return d;

@@ -25,6 +25,7 @@ struct SystemDesc {
   bool k_reassoc = true;        // mass_matrix summed with re-association allowed (hamk_device.hpp)
   bool rkf_park = false;        // lane / quad mapping: the RKF45 stepper's vectors in a run-time-indexed private array
   bool rk4_park = false;        // lane mapping: RK4 stage loop parks y / acc in LDS across the right-hand side
+  bool trig_const_vgpr = false; // lane mapping, 8 <= n <= 14: sincos_lut's fp64 literals live in vector registers (hamk_device.hpp LutK)
   bool rkf_two_waves = false;   // lane mapping, n <= 7: the parked RKF45 stepper at two wavefronts per SIMD (rows beyond a halved LDS share in registers)
   bool wave_blocked = false;    // wave kernels: LDL^T in panels of 16 with the trailing blocks updated on the matrix cores
   std::vector<double> inertia;
