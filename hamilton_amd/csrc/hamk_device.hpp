@@ -48,6 +48,9 @@
 #endif
 
 #define HAMK_DEV __device__ __forceinline__
+#ifndef HAMK_JET_REASSOC
+#define HAMK_JET_REASSOC 1    /* gradient parts of Jet1 + and - may be re-associated (x + x + ... -> count x: the potential's sum over outputs) */
+#endif
 #ifndef HAMK_K_REASSOC
 #define HAMK_K_REASSOC 1      /* K = J^T M J summed with re-association allowed (mass_matrix); 0: the round-2 FMA chain */
 #endif
@@ -193,16 +196,29 @@ HAMK_DEV Jet2<N> chain2(const Jet2<N>& a, const Jet2<N>& b, double f0, double fa
 
 // ---- ring operations ----------------------------------------------------------
 // Jet1
+// (the gradient parts of + and - may be re-associated, the values may not: a potential that sums many outputs of f whose
+// Jacobian rows share entries -- a chain's U = g sum_k y_k, dy_k/dq_j one value for every k >= j -- otherwise adds that
+// value n - j times per coordinate, n^2 / 2 additions where "count x value" is n multiplications; HAMK_JET_REASSOC)
 template <int N> HAMK_DEV Jet1<N> operator+(const Jet1<N>& a, const Jet1<N>& b) {
   Jet1<N> r; r.v = a.v + b.v;
+  {
+#if HAMK_JET_REASSOC
+#pragma clang fp reassociate(on)
+#endif
 #pragma unroll
-  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i];
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i];
+  }
   return r;
 }
 template <int N> HAMK_DEV Jet1<N> operator-(const Jet1<N>& a, const Jet1<N>& b) {
   Jet1<N> r; r.v = a.v - b.v;
+  {
+#if HAMK_JET_REASSOC
+#pragma clang fp reassociate(on)
+#endif
 #pragma unroll
-  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i];
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i];
+  }
   return r;
 }
 template <int N> HAMK_DEV Jet1<N> operator*(const Jet1<N>& a, const Jet1<N>& b) {

@@ -205,8 +205,16 @@ template <class S> struct SinkK {
   }
 };
 
-// LDL^T of the quad's K in registers, the forward substitution of one right-hand side riding along.
-// On return: Kp[i][j], j < 4 i + r: L; Kp[i][4 i + r] = 1 / d_(4 i + r); z[i] = (L^-1 rhs)_(4 i + r).
+// 1 / sqrt(d) for normal-range d > 0: hardware estimate + one third-order step (6 instructions, <= 1 ulp)
+HAMK_DEV double frsqrt(double d) {
+  const double y = __builtin_amdgcn_rsq(d);
+  const double e = fma(-(d * y), y, 1.0);
+  return fma(y * e, fma(0.375, e, 0.5), y);
+}
+
+// CHOLESKY K = G G^T of the quad's K in registers, IN PLACE, the forward substitution of one right-hand side riding along.
+// On return: Kp[i][j], j < 4 i + r: G; Kp[i][4 i + r] = 1 / G_aa (a = 4 i + r); z[i] = w_a = p_a - sum_(k < a) G[a][k] y_k with
+// y_k = w_k / G_kk (the owner keeps the UNSCALED w: solve_back divides twice).
 // Pivot j lives in lane j % 4, slot j / 4.  Right-looking in PANELS OF FOUR PIVOTS -- one slot of rows, the quad's own
 // granularity: the four pivots of a panel are eliminated one after the other inside the panel's four columns only
 // (d_j and the three or fewer column entries below it broadcast by DPP, every lane scaling its own rows), and the
@@ -214,38 +222,40 @@ template <class S> struct SinkK {
 // their owner (8 DPP moves), then four FMAs per entry.  Same flops and the same DPP traffic as pivot-by-pivot, but
 // every trailing entry is read and written n/4 times instead of n: at n = 32 the lane's 144 doubles of K exceed the
 // 256 architectural VGPRs, the rest lives in AGPRs, and each touch of such an entry costs four v_accvgpr moves.
+// Cholesky rather than LDL^T (round 4): with G = L sqrt(D) the update K[a][k] -= G[a][j] G[k][j] multiplies the lane's own
+// entry by the broadcast one -- both the SAME scaled column, stored where it will stay -- whereas LDL^T needs the column
+// twice while a panel is open (L[a][j] and d_j L[k][j]: 32 more doubles per lane at n = 32, all of them AGPR traffic),
+// and a pass of selects per panel to put L in place afterwards.  1 / sqrt costs what 1 / d did.
 // The code is the same for the four lanes: slot i is updated over columns up to 4 i + 3 whichever row of the slot the lane
 // owns; the entries beyond the lane's diagonal are the symmetric ones and never read.
 template <class S>
-HAMK_DEV void ldlt(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], int& st) {
-  constexpr int N = S::N, NR = Geo<N>::NR, NP4 = Geo<N>::NP4;
+HAMK_DEV void chol(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], int& st) {
+  constexpr int N = S::N, NR = Geo<N>::NR;
   bool ok = true;
 #pragma unroll
   for (int jb = 0; jb < NR; ++jb) {
     HAMK_PHASE();
     const int J0 = 4 * jb, J1 = (4 * jb + 4 < N) ? 4 * jb + 4 : N;        // this panel's pivots [J0, J1)
-    double l[NR][4];                                     // the lane's multipliers: l[i][jj] = L[4 i + r][J0 + jj]
-    double pinv[4] = {1.0, 1.0, 1.0, 1.0};               // 1 / d of the panel's pivots
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = J0 + jj;
-      if (j >= J1) {
-#pragma unroll
-        for (int i = 0; i < NR; ++i) l[i][jj] = 0.0;
-        continue;
-      }
-      double d, zj;
+      if (j >= J1) continue;
+      double d, wj;
       switch (jj) {                                      // (a literal after unrolling: one case survives)
-        case 0: d = qbcast<0>(Kp[jb][j]); zj = qbcast<0>(z[jb]); break;
-        case 1: d = qbcast<1>(Kp[jb][j]); zj = qbcast<1>(z[jb]); break;
-        case 2: d = qbcast<2>(Kp[jb][j]); zj = qbcast<2>(z[jb]); break;
-        default: d = qbcast<3>(Kp[jb][j]); zj = qbcast<3>(z[jb]); break;
+        case 0: d = qbcast<0>(Kp[jb][j]); wj = qbcast<0>(z[jb]); break;
+        case 1: d = qbcast<1>(Kp[jb][j]); wj = qbcast<1>(z[jb]); break;
+        case 2: d = qbcast<2>(Kp[jb][j]); wj = qbcast<2>(z[jb]); break;
+        default: d = qbcast<3>(Kp[jb][j]); wj = qbcast<3>(z[jb]); break;
       }
       ok = ok && (d > 0.0);
-      const double inv = frcp(d);
-      pinv[jj] = inv;
+      const double rs = frsqrt(d);
+      const double yj = wj * rs;
+      // column j, scaled where it stays: the rows below the pivot; the pivot's own lane keeps 1 / G_jj; rows above keep what they hold
 #pragma unroll
-      for (int i = 0; i < NR; ++i) l[i][jj] = (i >= jb && 4 * i + r > j) ? Kp[i][j] * inv : 0.0;
+      for (int i = jb + 1; i < NR; ++i) Kp[i][j] *= rs;
+      const double below = Kp[jb][j] * rs;
+      Kp[jb][j] = (r > jj) ? below : ((r == jj) ? rs : Kp[jb][j]);
+      const double lm = (r > jj) ? below : 0.0;         // the slot's multiplier: rows at or above the pivot take no update
       // inside the panel: the columns (j, J1) of every row below the pivot
 #pragma unroll
       for (int k = j + 1; k < J1; ++k) {
@@ -255,13 +265,15 @@ HAMK_DEV void ldlt(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&
           case 2: c = qbcast<2>(Kp[jb][j]); break;
           default: c = qbcast<3>(Kp[jb][j]); break;
         }
+        Kp[jb][k] = fma(-lm, c, Kp[jb][k]);
 #pragma unroll
-        for (int i = jb; i < NR; ++i) Kp[i][k] = fma(-l[i][jj], c, Kp[i][k]);
+        for (int i = jb + 1; i < NR; ++i) Kp[i][k] = fma(-Kp[i][j], c, Kp[i][k]);
       }
+      z[jb] = fma(-lm, yj, z[jb]);
 #pragma unroll
-      for (int i = jb; i < NR; ++i) z[i] = fma(-l[i][jj], zj, z[i]);
+      for (int i = jb + 1; i < NR; ++i) z[i] = fma(-Kp[i][j], yj, z[i]);
     }
-    // the trailing matrix, one pass: K[a][k] -= sum_jj L[a][J0 + jj] (d L[k][J0 + jj]), k >= J1
+    // the trailing matrix, one pass: K[a][k] -= sum_jj G[a][J0 + jj] G[k][J0 + jj], k >= J1
 #pragma unroll
     for (int k = J1; k < N; ++k) {
       const int sk = k >> 2;
@@ -280,23 +292,17 @@ HAMK_DEV void ldlt(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&
       for (int i = sk; i < NR; ++i) {
         double t = Kp[i][k];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) t = fma(-l[i][jj], c[jj], t);
+        for (int jj = 0; jj < 4; ++jj) if (J0 + jj < J1) t = fma(-Kp[i][J0 + jj], c[jj], t);
         Kp[i][k] = t;
       }
     }
-    // L of the panel, final (rows at or above a pivot keep what they hold: the pivot's own lane keeps d_j)
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-      for (int i = jb; i < NR; ++i)
-        if (J0 + jj < J1) Kp[i][J0 + jj] = (4 * i + r > J0 + jj) ? l[i][jj] : ((i == jb && r == jj) ? pinv[jj] : Kp[i][J0 + jj]);
   }
   if (!ok) st |= ST_SINGULAR;                            // every inertia positive (HAMK_INSTANTIATE_QUAD asserts it): a non-positive pivot IS singular
 }
 
-// D y = z, L^T v = y; returns the lane's v_(4 i + r).  Row-oriented: L[k][a] is in the lane that owns row k, so the lanes
-// accumulate partial sums s[a] = sum over their own solved rows k > a of L[k][a] v_k and the four partial sums meet in a
-// quad reduction when v_a is due.
+// G y = w is done (z holds w, y_a = w_a / G_aa); G^T v = y here; returns the lane's v_(4 i + r).  Row-oriented: G[k][a] is in
+// the lane that owns row k, so the lanes accumulate partial sums s[a] = sum over their own solved rows k > a of G[k][a] v_k and
+// the four partial sums meet in a quad reduction when v_a is due.
 template <class S>
 HAMK_DEV void solve_back(int r, const double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], const double (&z)[Geo<S::N>::NR], double (&v)[Geo<S::N>::NR]) {
   constexpr int N = S::N, NR = Geo<N>::NR, NP4 = Geo<N>::NP4;
@@ -311,7 +317,7 @@ HAMK_DEV void solve_back(int r, const double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4
     for (int rr = 3; rr >= 0; --rr) {
       const int a = 4 * i + rr;
       if (a >= N) continue;
-      const double va = fma(z[i], Kp[i][a], -qsum(s[a]));   // meaningful in lane rr, whose Kp[i][a] is 1 / d_a
+      const double va = fma(z[i], Kp[i][a], -qsum(s[a])) * Kp[i][a];   // meaningful in lane rr, whose Kp[i][a] is 1 / G_aa
       if (r == rr) vi = va;
       // row a's entries inside the diagonal block feed the rows of the same slot still to come
 #pragma unroll
@@ -353,7 +359,7 @@ HAMK_DEV void stage_inputs(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR]) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       double sv, cv;
-      if constexpr (LUT) sincos_lut_fast(qi[i], sv, cv); else sincos_f64_fast(qi[i], sv, cv);
+      if constexpr (LUT) sincos_lut_fast(qi[i], sv, cv, LutLiterals()); else sincos_f64_fast(qi[i], sv, cv);
       c.sq()[(4 * i + r) * 64] = sv; c.cq()[(4 * i + r) * 64] = cv;
       far = far || !(fabs(qi[i]) < 1.6e6);
     }
@@ -394,7 +400,7 @@ HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const
 #pragma unroll
   for (int i = 0; i < NR; ++i) { z[i] = pi[i]; c.gu()[(4 * i + r) * 64] = gUi[i]; gUi[i] = 0.0; }      // (dU/dq waits in LDS: Ctx::gu)
   HAMK_PHASE();
-  ldlt<S>(r, sink.acc, z, st);
+  chol<S>(r, sink.acc, z, st);
   HAMK_PHASE();
   solve_back<S>(r, sink.acc, z, vi);
   HAMK_PHASE();
