@@ -299,6 +299,14 @@ static void emit_reverse(std::ostringstream& o, const SystemDesc& d) {
     if (is_input(i)) return "v[" + std::to_string(r.ops[i].a) + "]";
     return "t" + std::to_string(i);
   };
+  auto valr = [&](int i) -> std::string {            // the same, as the reverse pass reads them
+    if (is_input(i)) return "qr.at(" + std::to_string(r.ops[i].a) + ")";
+    return val(i);
+  };
+  auto tanr = [&](int i) -> std::string {
+    if (active[i] && is_input(i)) return "vr.at(" + std::to_string(r.ops[i].a) + ")";
+    return tan_(i);
+  };
   auto adj = [&](int i, char w) -> std::string {     // adjoint accumulators: a = of value, b = of tangent
     if (is_input(i)) return std::string(1, w) + "q" + std::to_string(r.ops[i].a);
     return std::string(1, w) + std::to_string(i);
@@ -357,6 +365,11 @@ static void emit_reverse(std::ostringstream& o, const SystemDesc& d) {
     }
   }
   // ---- adjoints -----------------------------------------------------------------------------
+  // (the reverse pass reads q, v and the sincos pairs through reverse_vec / reverse_trig: the identity where they are registers; where they
+  // are LDS rows -- the four-lane kernels -- a re-laundered pointer, so that the pass loads them again instead of keeping 3 n
+  // doubles alive from the forward pass in registers the forward pass's own intermediates need)
+  o << "    using hamk::reverse_vec; using hamk::reverse_trig;\n";
+  o << "    const auto qr = reverse_vec(q); const auto vr = reverse_vec(v); const auto& tcr = reverse_trig(tc);\n";
   o << "    double";
   for (int j = 0; j < d.n; ++j) o << (j ? "," : "") << " aq" << j << " = 0.0, bq" << j << " = 0.0";
   o << ";\n";
@@ -379,20 +392,30 @@ static void emit_reverse(std::ostringstream& o, const SystemDesc& d) {
       case HAMK_OP_SUB: acc(p.a, 'a', aI); acc(p.a, 'b', bI); acc(p.b, 'a', "-" + aI); acc(p.b, 'b', "-" + bI); break;
       case HAMK_OP_NEG: acc(p.a, 'a', "-" + aI); acc(p.a, 'b', "-" + bI); break;
       case HAMK_OP_MUL:
-        acc(p.a, 'a', aI + " * " + val(p.b) + (active[p.b] ? " + " + bI + " * " + tan_(p.b) : ""));
-        acc(p.a, 'b', bI + " * " + val(p.b));
-        acc(p.b, 'a', aI + " * " + val(p.a) + (active[p.a] ? " + " + bI + " * " + tan_(p.a) : ""));
-        acc(p.b, 'b', bI + " * " + val(p.a));
+        acc(p.a, 'a', aI + " * " + valr(p.b) + (active[p.b] ? " + " + bI + " * " + tanr(p.b) : ""));
+        acc(p.a, 'b', bI + " * " + valr(p.b));
+        acc(p.b, 'a', aI + " * " + valr(p.a) + (active[p.a] ? " + " + bI + " * " + tanr(p.a) : ""));
+        acc(p.b, 'b', bI + " * " + valr(p.a));
         break;
       case HAMK_OP_POW:
       case HAMK_OP_ATAN2:
-        acc(p.a, 'a', aI + " * fa" + I + " + " + bI + " * (faa" + I + " * " + tan_(p.a) + " + fab" + I + " * " + tan_(p.b) + ")");
+        acc(p.a, 'a', aI + " * fa" + I + " + " + bI + " * (faa" + I + " * " + tanr(p.a) + " + fab" + I + " * " + tanr(p.b) + ")");
         acc(p.a, 'b', bI + " * fa" + I);
-        acc(p.b, 'a', aI + " * fb" + I + " + " + bI + " * (fab" + I + " * " + tan_(p.a) + " + fbb" + I + " * " + tan_(p.b) + ")");
+        acc(p.b, 'a', aI + " * fb" + I + " + " + bI + " * (fab" + I + " * " + tanr(p.a) + " + fbb" + I + " * " + tanr(p.b) + ")");
         acc(p.b, 'b', bI + " * fb" + I);
         break;
-      default:                                        // every unary function: y = g(x), ty = g'(x) tx
-        acc(p.a, 'a', aI + " * g" + I + " + " + bI + " * h" + I + " * " + tan_(p.a));
+      case HAMK_OP_SIN: {                             // g = cos, h = -sin, read again from the cache's view
+        const std::string sl = std::to_string(r.slot[i]);
+        acc(p.a, 'a', aI + " * tcr.c[" + sl + "] - " + bI + " * tcr.s[" + sl + "] * " + tanr(p.a));
+        acc(p.a, 'b', bI + " * tcr.c[" + sl + "]");
+      } break;
+      case HAMK_OP_COS: {                             // g = -sin, h = -cos
+        const std::string sl = std::to_string(r.slot[i]);
+        acc(p.a, 'a', "-(" + aI + " * tcr.s[" + sl + "] + " + bI + " * tcr.c[" + sl + "] * " + tanr(p.a) + ")");
+        acc(p.a, 'b', "-(" + bI + " * tcr.s[" + sl + "])");
+      } break;
+      default:                                        // every other unary function: y = g(x), ty = g'(x) tx
+        acc(p.a, 'a', aI + " * g" + I + " + " + bI + " * h" + I + " * " + tanr(p.a));
         acc(p.a, 'b', bI + " * g" + I);
         break;
     }

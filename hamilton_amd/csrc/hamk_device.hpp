@@ -855,6 +855,15 @@ HAMK_DEV void solve_spd(const double (&K)[N][N], const double (&p)[N], double (&
   else if (!ok) solve_lu<N>(K, p, v, st);   // rare, lane-divergent
 }
 
+// How the generated reverse sweep (S::dT_reverse) reads its inputs a second time: where they are registers, the same values;
+// hamk_quad.hpp overloads both for its LDS rows (found by argument-dependent lookup).
+template <class T> struct SameVec {
+  const T& x;
+  HAMK_DEV double at(int j) const { return x[j]; }
+};
+template <class T> HAMK_DEV SameVec<T> reverse_vec(const T& x) { return SameVec<T>{x}; }
+template <class TC> HAMK_DEV const TC& reverse_trig(const TC& tc) { return tc; }
+
 // ===========================================================================
 // The System record's closures on one trajectory (Hamilton.hs:160-169).
 // S (generated): N, M, U_CART, MODE_H, RK4_STAGE_LOOP, RKF_STAGE_LOOP, NTRIG_F, NTRIG_U, inertia(k),

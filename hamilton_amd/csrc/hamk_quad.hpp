@@ -45,6 +45,17 @@ template <class S> struct Lds {
   static constexpr int NP4 = Geo<S::N>::NP4;
   static constexpr int Q = 0, V = NP4 * 64, SQ = 2 * NP4 * 64, CQ = 3 * NP4 * 64, GU = 4 * NP4 * 64, TOTAL = 5 * NP4 * 64;
 };
+#ifndef HAMK_QUAD_MSEL
+#define HAMK_QUAD_MSEL 1
+#endif
+#if HAMK_QUAD_MSEL
+#define HAMK_QUAD_PICK(r, lm, a, b, c, d) hamk::quad::msel4(lm, a, b, c, d)
+#else
+#define HAMK_QUAD_PICK(r, lm, a, b, c, d) hamk::quad::sel4(r, a, b, c, d)
+#endif
+#ifndef HAMK_QUAD_LEFT
+#define HAMK_QUAD_LEFT 1
+#endif
 #define HAMK_QUAD_SMEM(S) __shared__ double smem[hamk::quad::Lds<S>::TOTAL]
 
 #ifdef HAMK_HOST_EMULATION
@@ -113,11 +124,41 @@ HAMK_DEV double sel4(int r, double a, double b, double c, double d) {
   return (r & 2) ? cd : ab;
 }
 
+// The same choice by ARITHMETIC: m[rr] = (lane == rr) ? 1 : 0, candidate a m[0] + b m[1] + c m[2] + d m[3] -- four fp64 instructions
+// instead of six v_cndmask, and one per candidate that is not a compile-time zero (the rows of K inside the diagonal block pick
+// from (a, 0, 0, 0), (a, b, 0, 0), (a, b, c, 0): 1 / 2 / 3 instructions instead of 4 / 4 / 6).  Exact for finite candidates; a
+// non-finite one reaches all four rows instead of one -- of a trajectory that is lost either way (ST_NONFINITE).  Written
+// OUTSIDE the re-association regions: the sum is a leaf there.
+struct LaneMask {
+  double m[4];
+  HAMK_DEV explicit LaneMask(int r) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) m[rr] = (r == rr) ? 1.0 : 0.0;
+  }
+};
+HAMK_DEV double msel4(const LaneMask& k, double a, double b, double c, double d) { return a * k.m[0] + b * k.m[1] + c * k.m[2] + d * k.m[3]; }
+
 // one component of the trajectory's shared state in LDS
 struct LdsVec {
   const double* p;
   HAMK_DEV double operator[](int j) const { return p[j * 64]; }
+  HAMK_DEV double at(int j) const { return p[j * 64]; }
 };
+// a second look at the same row through a pointer the compiler cannot connect with the first: the reverse pass of
+// S::dT_reverse LOADS q, v and the sincos pairs again (one ds_read2st64_b64 per two values) instead of keeping 3 n doubles
+// from its forward pass alive in accumulation registers (four v_accvgpr moves per value)
+HAMK_DEV const double* relaunder(const double* p) {
+#ifndef HAMK_HOST_EMULATION
+  // (the 32-bit LDS offset is what passes through the opaque statement: a laundered generic pointer would be read with flat loads)
+  typedef const __attribute__((address_space(3))) double* lds_ptr;
+  unsigned off = (unsigned)(unsigned long long)(lds_ptr)p;
+  asm volatile("" : "+v"(off));
+  return (const double*)(lds_ptr)(unsigned long long)off;
+#else
+  return p;
+#endif
+}
+HAMK_DEV LdsVec reverse_vec(const LdsVec& x) { return LdsVec{relaunder(x.p)}; }
 // sweep inputs with COMPILE-TIME seeds: q_j with d/dq_i = delta_ij (j is a literal after inlining)
 template <int N> struct InJet1 {
   const double* q;
@@ -141,6 +182,9 @@ template <class S> struct TrigLdsQ {
   TrigSite<S> s, c;
   double* ax; double* as; double* ac;       // unused (TRIG_REUSE never touches them)
 };
+template <class S> HAMK_DEV TrigLdsQ<S> reverse_trig(const TrigLdsQ<S>& t) {
+  TrigLdsQ<S> u = t; u.s.base = relaunder(t.s.base); u.c.base = relaunder(t.c.base); return u;
+}
 
 template <class S> struct Ctx {
   static constexpr int N = S::N, NR = Geo<N>::NR, NP4 = Geo<N>::NP4;
@@ -178,8 +222,9 @@ template <class S> struct SinkK {
   static constexpr int N = S::N, NR = Geo<N>::NR, NP4 = Geo<N>::NP4;
   double acc[NR][NP4];
   int r;
+  LaneMask lm{0};
   HAMK_DEV void init(int r_) {
-    r = r_;
+    r = r_; lm = LaneMask(r_);
 #pragma unroll
     for (int i = 0; i < NR; ++i)
 #pragma unroll
@@ -189,7 +234,7 @@ template <class S> struct SinkK {
 #pragma clang fp reassociate(on)
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const double xs = S::inertia(K) * sel4(r, dget<N>(x.d, 4 * i), dget<N>(x.d, 4 * i + 1), dget<N>(x.d, 4 * i + 2), dget<N>(x.d, 4 * i + 3));
+      const double xs = S::inertia(K) * HAMK_QUAD_PICK(r, lm, dget<N>(x.d, 4 * i), dget<N>(x.d, 4 * i + 1), dget<N>(x.d, 4 * i + 2), dget<N>(x.d, 4 * i + 3));
 #pragma unroll
       for (int b = 0; b < 4 * i + 4; ++b)
         if (b < N) acc[i][b] += xs * x.d[(b < N) ? b : 0];
@@ -236,6 +281,23 @@ HAMK_DEV void chol(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&
   for (int jb = 0; jb < NR; ++jb) {
     HAMK_PHASE();
     const int J0 = 4 * jb, J1 = (4 * jb + 4 < N) ? 4 * jb + 4 : N;        // this panel's pivots [J0, J1)
+#if HAMK_QUAD_LEFT
+    // LEFT-LOOKING: the panel's four columns receive the updates of ALL finished columns now, K[a][k] -= sum_(j < J0) G[a][j] G[k][j]
+    // (row k of the panel broadcast from its owner: slot jb of lane k % 4) -- every entry of K is read and written ONCE, the
+    // finished columns are only read
+#pragma unroll
+    for (int j = 0; j < J0; ++j) {
+      const double c0 = qbcast<0>(Kp[jb][j]), c1 = qbcast<1>(Kp[jb][j]), c2 = qbcast<2>(Kp[jb][j]), c3 = qbcast<3>(Kp[jb][j]);
+#pragma unroll
+      for (int i = jb; i < NR; ++i) {
+        const double g = Kp[i][j];
+        Kp[i][J0] = fma(-g, c0, Kp[i][J0]);
+        if (J0 + 1 < J1) Kp[i][J0 + 1] = fma(-g, c1, Kp[i][J0 + 1]);
+        if (J0 + 2 < J1) Kp[i][J0 + 2] = fma(-g, c2, Kp[i][J0 + 2]);
+        if (J0 + 3 < J1) Kp[i][J0 + 3] = fma(-g, c3, Kp[i][J0 + 3]);
+      }
+    }
+#endif
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = J0 + jj;
@@ -273,6 +335,10 @@ HAMK_DEV void chol(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&
 #pragma unroll
       for (int i = jb + 1; i < NR; ++i) z[i] = fma(-Kp[i][j], yj, z[i]);
     }
+#if HAMK_QUAD_LEFT
+  }
+  (void)0;
+#else
     // the trailing matrix, one pass: K[a][k] -= sum_jj G[a][J0 + jj] G[k][J0 + jj], k >= J1
 #pragma unroll
     for (int k = J1; k < N; ++k) {
@@ -297,6 +363,7 @@ HAMK_DEV void chol(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&
       }
     }
   }
+#endif
   if (!ok) st |= ST_SINGULAR;                            // every inertia positive (HAMK_INSTANTIATE_QUAD asserts it): a non-positive pivot IS singular
 }
 
@@ -317,11 +384,14 @@ HAMK_DEV void solve_back(int r, const double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4
     for (int rr = 3; rr >= 0; --rr) {
       const int a = 4 * i + rr;
       if (a >= N) continue;
-      const double va = fma(z[i], Kp[i][a], -qsum(s[a])) * Kp[i][a];   // meaningful in lane rr, whose Kp[i][a] is 1 / G_aa
-      if (r == rr) vi = va;
+      // (meaningful in lane rr, whose Kp[i][a] is 1 / G_aa: zero elsewhere -- ONE select per row; the other lanes' factors below
+      // are finite entries of the same block, and the lane's own v is the sum of its one non-zero)
+      const double full = fma(z[i], Kp[i][a], -qsum(s[a])) * Kp[i][a];     // (the quad reduction is executed by all four lanes)
+      const double va = (r == rr) ? full : 0.0;
+      vi += va;
       // row a's entries inside the diagonal block feed the rows of the same slot still to come
 #pragma unroll
-      for (int a2 = 4 * i; a2 < a; ++a2) s[a2] = fma((r == rr) ? Kp[i][a2] : 0.0, va, s[a2]);
+      for (int a2 = 4 * i; a2 < a; ++a2) s[a2] = fma(Kp[i][a2], va, s[a2]);
     }
     v[i] = vi;
 #pragma unroll
