@@ -14,14 +14,15 @@
 // sparse: a few hundred instructions), and only the storage and factorisation of K are shared -- row a of K lives in
 // lane a % 4 (register slot a / 4), 144 doubles per lane at n = 32 -- with the pivot column exchanged by DPP
 // quad_perm broadcasts: no LDS in the factorisation at all, no dependent memory round trips, pure VALU.
-//   per lane and right-hand side at n = 32 (counted from the code object, docs/NOTEBOOK.md section 2.7):
-//     sincos of the lane's 8 angles + exchange      ~0.3 k instructions
-//     sweep 1 + the lane's rows of K                ~1 k
-//     LDL^T (1.7 k FMAs + 1 k DPP moves + 32 rcp)   ~3 k
-//     back substitution                             ~0.5 k
-//     reverse sweep for dT/dq (redundant x 4)       ~1 k
-//   = ~6 k per lane for 16 trajectories per wavefront (~370 per trajectory) against ~3.4 k per wavefront for 2
-//   trajectories (~1700 per trajectory) of the wave-cooperative kernels.
+//   per lane and right-hand side at n = 32 (one stage of the RK4 loop, counted from the code object: 6.5 k instructions):
+//     sincos of the lane's 8 angles + sweep 1 + dU/dq      ~0.6 k
+//     the lane's rows of K (re-associated: count x product)  ~0.9 k
+//     Cholesky (2.1 k fp64 + 1.1 k DPP moves + 32 rsqrt)   ~3.5 k
+//     back substitution                                    ~0.7 k
+//     reverse sweep for dT/dq (redundant x 4) + the stage   ~0.9 k
+//   for 16 trajectories per wavefront (~400 per trajectory) against ~3.4 k per wavefront for 2 trajectories (~1700 per
+//   trajectory) of the wave-cooperative kernels.  Half of it is fp64 arithmetic; the rest is what the mapping costs: 1.2 k DPP
+//   moves, 0.7 k v_accvgpr moves (K alone is 288 of the 256 architectural VGPRs), 0.3 k selects.
 // LDS holds only what the four lanes share of the state: q, qd and the sincos pairs of the trajectory, [row][64
 // trajectories of the block] -- 64 KiB per 256-thread block at n = 32 -- read with immediate offsets from one base.
 //
@@ -407,13 +408,13 @@ template <class S, bool LUT> struct Trig {
   static constexpr int mode1 = shared ? TRIG_REUSE : (LUT ? TRIG_LUT : TRIG_FULL);
 };
 
-// One factorisation ships: K assembled whole by ONE sweep, LDL^T right-looking in rank-4 panels (ldlt above) -- the fewest
-// instructions (8.4 k per lane and right-hand side at n = 32), at the price of 160 spilled registers (~50 scratch instructions
-// per right-hand side: K + the sweep's working set + a panel's multipliers exceed the 512 registers).  The alternative built
-// and measured in round 3 -- left-looking Cholesky with K assembled panel by panel by eight sweeps: no scratch in the
-// stepping loop, HBM traffic 1.5 x the state, but 9.5 k instructions -- lost on the same box, back to back
-// (profiles/r03_quad_ab.jsonl: chain32 2.51e8 vs 2.15e8 steps/s, chain24 4.86e8 vs 3.85e8, chain16 at B = 16 384 9.0e8 vs
-// 7.2e8: the instruction count decides, not the scratch traffic) and was removed in round 4 (git history: 70845bd).
+// One factorisation ships: K assembled whole by ONE sweep, Cholesky in place, left-looking in panels of four pivots (chol above).
+// Its history, each step measured or counted (docs/NOTEBOOK.md): round 3 shipped LDL^T right-looking in rank-4 panels (8.4 k
+// instructions per lane and right-hand side at n = 32, 160 spilled registers) after a left-looking Cholesky with K assembled
+// panel by panel by eight sweeps had lost to it (no scratch, but 9.5 k instructions: profiles/r03_quad_ab.jsonl, the instruction
+// count decides); round 4 kept the one sweep and took the rest of that variant -- Cholesky, so that an open panel exists once
+// (not as L and as d L), and the left-looking order, so that finished columns are only read: 6.5 k instructions, no scratch in
+// the stepping loop.  -DHAMK_QUAD_LEFT=0 builds the right-looking order of the same in-place Cholesky (the A/B of round 4).
 
 // q of the quad's trajectory to LDS and, when every sincos site of f takes an input as operand, the pairs of the lane's
 // own coordinates with it (each lane evaluates its n/4 angles once; all sweeps of the evaluation read them).
