@@ -682,6 +682,15 @@ def test_quad_kernels_on_host_match_oracle(emulate_quad, oracle_lib, name, B):
         check_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=min(B, 6), steps=2, tol=1e-10)
 
 
+@pytest.mark.parametrize("name,B", [("chain32", 5), ("chain18", 3), ("threeBodyPolar", 4)])
+def test_quad_right_looking_order_on_host(emulate_quad, oracle_lib, name, B):
+    """-DHAMK_QUAD_LEFT=0 (the A/B build of round 4): the same in-place Cholesky with the trailing matrix updated panel by
+    panel instead of each panel collecting the finished columns -- same results to roundoff."""
+    spec = E.get(name)
+    L = emulate_quad(spec, defines=("HAMK_QUAD_LEFT 0",))
+    check_quad_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=B)
+
+
 def test_quad_flags_a_singular_mass_matrix(emulate_quad, oracle_lib):
     """twoBody at r = 0: K = diag(mu, mu r^2) has a zero pivot -> HAMK_ST_SINGULAR for that trajectory only."""
     spec = E.get("twoBody")
