@@ -274,15 +274,49 @@ HAMK_DEV double frsqrt(double d) {
 // and a pass of selects per panel to put L in place afterwards.  1 / sqrt costs what 1 / d did.
 // The code is the same for the four lanes: slot i is updated over columns up to 4 i + 3 whichever row of the slot the lane
 // owns; the entries beyond the lane's diagonal are the symmetric ones and never read.
+// the four columns of panel `pb` receive the updates of the finished columns [ja, je): K[a][k] -= sum_j G[a][j] G[k][j], row k of the
+// panel broadcast from its owner (slot pb of lane k % 4)
+template <class S, int pb, int ja, int je>
+HAMK_DEV void chol_update(double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4]) {
+  constexpr int N = S::N, NR = Geo<N>::NR, T0 = 4 * pb, T1 = (T0 + 4 < N) ? T0 + 4 : N;
+#pragma unroll
+  for (int j = ja; j < je; ++j) {
+    const double c0 = qbcast<0>(Kp[pb][j]), c1 = qbcast<1>(Kp[pb][j]), c2 = qbcast<2>(Kp[pb][j]), c3 = qbcast<3>(Kp[pb][j]);
+#pragma unroll
+    for (int i = pb; i < NR; ++i) {
+      const double g = Kp[i][j];
+      Kp[i][T0] = fma(-g, c0, Kp[i][T0]);
+      if (T0 + 1 < T1) Kp[i][T0 + 1] = fma(-g, c1, Kp[i][T0 + 1]);
+      if (T0 + 2 < T1) Kp[i][T0 + 2] = fma(-g, c2, Kp[i][T0 + 2]);
+      if (T0 + 3 < T1) Kp[i][T0 + 3] = fma(-g, c3, Kp[i][T0 + 3]);
+    }
+  }
+}
+template <class S, int jb>
+HAMK_DEV void chol_panel(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], bool& ok);
+template <class S, int jb>
+HAMK_DEV void chol_panels(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], bool& ok) {
+  if constexpr (jb < Geo<S::N>::NR) { chol_panel<S, jb>(r, Kp, z, ok); chol_panels<S, jb + 1>(r, Kp, z, ok); }
+}
+
 template <class S>
 HAMK_DEV void chol(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], int& st) {
   constexpr int N = S::N, NR = Geo<N>::NR;
   bool ok = true;
+#if HAMK_QUAD_LEFT == 2
+  // LEFT-LOOKING WITH LOOK-AHEAD: a panel's four pivots are one serial chain (broadcast d, 1 / sqrt, scale, broadcast, update the
+  // next diagonal entry ...) and a wavefront alone on its SIMD has nothing to put into that chain's latencies -- except the NEXT
+  // panel's updates from the columns finished before this panel, which depend on nothing the chain produces.  Panel jb + 1
+  // therefore collects those (a quarter after each pivot of panel jb) and, when its own turn comes, only the four columns of panel jb.
+  chol_panels<S, 0>(r, Kp, z, ok);
+  if (!ok) st |= ST_SINGULAR;
+  return;
+#endif
 #pragma unroll
   for (int jb = 0; jb < NR; ++jb) {
     HAMK_PHASE();
     const int J0 = 4 * jb, J1 = (4 * jb + 4 < N) ? 4 * jb + 4 : N;        // this panel's pivots [J0, J1)
-#if HAMK_QUAD_LEFT
+#if HAMK_QUAD_LEFT == 1
     // LEFT-LOOKING: the panel's four columns receive the updates of ALL finished columns now, K[a][k] -= sum_(j < J0) G[a][j] G[k][j]
     // (row k of the panel broadcast from its owner: slot jb of lane k % 4) -- every entry of K is read and written ONCE, the
     // finished columns are only read
@@ -366,6 +400,57 @@ HAMK_DEV void chol(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&
   }
 #endif
   if (!ok) st |= ST_SINGULAR;                            // every inertia positive (HAMK_INSTANTIATE_QUAD asserts it): a non-positive pivot IS singular
+}
+
+template <class S, int jb>
+HAMK_DEV void chol_panel(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], bool& ok) {
+  constexpr int N = S::N, NR = Geo<N>::NR;
+  constexpr int J0 = 4 * jb, J1 = (4 * jb + 4 < N) ? 4 * jb + 4 : N;
+  HAMK_PHASE();
+  if constexpr (jb > 0) chol_update<S, jb, J0 - 4, J0>(Kp);       // what the look-ahead could not know: the columns of panel jb - 1
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int j = J0 + jj;
+    if (j < J1) {
+      double d, wj;
+      switch (jj) {
+        case 0: d = qbcast<0>(Kp[jb][j]); wj = qbcast<0>(z[jb]); break;
+        case 1: d = qbcast<1>(Kp[jb][j]); wj = qbcast<1>(z[jb]); break;
+        case 2: d = qbcast<2>(Kp[jb][j]); wj = qbcast<2>(z[jb]); break;
+        default: d = qbcast<3>(Kp[jb][j]); wj = qbcast<3>(z[jb]); break;
+      }
+      ok = ok && (d > 0.0);
+      const double rs = frsqrt(d);
+      const double yj = wj * rs;
+#pragma unroll
+      for (int i = jb + 1; i < NR; ++i) Kp[i][j] *= rs;
+      const double below = Kp[jb][j] * rs;
+      Kp[jb][j] = (r > jj) ? below : ((r == jj) ? rs : Kp[jb][j]);
+      const double lm = (r > jj) ? below : 0.0;
+#pragma unroll
+      for (int k = j + 1; k < J1; ++k) {
+        double c;
+        switch (k & 3) {
+          case 1: c = qbcast<1>(Kp[jb][j]); break;
+          case 2: c = qbcast<2>(Kp[jb][j]); break;
+          default: c = qbcast<3>(Kp[jb][j]); break;
+        }
+        Kp[jb][k] = fma(-lm, c, Kp[jb][k]);
+#pragma unroll
+        for (int i = jb + 1; i < NR; ++i) Kp[i][k] = fma(-Kp[i][j], c, Kp[i][k]);
+      }
+      z[jb] = fma(-lm, yj, z[jb]);
+#pragma unroll
+      for (int i = jb + 1; i < NR; ++i) z[i] = fma(-Kp[i][j], yj, z[i]);
+    }
+    // look-ahead: a quarter of the finished columns [0, J0) into panel jb + 1
+    if constexpr (jb + 1 < NR && jb > 0) {
+      if (jj == 0) chol_update<S, jb + 1, 0 * jb, 1 * jb>(Kp);
+      else if (jj == 1) chol_update<S, jb + 1, 1 * jb, 2 * jb>(Kp);
+      else if (jj == 2) chol_update<S, jb + 1, 2 * jb, 3 * jb>(Kp);
+      else chol_update<S, jb + 1, 3 * jb, 4 * jb>(Kp);
+    }
+  }
 }
 
 // G y = w is done (z holds w, y_a = w_a / G_aa); G^T v = y here; returns the lane's v_(4 i + r).  Row-oriented: G[k][a] is in
