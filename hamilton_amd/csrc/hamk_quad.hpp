@@ -186,6 +186,59 @@ template <class S> struct TrigLdsQ {
 template <class S> HAMK_DEV TrigLdsQ<S> reverse_trig(const TrigLdsQ<S>& t) {
   TrigLdsQ<S> u = t; u.s.base = relaunder(t.s.base); u.c.base = relaunder(t.c.base); return u;
 }
+// The same rows read in ONE BURST into registers (HAMK_QUAD_BURST).  A wavefront alone on its SIMD pays every LDS round trip
+// it waits for, and left to itself the compiler issues each ds_read a few instructions before its first use (it schedules for
+// register pressure): the sweeps then stop ~50 (first sweep) + ~100 (reverse sweep) times per right-hand side for ~100 cycles
+// -- a quarter of the kernel's time by PMC (SQ_WAIT_ANY).  Loading the n sincos pairs and the n velocities together, behind a
+// scheduling fence, pays ONE round trip per sweep half; the registers are there (K is not yet assembled / already dead).
+#ifndef HAMK_QUAD_BURST
+#define HAMK_QUAD_BURST 1
+#endif
+HAMK_DEV void burst_fence() {
+#ifndef HAMK_HOST_EMULATION
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+template <class S> struct TrigRegsQ {
+  static constexpr int NT = (S::NTRIG_F > 0) ? S::NTRIG_F : 1;
+  double s[NT], c[NT];
+  const double* sb; const double* cb;
+  double* ax; double* as; double* ac;       // unused (TRIG_REUSE never touches them)
+  HAMK_DEV void load(const double* sbase, const double* cbase) {
+    sb = sbase; cb = cbase; ax = as = ac = nullptr;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) { s[k] = sbase[S::trig_input(k) * 64]; c[k] = cbase[S::trig_input(k) * 64]; }
+    burst_fence();
+  }
+};
+#ifndef HAMK_QUAD_RELOAD
+#define HAMK_QUAD_RELOAD 1      /* the reverse pass loads q', sincos again (0: keeps the forward pass's copies alive) */
+#endif
+#if HAMK_QUAD_RELOAD
+template <class S> HAMK_DEV TrigRegsQ<S> reverse_trig(const TrigRegsQ<S>& t) { TrigRegsQ<S> u; u.load(relaunder(t.sb), relaunder(t.cb)); return u; }
+#else
+template <class S> HAMK_DEV const TrigRegsQ<S>& reverse_trig(const TrigRegsQ<S>& t) { return t; }
+#endif
+template <int N> struct VecRegsQ {
+  double x[N];
+  const double* b;
+  HAMK_DEV void load(const double* base) {
+    b = base;
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] = base[j * 64];
+    burst_fence();
+  }
+  HAMK_DEV double operator[](int j) const { return x[j]; }
+  HAMK_DEV double at(int j) const { return x[j]; }
+};
+#if HAMK_QUAD_RELOAD
+template <int N> HAMK_DEV VecRegsQ<N> reverse_vec(const VecRegsQ<N>& v) { VecRegsQ<N> u; u.load(relaunder(v.b)); return u; }
+#else
+template <int N> HAMK_DEV const VecRegsQ<N>& reverse_vec(const VecRegsQ<N>& v) { return v; }
+#endif
+// (what velocity() does between staging the inputs and the first sweep)
+template <class S, class TC> HAMK_DEV void trig_fill(TC&, const double*, const double*) {}
+template <class S> HAMK_DEV void trig_fill(TrigRegsQ<S>& t, const double* sb, const double* cb) { t.load(sb, cb); }
 
 template <class S> struct Ctx {
   static constexpr int N = S::N, NR = Geo<N>::NR, NP4 = Geo<N>::NP4;
@@ -542,6 +595,7 @@ HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const
   constexpr int N = S::N, NR = Geo<N>::NR;
   const int r = c.r;
   stage_inputs<S, LUT>(c, qi);
+  trig_fill<S>(tc, c.sq(), c.cq());
   SinkK<S> sink;
   sink.init(r);
   InJet1<N> in{c.q()};
@@ -574,6 +628,20 @@ HAMK_DEV void ham_eqs(const Ctx<S>& c0, const double (&qi)[Geo<S::N>::NR], const
   // dT/dq = -d/dq [sum_k m_k (J qd)_k (D_qd x_k)] with (J qd)_k held fixed: the generated reverse sweep, per trajectory,
   // every lane of the quad (compile-time sparsity; the cooperative alternative is dense in every direction)
   if constexpr (Trig<S, LUT>::shared) {
+#if HAMK_QUAD_BURST
+    {
+      TrigRegsQ<S> tr;                                    // (filled by velocity() once the inputs are staged)
+      velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tr);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) c.v()[(4 * i + r) * 64] = vi[i];
+    HAMK_QUAD_SYNC();
+    const Ctx<S> c2 = c.launder();
+    LdsVec q{c2.q()};
+    VecRegsQ<N> v; v.load(c2.v());
+    TrigRegsQ<S> t2; t2.load(c2.sq(), c2.cq());
+    S::dT_reverse(q, v, t2, dT);
+#else
     TrigLdsQ<S> tl = c.trig();
     velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tl);
 #pragma unroll
@@ -583,6 +651,7 @@ HAMK_DEV void ham_eqs(const Ctx<S>& c0, const double (&qi)[Geo<S::N>::NR], const
     LdsVec q{c2.q()}, v{c2.v()};
     TrigLdsQ<S> t2 = c2.trig();
     S::dT_reverse(q, v, t2, dT);
+#endif
   } else {
     TrigCache<S::NTRIG_F> tc;
     velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tc);
@@ -608,7 +677,11 @@ HAMK_DEV void velocity_only(const Ctx<S>& c0, const double (&qi)[Geo<S::N>::NR],
   constexpr int NR = Geo<S::N>::NR;
   const Ctx<S> c = c0.launder();
   double gUi[NR];
+#if HAMK_QUAD_BURST
+  if constexpr (Trig<S, LUT>::shared) { TrigRegsQ<S> tr; velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tr); }
+#else
   if constexpr (Trig<S, LUT>::shared) { TrigLdsQ<S> tl = c.trig(); velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tl); }
+#endif
   else { TrigCache<S::NTRIG_F> tc; velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tc); }
 }
 
