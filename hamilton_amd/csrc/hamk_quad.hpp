@@ -145,9 +145,11 @@ struct LdsVec {
   HAMK_DEV double operator[](int j) const { return p[j * 64]; }
   HAMK_DEV double at(int j) const { return p[j * 64]; }
 };
-// a second look at the same row through a pointer the compiler cannot connect with the first: the reverse pass of
+// a second look at the same row through a pointer the compiler cannot connect with the first: with it the reverse pass of
 // S::dT_reverse LOADS q, v and the sincos pairs again (one ds_read2st64_b64 per two values) instead of keeping 3 n doubles
-// from its forward pass alive in accumulation registers (four v_accvgpr moves per value)
+// from its forward pass alive in accumulation registers (four v_accvgpr moves per value).  Fewer instructions -- and slower on
+// the hardware (HAMK_QUAD_RELOAD, off: chain32 2.82e8 vs 2.89e8, chain24 4.97e8 vs 5.48e8 steps/s, profiles/r04h_ab.jsonl): a
+// wavefront alone on its SIMD pays the extra LDS round trip in full and the moves at one issue slot each.
 HAMK_DEV const double* relaunder(const double* p) {
 #ifndef HAMK_HOST_EMULATION
   // (the 32-bit LDS offset is what passes through the opaque statement: a laundered generic pointer would be read with flat loads)
@@ -212,7 +214,7 @@ template <class S> struct TrigRegsQ {
   }
 };
 #ifndef HAMK_QUAD_RELOAD
-#define HAMK_QUAD_RELOAD 1      /* the reverse pass loads q', sincos again (0: keeps the forward pass's copies alive) */
+#define HAMK_QUAD_RELOAD 0      /* 1: the reverse pass loads q', sincos a second time (fewer accumulation-register moves, one more LDS round trip: measured slower) */
 #endif
 #if HAMK_QUAD_RELOAD
 template <class S> HAMK_DEV TrigRegsQ<S> reverse_trig(const TrigRegsQ<S>& t) { TrigRegsQ<S> u; u.load(relaunder(t.sb), relaunder(t.cb)); return u; }
@@ -565,12 +567,40 @@ HAMK_DEV void stage_inputs(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR]) {
   for (int i = 0; i < NR; ++i) c.q()[(4 * i + r) * 64] = qi[i];
   if constexpr (Trig<S, LUT>::shared) {
     bool far = false;
+    if constexpr (LUT) {
+      // the lane's table pairs in one burst (hamk::sincos_lut_batch: reductions, then every gather, then the polynomials)
+      const LutLiterals kc;
+      double rr[NR], sa[NR], ca[NR];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      double sv, cv;
-      if constexpr (LUT) sincos_lut_fast(qi[i], sv, cv, LutLiterals()); else sincos_f64_fast(qi[i], sv, cv);
-      c.sq()[(4 * i + r) * 64] = sv; c.cq()[(4 * i + r) * 64] = cv;
-      far = far || !(fabs(qi[i]) < 1.6e6);
+      for (int i = 0; i < NR; ++i) {
+        const double kk = rint(qi[i] * kc.inv_step);
+        double t = fma(-kk, kc.w0, qi[i]);
+        t = fma(-kk, kc.w1, t);
+        rr[i] = fma(-kk, kc.w2, t);
+        const int idx = ((int)kk) & (HAMK_LUT_N - 1);
+        sa[i] = HAMK_LUT[2 * idx]; ca[i] = HAMK_LUT[2 * idx + 1];
+      }
+      burst_fence();
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const double z = rr[i] * rr[i];
+        const double ps = fma(kc.s5, z, kc.s3);
+        const double sd = fma(rr[i] * z, ps, rr[i]);
+        double pc = fma(kc.c6, z, kc.c4);
+        pc = fma(pc, z, -0.5);
+        const double cm1 = z * pc;
+        c.sq()[(4 * i + r) * 64] = sa[i] + fma(sa[i], cm1, ca[i] * sd);
+        c.cq()[(4 * i + r) * 64] = ca[i] + fma(ca[i], cm1, -(sa[i] * sd));
+        far = far || !(fabs(qi[i]) < 1.6e6);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        double sv, cv;
+        sincos_f64_fast(qi[i], sv, cv);
+        c.sq()[(4 * i + r) * 64] = sv; c.cq()[(4 * i + r) * 64] = cv;
+        far = far || !(fabs(qi[i]) < 1.6e6);
+      }
     }
 #ifndef HAMK_PROBE_NO_SLOWPATH
     // huge, NaN, Inf: the library path -- ONE copy for the lane's angles (a rolled loop over what is already in LDS;
