@@ -24,5 +24,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCL
 # LDS and matrix-core activity, each group in its own pass (a counter this build of rocprofv3 does not know costs only its group)
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_lds -o $TAG -- $B --no-isa --steps 3 --warmup 1 > $OUT/pmc_lds.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_mfma -o $TAG -- $B --no-isa --steps 3 --warmup 1 > $OUT/pmc_mfma.log 2>&1
+# where a wavefront's cycles go: SQ_WAVE_CYCLES = SQ_ACTIVE_INST_ANY + SQ_WAIT_ANY (parked at s_waitcnt / barrier) + SQ_WAIT_INST_ANY (issue stalls)
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/pmc_wait -o $TAG -- $B --no-isa --steps 3 --warmup 1 > $OUT/pmc_wait.log 2>&1
 grep -h '"metric"' $OUT/stats.log | tail -1 > $OUT/bench_under_profiler.json
 ls $OUT/*

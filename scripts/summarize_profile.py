@@ -25,7 +25,7 @@ if os.path.exists(bj) and os.path.getsize(bj):
     summary["rocprof_vs_hip_events"] = float(stats[KERNEL]["AverageNs"]) * 1e-6 / bench["roofline"]["kernel_ms"]
 
 pmc = {}
-for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds", "pmc_mfma", "pmc_vmem", "pmc_ifetch"):
+for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds", "pmc_mfma", "pmc_vmem", "pmc_ifetch", "pmc_wait"):
     path = os.path.join(src, name, f"{tag}_counter_collection.csv")
     if not os.path.exists(path):
         continue
