@@ -504,49 +504,6 @@ HAMK_DEV void sincos_lut(double x, double& s, double& c) { sincos_lut(x, s, c, L
 template <class TC> HAMK_DEV auto lut_consts(const TC& tc, int) -> decltype(tc.kc) { return tc.kc; }
 template <class TC> HAMK_DEV LutLiterals lut_consts(const TC&, long) { return LutLiterals(); }
 
-// ALL sincos sites of a right-hand side through the table at once (sites whose operand is an input: the angles of a chain).
-// One site at a time -- reduce, gather the table pair, polynomial -- the compiler issues each 16-byte gather a few
-// instructions before its first use (it schedules for register pressure), and a wavefront that is alone on its SIMD -- every
-// stepping kernel from n = 8 -- then stops once per site for a full LDS round trip: 8 stops per 730-instruction stage at n = 8
-// (PMC, chain8: SQ_WAIT_ANY 31 % of the wavefront's cycles).  Here the reductions come first, the gathers are issued together
-// behind a scheduling fence, the polynomials follow: one round trip per right-hand side.  Same arithmetic, same bits.
-#ifndef HAMK_LUT_BURST_MIN
-#define HAMK_LUT_BURST_MIN 5        /* sites from which a right-hand side takes its sincos pairs in one burst (generated) */
-#endif
-template <class S, class TC> HAMK_DEV void sincos_lut_batch(const double (&q)[S::N], TC& tc) {
-  constexpr int NT = (S::NTRIG_F > 0) ? S::NTRIG_F : 1;
-  const auto kc = lut_consts(tc, 0);
-  double r[NT], sa[NT], ca[NT];
-#pragma unroll
-  for (int k = 0; k < NT; ++k) {
-    const double x = q[S::trig_input(k)];
-    const double kk = rint(x * kc.inv_step);
-    double t = fma(-kk, kc.w0, x);
-    t = fma(-kk, kc.w1, t);
-    r[k] = fma(-kk, kc.w2, t);
-    const int idx = ((int)kk) & (HAMK_LUT_N - 1);
-    sa[k] = HAMK_LUT[2 * idx]; ca[k] = HAMK_LUT[2 * idx + 1];
-  }
-#ifndef HAMK_HOST_EMULATION
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-  for (int k = 0; k < NT; ++k) {
-    const double z = r[k] * r[k];
-    const double ps = fma(kc.s5, z, kc.s3);
-    const double sd = fma(r[k] * z, ps, r[k]);                     // sin r
-    double pc = fma(kc.c6, z, kc.c4);
-    pc = fma(pc, z, -0.5);
-    const double cm1 = z * pc;                                     // cos r - 1
-    tc.s[k] = sa[k] + fma(sa[k], cm1, ca[k] * sd);
-    tc.c[k] = ca[k] + fma(ca[k], cm1, -(sa[k] * sd));
-#ifndef HAMK_PROBE_NO_SLOWPATH
-    const double x = q[S::trig_input(k)];
-    if (!(fabs(x) < kc.lim)) { tc.s[k] = ::sin(x); tc.c[k] = ::cos(x); }        // huge, NaN, Inf: library path
-#endif
-  }
-}
-
 // sin and cos of one argument always come as a pair (codegen fuses the tape's
 // SIN/COS of a shared operand): one fp64 sincos feeds value, gradient and Hessian.
 // The primal pair lives in a TrigCache slot, filled according to the sweep's TRIG mode:
@@ -1068,12 +1025,7 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
   } else {
     Jet1<N> qj[N], xj[M];
     seed1<S>(q, qj);
-    if constexpr (TRIG == TRIG_LUT && S::TRIG_ALL_INPUTS && S::NTRIG_F >= HAMK_LUT_BURST_MIN) {
-      sincos_lut_batch<S>(q, tc);                          // every site's table pair in one burst (see sincos_lut_batch)
-      S::template coords<Jet1<N>, TRIG_REUSE>(qj, xj, tc);
-    } else {
-      S::template coords<Jet1<N>, TRIG>(qj, xj, tc);
-    }
+    S::template coords<Jet1<N>, TRIG>(qj, xj, tc);
     mass_matrix<S>(xj, K);
     solve_spd<N, S::INERTIA_POS>(K, p, v, st);
     grad_potential<S>(qj, xj, gU, U, tc);

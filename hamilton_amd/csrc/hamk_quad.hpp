@@ -567,40 +567,12 @@ HAMK_DEV void stage_inputs(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR]) {
   for (int i = 0; i < NR; ++i) c.q()[(4 * i + r) * 64] = qi[i];
   if constexpr (Trig<S, LUT>::shared) {
     bool far = false;
-    if constexpr (LUT) {
-      // the lane's table pairs in one burst (hamk::sincos_lut_batch: reductions, then every gather, then the polynomials)
-      const LutLiterals kc;
-      double rr[NR], sa[NR], ca[NR];
 #pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        const double kk = rint(qi[i] * kc.inv_step);
-        double t = fma(-kk, kc.w0, qi[i]);
-        t = fma(-kk, kc.w1, t);
-        rr[i] = fma(-kk, kc.w2, t);
-        const int idx = ((int)kk) & (HAMK_LUT_N - 1);
-        sa[i] = HAMK_LUT[2 * idx]; ca[i] = HAMK_LUT[2 * idx + 1];
-      }
-      burst_fence();
-#pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        const double z = rr[i] * rr[i];
-        const double ps = fma(kc.s5, z, kc.s3);
-        const double sd = fma(rr[i] * z, ps, rr[i]);
-        double pc = fma(kc.c6, z, kc.c4);
-        pc = fma(pc, z, -0.5);
-        const double cm1 = z * pc;
-        c.sq()[(4 * i + r) * 64] = sa[i] + fma(sa[i], cm1, ca[i] * sd);
-        c.cq()[(4 * i + r) * 64] = ca[i] + fma(ca[i], cm1, -(sa[i] * sd));
-        far = far || !(fabs(qi[i]) < 1.6e6);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        double sv, cv;
-        sincos_f64_fast(qi[i], sv, cv);
-        c.sq()[(4 * i + r) * 64] = sv; c.cq()[(4 * i + r) * 64] = cv;
-        far = far || !(fabs(qi[i]) < 1.6e6);
-      }
+    for (int i = 0; i < NR; ++i) {
+      double sv, cv;
+      if constexpr (LUT) sincos_lut_fast(qi[i], sv, cv, LutLiterals()); else sincos_f64_fast(qi[i], sv, cv);
+      c.sq()[(4 * i + r) * 64] = sv; c.cq()[(4 * i + r) * 64] = cv;
+      far = far || !(fabs(qi[i]) < 1.6e6);
     }
 #ifndef HAMK_PROBE_NO_SLOWPATH
     // huge, NaN, Inf: the library path -- ONE copy for the lane's angles (a rolled loop over what is already in LDS;
