@@ -48,9 +48,6 @@
 #endif
 
 #define HAMK_DEV __device__ __forceinline__
-#ifndef HAMK_RKF_BURST
-#define HAMK_RKF_BURST 1      /* the parked adaptive stepper reads the rows of a stage in bursts behind a scheduling fence (rkf45_body_parked) */
-#endif
 #ifndef HAMK_JET_REASSOC
 #define HAMK_JET_REASSOC 1    /* gradient parts of Jet1 + and - may be re-associated (x + x + ... -> count x: the potential's sum over outputs) */
 #endif
@@ -1502,19 +1499,6 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
 #define HAMK_RKF_LROW(r) (rows + (r) * D * 256 + threadIdx.x)
 #define HAMK_RKF_K(KR, j) ((2 + (KR) < NL) ? HAMK_RKF_LROW(2 + (KR))[(j) * 256] : v[KR][j])      /* k_{2 + KR}[j] */
 #define HAMK_RKF_RECENT(KR, j) (out[j])                  /* a right-hand side's result is used from the registers by the stage that follows it */
-  // components per burst of row loads (see the stage switch): 16 where the rows wait in LDS / scratch at one wavefront per SIMD;
-  // the whole vector, and no fence, where they are registers (n <= 7) or the bursts are switched off
-#if HAMK_RKF_BURST && !HAMK_RKF_ROWS_IN_REGS
-  constexpr int CH = (D < 16) ? D : 16;
-#ifdef HAMK_HOST_EMULATION
-#define HAMK_RKF_FENCE() ((void)0)
-#else
-#define HAMK_RKF_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
-#else
-  constexpr int CH = D;
-#define HAMK_RKF_FENCE() ((void)0)
-#endif
   auto put_k = [&](int kr, const double (&x)[D]) {         // k_{2 + kr}; kr: a run-time value (the stage counter)
     if (NL > 2 && 2 + kr < NL) {
 #pragma unroll
@@ -1595,99 +1579,43 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
 #pragma unroll 1
       for (int sg = 0; sg < 6; ++sg) {
         double yt[D];
-        // The rows a stage combines are read in BURSTS of CH components -- every load of the chunk, a scheduling fence, then the
-        // arithmetic (HAMK_RKF_BURST; the same expressions, the same bits).  Left to itself the compiler issues three or four
-        // loads, waits for them, computes two components and starts over: a wavefront alone on its SIMD sits out an LDS or
-        // scratch round trip per pair of components, ~50 per attempt at n = 8 (PMC: a third of the kernel's cycles parked at
-        // s_waitcnt), and the rows in scratch never have more than a few requests in flight.
         switch (sg) {
           case 0:
 #pragma unroll
-            for (int c0 = 0; c0 < D; c0 += CH) {
-              double a[CH], b[CH];
-#pragma unroll
-              for (int jj = 0; jj < CH; ++jj) if (c0 + jj < D) { a[jj] = py[(c0 + jj) * 256]; b[jj] = pf[(c0 + jj) * 256]; }
-              HAMK_RKF_FENCE();
-#pragma unroll
-              for (int jj = 0; jj < CH; ++jj) if (c0 + jj < D) yt[c0 + jj] = a[jj] + (1.0 / 4.0) * hh * b[jj];
-            }
+            for (int j = 0; j < D; ++j) yt[j] = py[j * 256] + (1.0 / 4.0) * hh * pf[j * 256];
             break;
           case 1:
 #pragma unroll
-            for (int c0 = 0; c0 < D; c0 += CH) {
-              double a[CH], b[CH];
-#pragma unroll
-              for (int jj = 0; jj < CH; ++jj) if (c0 + jj < D) { a[jj] = py[(c0 + jj) * 256]; b[jj] = pf[(c0 + jj) * 256]; }
-              HAMK_RKF_FENCE();
-#pragma unroll
-              for (int jj = 0; jj < CH; ++jj) if (c0 + jj < D) yt[c0 + jj] = a[jj] + hh * ((3.0 / 32.0) * b[jj] + (9.0 / 32.0) * HAMK_RKF_RECENT(0, c0 + jj));
-            }
+            for (int j = 0; j < D; ++j) yt[j] = py[j * 256] + hh * ((3.0 / 32.0) * pf[j * 256] + (9.0 / 32.0) * HAMK_RKF_RECENT(0, j));
             break;
           case 2:
 #pragma unroll
-            for (int c0 = 0; c0 < D; c0 += CH) {
-              double a[CH], b[CH], c[CH];
-#pragma unroll
-              for (int jj = 0; jj < CH; ++jj) if (c0 + jj < D) { a[jj] = py[(c0 + jj) * 256]; b[jj] = pf[(c0 + jj) * 256]; c[jj] = HAMK_RKF_K(0, c0 + jj); }
-              HAMK_RKF_FENCE();
-#pragma unroll
-              for (int jj = 0; jj < CH; ++jj) if (c0 + jj < D)
-                yt[c0 + jj] = a[jj] + hh * ((1932.0 / 2197.0) * b[jj] + (-7200.0 / 2197.0) * c[jj] + (7296.0 / 2197.0) * HAMK_RKF_RECENT(1, c0 + jj));
-            }
+            for (int j = 0; j < D; ++j)
+              yt[j] = py[j * 256] + hh * ((1932.0 / 2197.0) * pf[j * 256] + (-7200.0 / 2197.0) * HAMK_RKF_K(0, j) + (7296.0 / 2197.0) * HAMK_RKF_RECENT(1, j));
             break;
           case 3:
 #pragma unroll
-            for (int c0 = 0; c0 < D; c0 += CH) {
-              double a[CH], b[CH], c[CH], d[CH];
-#pragma unroll
-              for (int jj = 0; jj < CH; ++jj) if (c0 + jj < D) {
-                a[jj] = py[(c0 + jj) * 256]; b[jj] = pf[(c0 + jj) * 256]; c[jj] = HAMK_RKF_K(0, c0 + jj); d[jj] = HAMK_RKF_K(1, c0 + jj);
-              }
-              HAMK_RKF_FENCE();
-#pragma unroll
-              for (int jj = 0; jj < CH; ++jj) if (c0 + jj < D)
-                yt[c0 + jj] = a[jj] + hh * ((8341.0 / 4104.0) * b[jj] + (-32832.0 / 4104.0) * c[jj] +
-                                            (29440.0 / 4104.0) * d[jj] + (-845.0 / 4104.0) * HAMK_RKF_RECENT(2, c0 + jj));
-            }
+            for (int j = 0; j < D; ++j)
+              yt[j] = py[j * 256] + hh * ((8341.0 / 4104.0) * pf[j * 256] + (-32832.0 / 4104.0) * HAMK_RKF_K(0, j) +
+                                          (29440.0 / 4104.0) * HAMK_RKF_K(1, j) + (-845.0 / 4104.0) * HAMK_RKF_RECENT(2, j));
             break;
           case 4:
 #pragma unroll
-            for (int c0 = 0; c0 < D; c0 += CH) {
-              double a[CH], b[CH], c[CH], d[CH], e[CH];
-#pragma unroll
-              for (int jj = 0; jj < CH; ++jj) if (c0 + jj < D) {
-                a[jj] = py[(c0 + jj) * 256]; b[jj] = pf[(c0 + jj) * 256]; c[jj] = HAMK_RKF_K(0, c0 + jj); d[jj] = HAMK_RKF_K(1, c0 + jj);
-                e[jj] = HAMK_RKF_K(2, c0 + jj);
-              }
-              HAMK_RKF_FENCE();
-#pragma unroll
-              for (int jj = 0; jj < CH; ++jj) if (c0 + jj < D)
-                yt[c0 + jj] = a[jj] + hh * ((-6080.0 / 20520.0) * b[jj] + (41040.0 / 20520.0) * c[jj] +
-                                            (-28352.0 / 20520.0) * d[jj] + (9295.0 / 20520.0) * e[jj] +
-                                            (-5643.0 / 20520.0) * HAMK_RKF_RECENT(3, c0 + jj));
-            }
+            for (int j = 0; j < D; ++j)
+              yt[j] = py[j * 256] + hh * ((-6080.0 / 20520.0) * pf[j * 256] + (41040.0 / 20520.0) * HAMK_RKF_K(0, j) +
+                                          (-28352.0 / 20520.0) * HAMK_RKF_K(1, j) + (9295.0 / 20520.0) * HAMK_RKF_K(2, j) +
+                                          (-5643.0 / 20520.0) * HAMK_RKF_RECENT(3, j));
             break;
           default: {
             double ye[D];
 #pragma unroll
-            for (int c0 = 0; c0 < D; c0 += CH) {
-              double a[CH], b[CH], c[CH], d[CH], e[CH];
-#pragma unroll
-              for (int jj = 0; jj < CH; ++jj) if (c0 + jj < D) {
-                a[jj] = py[(c0 + jj) * 256]; b[jj] = pf[(c0 + jj) * 256]; c[jj] = HAMK_RKF_K(1, c0 + jj); d[jj] = HAMK_RKF_K(2, c0 + jj);
-                e[jj] = HAMK_RKF_K(3, c0 + jj);
-              }
-              HAMK_RKF_FENCE();
-#pragma unroll
-              for (int jj = 0; jj < CH; ++jj) if (c0 + jj < D) {
-                const int j = c0 + jj;
-                const double f0 = b[jj], k3 = c[jj], k4 = d[jj], k5 = e[jj], k6 = HAMK_RKF_RECENT(4, j);
-                const double di = (902880.0 / 7618050.0) * f0 + (3953664.0 / 7618050.0) * k3 +
-                                  (3855735.0 / 7618050.0) * k4 + (-1371249.0 / 7618050.0) * k5 +
-                                  (277020.0 / 7618050.0) * k6;
-                yt[j] = a[jj] + hh * di;
-                ye[j] = hh * ((1.0 / 360.0) * f0 + (-128.0 / 4275.0) * k3 + (-2197.0 / 75240.0) * k4 + (1.0 / 50.0) * k5 + (2.0 / 55.0) * k6);
-              }
+            for (int j = 0; j < D; ++j) {
+              const double f0 = pf[j * 256], k3 = HAMK_RKF_K(1, j), k4 = HAMK_RKF_K(2, j), k5 = HAMK_RKF_K(3, j), k6 = HAMK_RKF_RECENT(4, j);
+              const double di = (902880.0 / 7618050.0) * f0 + (3953664.0 / 7618050.0) * k3 +
+                                (3855735.0 / 7618050.0) * k4 + (-1371249.0 / 7618050.0) * k5 +
+                                (277020.0 / 7618050.0) * k6;
+              yt[j] = py[j * 256] + hh * di;
+              ye[j] = hh * ((1.0 / 360.0) * f0 + (-128.0 / 4275.0) * k3 + (-2197.0 / 75240.0) * k4 + (1.0 / 50.0) * k5 + (2.0 / 55.0) * k6);
             }
 #pragma unroll
             for (int j = 0; j < D; ++j) HAMK_RKF_YN(j) = yt[j];
@@ -1710,15 +1638,13 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
         if (sg < 4) put_k(sg, out);                         // k2..k5; k6 and dydt_out are used from the registers and never stored
       }
       // --- cstd.c: std_control_hadjust, ord = 5 ------------------------------
-      double yn[D], ee[D];
+      double yn[D];
       double rmax = 2.2250738585072014e-308;
 #pragma unroll
-      for (int j = 0; j < D; ++j) { yn[j] = HAMK_RKF_YN(j); ee[j] = HAMK_RKF_E(j); }
-      HAMK_RKF_FENCE();
-#pragma unroll
       for (int j = 0; j < D; ++j) {
+        yn[j] = HAMK_RKF_YN(j);
         const double D0 = eps_rel * (fabs(yn[j]) + fabs(hh * out[j])) + eps_abs;
-        const double rr = fabs(ee[j]) / fabs(D0);
+        const double rr = fabs(HAMK_RKF_E(j)) / fabs(D0);
         rmax = (rr > rmax) ? rr : rmax;
       }
       const double tnew = final_step ? ti : t + hh;
@@ -1767,7 +1693,6 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
   if (status) status[i] = st;
   if (nsub) nsub[i] = attempts;
 #undef HAMK_RKF_RECENT
-#undef HAMK_RKF_FENCE
 #undef HAMK_RKF_YN
 #undef HAMK_RKF_E
 #undef HAMK_RKF_K
