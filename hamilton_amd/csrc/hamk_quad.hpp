@@ -46,17 +46,6 @@ template <class S> struct Lds {
   static constexpr int NP4 = Geo<S::N>::NP4;
   static constexpr int Q = 0, V = NP4 * 64, SQ = 2 * NP4 * 64, CQ = 3 * NP4 * 64, GU = 4 * NP4 * 64, TOTAL = 5 * NP4 * 64;
 };
-#ifndef HAMK_QUAD_MSEL
-#define HAMK_QUAD_MSEL 1
-#endif
-#if HAMK_QUAD_MSEL
-#define HAMK_QUAD_PICK(r, lm, a, b, c, d) hamk::quad::msel4(lm, a, b, c, d)
-#else
-#define HAMK_QUAD_PICK(r, lm, a, b, c, d) hamk::quad::sel4(r, a, b, c, d)
-#endif
-#ifndef HAMK_QUAD_LEFT
-#define HAMK_QUAD_LEFT 1
-#endif
 #define HAMK_QUAD_SMEM(S) __shared__ double smem[hamk::quad::Lds<S>::TOTAL]
 
 #ifdef HAMK_HOST_EMULATION
@@ -145,11 +134,13 @@ struct LdsVec {
   HAMK_DEV double operator[](int j) const { return p[j * 64]; }
   HAMK_DEV double at(int j) const { return p[j * 64]; }
 };
-// a second look at the same row through a pointer the compiler cannot connect with the first: with it the reverse pass of
-// S::dT_reverse LOADS q, v and the sincos pairs again (one ds_read2st64_b64 per two values) instead of keeping 3 n doubles
-// from its forward pass alive in accumulation registers (four v_accvgpr moves per value).  Fewer instructions -- and slower on
-// the hardware (HAMK_QUAD_RELOAD, off: chain32 2.82e8 vs 2.89e8, chain24 4.97e8 vs 5.48e8 steps/s, profiles/r04h_ab.jsonl): a
-// wavefront alone on its SIMD pays the extra LDS round trip in full and the moves at one issue slot each.
+// The generated reverse sweep (S::dT_reverse) reads q, v and the sincos pairs through reverse_vec / reverse_trig in its second
+// half.  Where they are LDS rows read in place -- q always, v and the pairs in the kernels whose sites are not inputs -- that is
+// a second look through a pointer the compiler cannot connect with the first (the reverse half LOADS them again instead of
+// keeping them alive in accumulation registers from the forward half); where they were loaded in one burst (TrigRegsQ,
+// VecRegsQ below) the copies are kept: re-loading those too is fewer instructions and was measured slower (chain32 2.82e8 vs
+// 2.89e8, chain24 4.97e8 vs 5.48e8 steps/s, profiles/r04h_ab.jsonl) -- a wavefront alone on its SIMD pays the extra LDS round
+// trip in full and the moves at one issue slot each.
 HAMK_DEV const double* relaunder(const double* p) {
 #ifndef HAMK_HOST_EMULATION
   // (the 32-bit LDS offset is what passes through the opaque statement: a laundered generic pointer would be read with flat loads)
@@ -188,14 +179,13 @@ template <class S> struct TrigLdsQ {
 template <class S> HAMK_DEV TrigLdsQ<S> reverse_trig(const TrigLdsQ<S>& t) {
   TrigLdsQ<S> u = t; u.s.base = relaunder(t.s.base); u.c.base = relaunder(t.c.base); return u;
 }
-// The same rows read in ONE BURST into registers (HAMK_QUAD_BURST).  A wavefront alone on its SIMD pays every LDS round trip
-// it waits for, and left to itself the compiler issues each ds_read a few instructions before its first use (it schedules for
-// register pressure): the sweeps then stop ~50 (first sweep) + ~100 (reverse sweep) times per right-hand side for ~100 cycles
-// -- a quarter of the kernel's time by PMC (SQ_WAIT_ANY).  Loading the n sincos pairs and the n velocities together, behind a
-// scheduling fence, pays ONE round trip per sweep half; the registers are there (K is not yet assembled / already dead).
-#ifndef HAMK_QUAD_BURST
-#define HAMK_QUAD_BURST 1
-#endif
+// The same rows read in ONE BURST into registers.  A wavefront alone on its SIMD pays every LDS round trip it waits for, and
+// left to itself the compiler issues each ds_read a few instructions before its first use (it schedules for register
+// pressure): the sweeps then stop ~50 (first sweep) + ~100 (reverse sweep) times per right-hand side for ~100 cycles -- a
+// quarter of the kernel's time by PMC (SQ_WAIT_ANY).  Loading the n sincos pairs and the n velocities together, behind a
+// scheduling fence, pays ONE round trip per sweep; the registers are there (K is not yet assembled / already dead).  The
+// reverse sweep keeps what it needs of them for its second half (re-loading them there instead is fewer instructions and was
+// measured slower: profiles/r04h_ab.jsonl).  chain32 2.66e8 -> 2.89e8, chain24 4.93e8 -> 5.48e8 steps/s.
 HAMK_DEV void burst_fence() {
 #ifndef HAMK_HOST_EMULATION
   __builtin_amdgcn_sched_barrier(0);
@@ -204,28 +194,18 @@ HAMK_DEV void burst_fence() {
 template <class S> struct TrigRegsQ {
   static constexpr int NT = (S::NTRIG_F > 0) ? S::NTRIG_F : 1;
   double s[NT], c[NT];
-  const double* sb; const double* cb;
   double* ax; double* as; double* ac;       // unused (TRIG_REUSE never touches them)
   HAMK_DEV void load(const double* sbase, const double* cbase) {
-    sb = sbase; cb = cbase; ax = as = ac = nullptr;
+    ax = as = ac = nullptr;
 #pragma unroll
     for (int k = 0; k < NT; ++k) { s[k] = sbase[S::trig_input(k) * 64]; c[k] = cbase[S::trig_input(k) * 64]; }
     burst_fence();
   }
 };
-#ifndef HAMK_QUAD_RELOAD
-#define HAMK_QUAD_RELOAD 0      /* 1: the reverse pass loads q', sincos a second time (fewer accumulation-register moves, one more LDS round trip: measured slower) */
-#endif
-#if HAMK_QUAD_RELOAD
-template <class S> HAMK_DEV TrigRegsQ<S> reverse_trig(const TrigRegsQ<S>& t) { TrigRegsQ<S> u; u.load(relaunder(t.sb), relaunder(t.cb)); return u; }
-#else
-template <class S> HAMK_DEV const TrigRegsQ<S>& reverse_trig(const TrigRegsQ<S>& t) { return t; }
-#endif
+template <class S> HAMK_DEV const TrigRegsQ<S>& reverse_trig(const TrigRegsQ<S>& t) { return t; }      // (kept alive, not re-loaded)
 template <int N> struct VecRegsQ {
   double x[N];
-  const double* b;
   HAMK_DEV void load(const double* base) {
-    b = base;
 #pragma unroll
     for (int j = 0; j < N; ++j) x[j] = base[j * 64];
     burst_fence();
@@ -233,11 +213,7 @@ template <int N> struct VecRegsQ {
   HAMK_DEV double operator[](int j) const { return x[j]; }
   HAMK_DEV double at(int j) const { return x[j]; }
 };
-#if HAMK_QUAD_RELOAD
-template <int N> HAMK_DEV VecRegsQ<N> reverse_vec(const VecRegsQ<N>& v) { VecRegsQ<N> u; u.load(relaunder(v.b)); return u; }
-#else
 template <int N> HAMK_DEV const VecRegsQ<N>& reverse_vec(const VecRegsQ<N>& v) { return v; }
-#endif
 // (what velocity() does between staging the inputs and the first sweep)
 template <class S, class TC> HAMK_DEV void trig_fill(TC&, const double*, const double*) {}
 template <class S> HAMK_DEV void trig_fill(TrigRegsQ<S>& t, const double* sb, const double* cb) { t.load(sb, cb); }
@@ -290,7 +266,7 @@ template <class S> struct SinkK {
 #pragma clang fp reassociate(on)
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const double xs = S::inertia(K) * HAMK_QUAD_PICK(r, lm, dget<N>(x.d, 4 * i), dget<N>(x.d, 4 * i + 1), dget<N>(x.d, 4 * i + 2), dget<N>(x.d, 4 * i + 3));
+      const double xs = S::inertia(K) * msel4(lm, dget<N>(x.d, 4 * i), dget<N>(x.d, 4 * i + 1), dget<N>(x.d, 4 * i + 2), dget<N>(x.d, 4 * i + 3));
 #pragma unroll
       for (int b = 0; b < 4 * i + 4; ++b)
         if (b < N) acc[i][b] += xs * x.d[(b < N) ? b : 0];
@@ -316,65 +292,31 @@ HAMK_DEV double frsqrt(double d) {
 // CHOLESKY K = G G^T of the quad's K in registers, IN PLACE, the forward substitution of one right-hand side riding along.
 // On return: Kp[i][j], j < 4 i + r: G; Kp[i][4 i + r] = 1 / G_aa (a = 4 i + r); z[i] = w_a = p_a - sum_(k < a) G[a][k] y_k with
 // y_k = w_k / G_kk (the owner keeps the UNSCALED w: solve_back divides twice).
-// Pivot j lives in lane j % 4, slot j / 4.  Right-looking in PANELS OF FOUR PIVOTS -- one slot of rows, the quad's own
-// granularity: the four pivots of a panel are eliminated one after the other inside the panel's four columns only
-// (d_j and the three or fewer column entries below it broadcast by DPP, every lane scaling its own rows), and the
-// trailing matrix then receives the panel's rank-4 update in ONE pass -- column k's four panel entries broadcast from
-// their owner (8 DPP moves), then four FMAs per entry.  Same flops and the same DPP traffic as pivot-by-pivot, but
-// every trailing entry is read and written n/4 times instead of n: at n = 32 the lane's 144 doubles of K exceed the
-// 256 architectural VGPRs, the rest lives in AGPRs, and each touch of such an entry costs four v_accvgpr moves.
+// Pivot j lives in lane j % 4, slot j / 4.  LEFT-LOOKING IN PANELS OF FOUR PIVOTS -- one slot of rows, the quad's own granularity:
+// when a panel's turn comes its four columns receive the updates of ALL finished columns, K[a][k] -= sum_(j < J0) G[a][j] G[k][j]
+// (row k of the panel broadcast from its owner, slot jb of lane k % 4: 8 DPP moves per finished column, then four FMAs per row
+// slot), and its four pivots are then eliminated one after the other inside the panel's columns (d_j and the three or fewer
+// column entries below it broadcast by DPP, every lane scaling its own rows).  Every entry of K is read and written ONCE and
+// the finished columns are only read: at n = 32 the lane's 144 doubles of K exceed the 256 architectural VGPRs, the rest lives
+// in AGPRs, and a touch of such an entry costs two v_accvgpr moves each way (right-looking in rank-4 panels, round 3, read and
+// wrote every trailing entry once per panel).
 // Cholesky rather than LDL^T (round 4): with G = L sqrt(D) the update K[a][k] -= G[a][j] G[k][j] multiplies the lane's own
 // entry by the broadcast one -- both the SAME scaled column, stored where it will stay -- whereas LDL^T needs the column
 // twice while a panel is open (L[a][j] and d_j L[k][j]: 32 more doubles per lane at n = 32, all of them AGPR traffic),
 // and a pass of selects per panel to put L in place afterwards.  1 / sqrt costs what 1 / d did.
 // The code is the same for the four lanes: slot i is updated over columns up to 4 i + 3 whichever row of the slot the lane
 // owns; the entries beyond the lane's diagonal are the symmetric ones and never read.
-// the four columns of panel `pb` receive the updates of the finished columns [ja, je): K[a][k] -= sum_j G[a][j] G[k][j], row k of the
-// panel broadcast from its owner (slot pb of lane k % 4)
-template <class S, int pb, int ja, int je>
-HAMK_DEV void chol_update(double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4]) {
-  constexpr int N = S::N, NR = Geo<N>::NR, T0 = 4 * pb, T1 = (T0 + 4 < N) ? T0 + 4 : N;
-#pragma unroll
-  for (int j = ja; j < je; ++j) {
-    const double c0 = qbcast<0>(Kp[pb][j]), c1 = qbcast<1>(Kp[pb][j]), c2 = qbcast<2>(Kp[pb][j]), c3 = qbcast<3>(Kp[pb][j]);
-#pragma unroll
-    for (int i = pb; i < NR; ++i) {
-      const double g = Kp[i][j];
-      Kp[i][T0] = fma(-g, c0, Kp[i][T0]);
-      if (T0 + 1 < T1) Kp[i][T0 + 1] = fma(-g, c1, Kp[i][T0 + 1]);
-      if (T0 + 2 < T1) Kp[i][T0 + 2] = fma(-g, c2, Kp[i][T0 + 2]);
-      if (T0 + 3 < T1) Kp[i][T0 + 3] = fma(-g, c3, Kp[i][T0 + 3]);
-    }
-  }
-}
-template <class S, int jb>
-HAMK_DEV void chol_panel(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], bool& ok);
-template <class S, int jb>
-HAMK_DEV void chol_panels(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], bool& ok) {
-  if constexpr (jb < Geo<S::N>::NR) { chol_panel<S, jb>(r, Kp, z, ok); chol_panels<S, jb + 1>(r, Kp, z, ok); }
-}
-
+// (Measured against this order on one box and not kept, profiles/r04g_ab.jsonl, r04h_ab.jsonl, r04i_ab.jsonl: the right-looking
+// order of the same in-place Cholesky, -1.7 ... -5 %; a look-ahead -- the next panel collecting the finished columns while
+// this panel's pivots are eliminated -- +3 % at n = 32, -1 % at n = 24 and 17.  git history: 4c91209.)
 template <class S>
 HAMK_DEV void chol(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], int& st) {
   constexpr int N = S::N, NR = Geo<N>::NR;
   bool ok = true;
-#if HAMK_QUAD_LEFT == 2
-  // LEFT-LOOKING WITH LOOK-AHEAD: a panel's four pivots are one serial chain (broadcast d, 1 / sqrt, scale, broadcast, update the
-  // next diagonal entry ...) and a wavefront alone on its SIMD has nothing to put into that chain's latencies -- except the NEXT
-  // panel's updates from the columns finished before this panel, which depend on nothing the chain produces.  Panel jb + 1
-  // therefore collects those (a quarter after each pivot of panel jb) and, when its own turn comes, only the four columns of panel jb.
-  chol_panels<S, 0>(r, Kp, z, ok);
-  if (!ok) st |= ST_SINGULAR;
-  return;
-#endif
 #pragma unroll
   for (int jb = 0; jb < NR; ++jb) {
     HAMK_PHASE();
     const int J0 = 4 * jb, J1 = (4 * jb + 4 < N) ? 4 * jb + 4 : N;        // this panel's pivots [J0, J1)
-#if HAMK_QUAD_LEFT == 1
-    // LEFT-LOOKING: the panel's four columns receive the updates of ALL finished columns now, K[a][k] -= sum_(j < J0) G[a][j] G[k][j]
-    // (row k of the panel broadcast from its owner: slot jb of lane k % 4) -- every entry of K is read and written ONCE, the
-    // finished columns are only read
 #pragma unroll
     for (int j = 0; j < J0; ++j) {
       const double c0 = qbcast<0>(Kp[jb][j]), c1 = qbcast<1>(Kp[jb][j]), c2 = qbcast<2>(Kp[jb][j]), c3 = qbcast<3>(Kp[jb][j]);
@@ -387,7 +329,6 @@ HAMK_DEV void chol(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&
         if (J0 + 3 < J1) Kp[i][J0 + 3] = fma(-g, c3, Kp[i][J0 + 3]);
       }
     }
-#endif
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = J0 + jj;
@@ -425,87 +366,8 @@ HAMK_DEV void chol(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&
 #pragma unroll
       for (int i = jb + 1; i < NR; ++i) z[i] = fma(-Kp[i][j], yj, z[i]);
     }
-#if HAMK_QUAD_LEFT
   }
-  (void)0;
-#else
-    // the trailing matrix, one pass: K[a][k] -= sum_jj G[a][J0 + jj] G[k][J0 + jj], k >= J1
-#pragma unroll
-    for (int k = J1; k < N; ++k) {
-      const int sk = k >> 2;
-      double c[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        if (J0 + jj >= J1) { c[jj] = 0.0; continue; }
-        switch (k & 3) {
-          case 0: c[jj] = qbcast<0>(Kp[sk][J0 + jj]); break;
-          case 1: c[jj] = qbcast<1>(Kp[sk][J0 + jj]); break;
-          case 2: c[jj] = qbcast<2>(Kp[sk][J0 + jj]); break;
-          default: c[jj] = qbcast<3>(Kp[sk][J0 + jj]); break;
-        }
-      }
-#pragma unroll
-      for (int i = sk; i < NR; ++i) {
-        double t = Kp[i][k];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) if (J0 + jj < J1) t = fma(-Kp[i][J0 + jj], c[jj], t);
-        Kp[i][k] = t;
-      }
-    }
-  }
-#endif
   if (!ok) st |= ST_SINGULAR;                            // every inertia positive (HAMK_INSTANTIATE_QUAD asserts it): a non-positive pivot IS singular
-}
-
-template <class S, int jb>
-HAMK_DEV void chol_panel(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], bool& ok) {
-  constexpr int N = S::N, NR = Geo<N>::NR;
-  constexpr int J0 = 4 * jb, J1 = (4 * jb + 4 < N) ? 4 * jb + 4 : N;
-  HAMK_PHASE();
-  if constexpr (jb > 0) chol_update<S, jb, J0 - 4, J0>(Kp);       // what the look-ahead could not know: the columns of panel jb - 1
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int j = J0 + jj;
-    if (j < J1) {
-      double d, wj;
-      switch (jj) {
-        case 0: d = qbcast<0>(Kp[jb][j]); wj = qbcast<0>(z[jb]); break;
-        case 1: d = qbcast<1>(Kp[jb][j]); wj = qbcast<1>(z[jb]); break;
-        case 2: d = qbcast<2>(Kp[jb][j]); wj = qbcast<2>(z[jb]); break;
-        default: d = qbcast<3>(Kp[jb][j]); wj = qbcast<3>(z[jb]); break;
-      }
-      ok = ok && (d > 0.0);
-      const double rs = frsqrt(d);
-      const double yj = wj * rs;
-#pragma unroll
-      for (int i = jb + 1; i < NR; ++i) Kp[i][j] *= rs;
-      const double below = Kp[jb][j] * rs;
-      Kp[jb][j] = (r > jj) ? below : ((r == jj) ? rs : Kp[jb][j]);
-      const double lm = (r > jj) ? below : 0.0;
-#pragma unroll
-      for (int k = j + 1; k < J1; ++k) {
-        double c;
-        switch (k & 3) {
-          case 1: c = qbcast<1>(Kp[jb][j]); break;
-          case 2: c = qbcast<2>(Kp[jb][j]); break;
-          default: c = qbcast<3>(Kp[jb][j]); break;
-        }
-        Kp[jb][k] = fma(-lm, c, Kp[jb][k]);
-#pragma unroll
-        for (int i = jb + 1; i < NR; ++i) Kp[i][k] = fma(-Kp[i][j], c, Kp[i][k]);
-      }
-      z[jb] = fma(-lm, yj, z[jb]);
-#pragma unroll
-      for (int i = jb + 1; i < NR; ++i) z[i] = fma(-Kp[i][j], yj, z[i]);
-    }
-    // look-ahead: a quarter of the finished columns [0, J0) into panel jb + 1
-    if constexpr (jb + 1 < NR && jb > 0) {
-      if (jj == 0) chol_update<S, jb + 1, 0 * jb, 1 * jb>(Kp);
-      else if (jj == 1) chol_update<S, jb + 1, 1 * jb, 2 * jb>(Kp);
-      else if (jj == 2) chol_update<S, jb + 1, 2 * jb, 3 * jb>(Kp);
-      else chol_update<S, jb + 1, 3 * jb, 4 * jb>(Kp);
-    }
-  }
 }
 
 // G y = w is done (z holds w, y_a = w_a / G_aa); G^T v = y here; returns the lane's v_(4 i + r).  Row-oriented: G[k][a] is in
@@ -554,7 +416,7 @@ template <class S, bool LUT> struct Trig {
 // panel by panel by eight sweeps had lost to it (no scratch, but 9.5 k instructions: profiles/r03_quad_ab.jsonl, the instruction
 // count decides); round 4 kept the one sweep and took the rest of that variant -- Cholesky, so that an open panel exists once
 // (not as L and as d L), and the left-looking order, so that finished columns are only read: 6.5 k instructions, no scratch in
-// the stepping loop.  -DHAMK_QUAD_LEFT=0 builds the right-looking order of the same in-place Cholesky (the A/B of round 4).
+// the stepping loop.
 
 // q of the quad's trajectory to LDS and, when every sincos site of f takes an input as operand, the pairs of the lane's
 // own coordinates with it (each lane evaluates its n/4 angles once; all sweeps of the evaluation read them).
@@ -630,7 +492,6 @@ HAMK_DEV void ham_eqs(const Ctx<S>& c0, const double (&qi)[Geo<S::N>::NR], const
   // dT/dq = -d/dq [sum_k m_k (J qd)_k (D_qd x_k)] with (J qd)_k held fixed: the generated reverse sweep, per trajectory,
   // every lane of the quad (compile-time sparsity; the cooperative alternative is dense in every direction)
   if constexpr (Trig<S, LUT>::shared) {
-#if HAMK_QUAD_BURST
     {
       TrigRegsQ<S> tr;                                    // (filled by velocity() once the inputs are staged)
       velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tr);
@@ -643,17 +504,6 @@ HAMK_DEV void ham_eqs(const Ctx<S>& c0, const double (&qi)[Geo<S::N>::NR], const
     VecRegsQ<N> v; v.load(c2.v());
     TrigRegsQ<S> t2; t2.load(c2.sq(), c2.cq());
     S::dT_reverse(q, v, t2, dT);
-#else
-    TrigLdsQ<S> tl = c.trig();
-    velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tl);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) c.v()[(4 * i + r) * 64] = vi[i];
-    HAMK_QUAD_SYNC();
-    const Ctx<S> c2 = c.launder();
-    LdsVec q{c2.q()}, v{c2.v()};
-    TrigLdsQ<S> t2 = c2.trig();
-    S::dT_reverse(q, v, t2, dT);
-#endif
   } else {
     TrigCache<S::NTRIG_F> tc;
     velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tc);
@@ -679,11 +529,7 @@ HAMK_DEV void velocity_only(const Ctx<S>& c0, const double (&qi)[Geo<S::N>::NR],
   constexpr int NR = Geo<S::N>::NR;
   const Ctx<S> c = c0.launder();
   double gUi[NR];
-#if HAMK_QUAD_BURST
   if constexpr (Trig<S, LUT>::shared) { TrigRegsQ<S> tr; velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tr); }
-#else
-  if constexpr (Trig<S, LUT>::shared) { TrigLdsQ<S> tl = c.trig(); velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tl); }
-#endif
   else { TrigCache<S::NTRIG_F> tc; velocity<S, LUT>(c, qi, pi, vi, gUi, U, st, tc); }
 }
 

@@ -682,16 +682,6 @@ def test_quad_kernels_on_host_match_oracle(emulate_quad, oracle_lib, name, B):
         check_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=min(B, 6), steps=2, tol=1e-10)
 
 
-@pytest.mark.parametrize("name,B,order", [("chain18", 3, 0), ("chain18", 3, 2), ("threeBodyPolar", 4, 0), ("threeBodyPolar", 4, 2), ("chain32", 5, 2)])
-def test_quad_factorisation_orders_on_host(emulate_quad, oracle_lib, name, B, order):
-    """-DHAMK_QUAD_LEFT=0 / 1 / 2 (the A/B builds of round 4): the same in-place Cholesky with the trailing matrix updated panel
-    by panel (0), each panel collecting the finished columns when its turn comes (1), or the next panel collecting them while
-    this one's pivots are eliminated (2) -- same results to roundoff.  (Order 1 ships: every other quad test runs it.)"""
-    spec = E.get(name)
-    L = emulate_quad(spec, defines=(f"HAMK_QUAD_LEFT {order}",))
-    check_quad_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=B)
-
-
 def test_quad_flags_a_singular_mass_matrix(emulate_quad, oracle_lib):
     """twoBody at r = 0: K = diag(mu, mu r^2) has a zero pivot -> HAMK_ST_SINGULAR for that trajectory only."""
     spec = E.get("twoBody")
