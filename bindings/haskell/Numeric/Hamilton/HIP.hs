@@ -115,26 +115,32 @@ foreign import ccall safe "hamk_system_create_ex"
 --   (@HAMK_MAP_*@, @HAMK_AD_*@, @HAMK_BODY_*@, @HAMK_TRIG_*@, @HAMK_ON@ = 1 / @HAMK_OFF@ = 2).
 data Options = Options
   { optMapping, optAdMode, optRk4Body, optRkfBody, optTrig, optGslApi, optSelfCheck, optBuild
-  , optWaveBlocked, optRk4MinWaves, optKReassoc, optRk4Park, optMaxSubsteps, optCache :: Int32
+  , optRk4MinWaves, optKReassoc, optRk4Park, optMaxSubsteps, optCache :: Int32
   , optLanesPerTrajectory :: Int32   -- ^ OUTPUT of @hamk_system_get_options@: 1, 4, 16, 32 or 64
-  , optRkfPark :: Int32              -- ^ the adaptive stepper's vectors parked in LDS / a private array (ON / OFF / AUTO)
+  , optRkfPark :: Int32              -- ^ QUAD mapping: the adaptive stepper's vectors parked in LDS / a private array (ON / OFF / AUTO);
+                                     --   lane mapping: follows 'optRkfBody' (reported; a contradicting value is refused)
   , optEnsembleSize :: Int64         -- ^ size of the WHOLE ensemble the handle's launches are pieces of: the mapping is chosen
                                      --   for it, so any shard layout reproduces the one-launch bits; 0 = per launch
   }
 
 defaultOptions :: Options
-defaultOptions = Options 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0
+defaultOptions = Options 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0
+
+-- | @HAMK_OPTIONS_VERSION@ of include/hamk.h: the layout revision this instance writes (round 5: @wave_blocked@ removed).
+optionsVersion :: Word32
+optionsVersion = 0x484b0005
 
 instance Storable Options where
-  sizeOf _ = 128                                   -- uint32 size, 14 choices, lanes_per_trajectory, rkf_park, pad, int64 ensemble_size, reserved[12]
+  sizeOf _ = 128                                   -- uint32 size, uint32 version, 13 choices, lanes_per_trajectory, rkf_park, pad, int64 ensemble_size, reserved[12]
   alignment _ = 8
-  peek p = Options <$> f 4 <*> f 8 <*> f 12 <*> f 16 <*> f 20 <*> f 24 <*> f 28 <*> f 32 <*> f 36 <*> f 40 <*> f 44
+  peek p = Options <$> f 8 <*> f 12 <*> f 16 <*> f 20 <*> f 24 <*> f 28 <*> f 32 <*> f 36 <*> f 40 <*> f 44
                    <*> f 48 <*> f 52 <*> f 56 <*> f 60 <*> f 64 <*> peekByteOff p 72
     where f = peekByteOff p
-  poke p (Options a b c d e g h i j k l m' n' o' lanes park ens) = do
+  poke p (Options a b c d e g h i k l m' n' o' lanes park ens) = do
     mapM_ (\off -> pokeByteOff p off (0 :: Int32)) [0, 4 .. 124]
     pokeByteOff p 0 (128 :: Word32)
-    mapM_ (\(off, v) -> pokeByteOff p off v) (zip [4, 8 ..] [a, b, c, d, e, g, h, i, j, k, l, m', n', o', lanes, park])
+    pokeByteOff p 4 optionsVersion
+    mapM_ (\(off, v) -> pokeByteOff p off v) (zip [8, 12 ..] [a, b, c, d, e, g, h, i, k, l, m', n', o', lanes, park])
     pokeByteOff p 72 ens
 foreign import ccall "&hamk_system_destroy"
   p_system_destroy :: FunPtr (Ptr HamkSystem -> IO ())

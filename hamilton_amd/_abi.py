@@ -41,14 +41,15 @@ AD_H, AD_D, AD_R = 1, 2, 3
 BODY_UNROLLED, BODY_STAGE_LOOP = 1, 2
 TRIG_DIRECT, TRIG_TABLE, TRIG_TABLE_ROTATE = 1, 2, 3
 BUILD_DEFAULT, BUILD_NOLICM = 1, 2
+OPTIONS_VERSION = 0x484B0005                                # HAMK_OPTIONS_VERSION of include/hamk.h
 
 
 class HamkOptions(ctypes.Structure):
     """`hamk_options` of include/hamk.h: what the library otherwise decides for itself (0 = HAMK_AUTO)."""
-    _fields_ = [("size", ctypes.c_uint32), ("mapping", ctypes.c_int32), ("ad_mode", ctypes.c_int32),
+    _fields_ = [("size", ctypes.c_uint32), ("version", ctypes.c_uint32), ("mapping", ctypes.c_int32), ("ad_mode", ctypes.c_int32),
                 ("rk4_body", ctypes.c_int32), ("rkf_body", ctypes.c_int32), ("trig", ctypes.c_int32),
                 ("gsl_api", ctypes.c_int32), ("self_check", ctypes.c_int32), ("build", ctypes.c_int32),
-                ("wave_blocked", ctypes.c_int32), ("rk4_min_waves", ctypes.c_int32), ("k_reassoc", ctypes.c_int32),
+                ("rk4_min_waves", ctypes.c_int32), ("k_reassoc", ctypes.c_int32),
                 ("rk4_park", ctypes.c_int32), ("max_substeps", ctypes.c_int32), ("cache", ctypes.c_int32),
                 ("lanes_per_trajectory", ctypes.c_int32), ("rkf_park", ctypes.c_int32), ("_align", ctypes.c_int32),
                 ("ensemble_size", ctypes.c_int64), ("reserved", ctypes.c_int32 * 12)]
@@ -56,13 +57,14 @@ class HamkOptions(ctypes.Structure):
     def __init__(self, **kw):
         super().__init__()
         self.size = ctypes.sizeof(HamkOptions)
+        self.version = OPTIONS_VERSION
         for k, v in kw.items():
-            if k not in dict(self._fields_) or k in ("size", "reserved", "_align"):
+            if k not in dict(self._fields_) or k in ("size", "version", "reserved", "_align"):
                 raise TypeError(f"hamk_options has no field {k!r}")
             setattr(self, k, int(v))
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k not in ("size", "reserved", "_align")}
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k not in ("size", "version", "reserved", "_align")}
 
 
 # name -> (restype, argtypes); mirrors include/hamk.h declaration by declaration

@@ -104,9 +104,9 @@ class Stager {
   bool pin_alloc(size_t bytes, void** host, void** dev) {
     if (s_->cur->pin_failed) return false;
     if (!s_->cur->pin) {
-      static const bool off = [] { const char* e = std::getenv("HAMK_PINNED"); return e && e[0] == '0'; }();
+      static const bool off = [] { const char* e = test_env("HAMK_PINNED"); return e && e[0] == '0'; }();
       void* h = nullptr; void* d = nullptr;
-      static const bool noncoh = [] { const char* e = std::getenv("HAMK_PINNED"); return e && e[0] == 'n'; }();   // test hook: the broken variant
+      static const bool noncoh = [] { const char* e = test_env("HAMK_PINNED"); return e && e[0] == 'n'; }();   // test hook: the broken variant
       if (off || hipHostMalloc(&h, kPinArena, hipHostMallocMapped | (noncoh ? 0u : hipHostMallocCoherent)) != hipSuccess ||
           hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
         if (h) hipHostFree(h);
@@ -243,6 +243,7 @@ void hamk_options_init(hamk_options* opt) {
   if (!opt) return;
   std::memset(opt, 0, sizeof *opt);
   opt->size = (uint32_t)sizeof *opt;
+  opt->version = HAMK_OPTIONS_VERSION;
 }
 
 int hamk_system_create(int32_t m, int32_t n, const double* inertia, const hamk_op* f_ops, int32_t f_nops,
@@ -270,7 +271,10 @@ int hamk_system_create_ex(int32_t m, int32_t n, const double* inertia, const ham
   hamk_options_init(&o);
   if (opt) {
     if (opt->size < 8 || opt->size > 4096) return fail(HAMK_ERR_INVALID, "hamk_options: size is not set (hamk_options_init)");
-    std::memcpy(&o, opt, std::min((size_t)opt->size, sizeof o));      // a caller built against an older header: the tail stays AUTO
+    if (opt->version != HAMK_OPTIONS_VERSION)
+      return fail(HAMK_ERR_INVALID, "hamk_options: layout revision mismatch (built against another include/hamk.h, or hamk_options_init "
+                                    "was not called): this library reads HAMK_OPTIONS_VERSION 0x484b0005");
+    std::memcpy(&o, opt, std::min((size_t)opt->size, sizeof o));      // a caller built against an older header of THIS revision: the tail stays AUTO
     o.size = (uint32_t)sizeof o;
   }
   err = check_options(o, n);
@@ -291,14 +295,14 @@ int hamk_system_create_ex(int32_t m, int32_t n, const double* inertia, const ham
   s->base.u_ops.assign(u_ops, u_ops + u_nops);
   s->base.u_out = u_out;
   s->gsl_api = o.gsl_api ? o.gsl_api : 2;
-  if (o.gsl_api == HAMK_AUTO) if (const char* e = std::getenv("HAMK_GSL_API")) s->gsl_api = (e[0] == '1') ? 1 : 2;
+  if (o.gsl_api == HAMK_AUTO) if (const char* e = test_env("HAMK_GSL_API")) s->gsl_api = (e[0] == '1') ? 1 : 2;
   s->self_check_on = o.self_check != HAMK_OFF;
-  if (o.self_check == HAMK_AUTO) if (const char* e = std::getenv("HAMK_SELFCHECK")) if (e[0] == '0') s->self_check_on = false;
+  if (o.self_check == HAMK_AUTO) if (const char* e = test_env("HAMK_SELFCHECK")) if (e[0] == '0') s->self_check_on = false;
   s->cache_on = o.cache != HAMK_OFF;
   s->ensemble_size = o.ensemble_size;
   s->max_substeps = o.max_substeps > 0 ? o.max_substeps : (1 << 24);
   if (o.max_substeps == HAMK_AUTO)                          // test suites: a kernel gone wrong must end, not spin through 16M attempts per lane
-    if (const char* e = std::getenv("HAMK_MAX_SUBSTEPS")) { const long k = std::atol(e); if (k > 0 && k < (1L << 24)) s->max_substeps = (int)k; }
+    if (const char* e = test_env("HAMK_MAX_SUBSTEPS")) { const long k = std::atol(e); if (k > 0 && k < (1L << 24)) s->max_substeps = (int)k; }
   // the specialisation a large ensemble uses is built now: a tape the kernels cannot be specialised for fails here
   Variant* v = nullptr;
   const int rc = variant_for(s, INT64_MAX, K_RK4, &v);
@@ -338,7 +342,6 @@ int hamk_system_get_options(hamk_system* s, int64_t B, hamk_options* r) {
   r->self_check = s->self_check_on ? HAMK_ON : HAMK_OFF;
   const int bf = build_force(s);
   r->build = bf == 0 ? HAMK_BUILD_DEFAULT : (bf == 1 ? HAMK_BUILD_NOLICM : HAMK_AUTO);
-  r->wave_blocked = d.wave_blocked ? HAMK_ON : HAMK_OFF;
   r->rk4_min_waves = d.rk4_min_waves;
   r->k_reassoc = d.k_reassoc ? HAMK_ON : HAMK_OFF;
   r->rk4_park = d.rk4_park ? HAMK_ON : HAMK_OFF;
@@ -523,9 +526,10 @@ namespace { struct HamkBoxes { double q_lo[64], q_hi[64], qd_lo[64], qd_hi[64]; 
 int hamk_sample_batch(hamk_system* s, int64_t B, int64_t first_index, uint64_t seed, const double* q_lo, const double* q_hi,
                       const double* qd_lo, const double* qd_hi, double* q, double* qd, int32_t mem) {
   TRY(check_call(s, B, mem));
-  if (!q_lo || !q_hi || !qd_lo || !qd_hi || !q || !qd) return fail(HAMK_ERR_INVALID, "null box / q / qd");
   if (first_index < 0) return fail(HAMK_ERR_INVALID, "negative first_index");
-  if (B == 0) return HAMK_OK;
+  if (first_index > INT64_MAX - B) return fail(HAMK_ERR_INVALID, "first_index + B overflows the trajectory index");
+  if (B == 0) return HAMK_OK;                               // an empty shard (its arrays may be null) is a no-op
+  if (!q_lo || !q_hi || !qd_lo || !qd_hi || !q || !qd) return fail(HAMK_ERR_INVALID, "null box / q / qd");
   const std::vector<char>* code = nullptr;
   TRY(sample_code(s->cache_on, &code));                     // (before the device is looked at: hiprtc needs no GPU, so a build
   TRY(current_device_state(s));                             //  machine without one still proves the kernel compiles for gfx950)

@@ -178,7 +178,7 @@ int compile_module(Variant* s, bool cache_on, bool no_machine_licm, std::vector<
   }
   std::string extra;                                   // experiments: HAMK_HIPRTC_FLAGS="-mllvm -foo ..."
   std::vector<std::string> extra_tok;
-  if (const char* e = std::getenv("HAMK_HIPRTC_FLAGS")) {
+  if (const char* e = test_env("HAMK_HIPRTC_FLAGS")) {
     extra = e;
     size_t pos = 0;
     while (pos < extra.size()) {
@@ -248,14 +248,14 @@ size_t kernel_code_bytes(const std::vector<char>& elf, const char* name) {
 }
 
 
-// SGPRs a kernel spills, from the code object's metadata note (msgpack; within a kernel's map the
-// keys are sorted, so ".name" precedes ".sgpr_spill_count" and the argument maps' ".name" entries
-// come before both).  -1 if not found.
-int sgpr_spill_count(const std::vector<char>& elf, const char* kernel) {
-  static const char kName[] = "\xa5.name", kSpill[] = "\xb1.sgpr_spill_count";
-  const size_t ln = sizeof kName - 1, ls = sizeof kSpill - 1;
+// An unsigned entry of one kernel's metadata map in the code object's note (msgpack; within a kernel's map the keys are
+// sorted, so ".name" precedes ".sgpr_spill_count" / ".vgpr_spill_count" and the argument maps' ".name" entries come before
+// them).  key: the msgpack fixstr / str8 encoding of the key, e.g. "\xb1.sgpr_spill_count".  -1 if not found.
+static int metadata_count(const std::vector<char>& elf, const char* kernel, const char* key, size_t lk) {
+  static const char kName[] = "\xa5.name";
+  const size_t ln = sizeof kName - 1;
   std::string last;
-  for (size_t i = 0; i + ls + 5 < elf.size(); ++i) {
+  for (size_t i = 0; i + lk + 5 < elf.size(); ++i) {
     if (elf[i] == kName[0] && std::memcmp(&elf[i], kName, ln) == 0) {
       const unsigned char b = (unsigned char)elf[i + ln];
       size_t len = 0, at = 0;
@@ -263,8 +263,8 @@ int sgpr_spill_count(const std::vector<char>& elf, const char* kernel) {
       else if (b == 0xd9) { len = (unsigned char)elf[i + ln + 1]; at = i + ln + 2; }
       else continue;
       if (at + len <= elf.size()) last.assign(&elf[at], len);
-    } else if (elf[i] == kSpill[0] && std::memcmp(&elf[i], kSpill, ls) == 0) {
-      const unsigned char* v = (const unsigned char*)&elf[i + ls];
+    } else if (elf[i] == key[0] && std::memcmp(&elf[i], key, lk) == 0) {
+      const unsigned char* v = (const unsigned char*)&elf[i + lk];
       long n = -1;
       if (v[0] < 0x80) n = v[0];
       else if (v[0] == 0xcc) n = v[1];
@@ -274,6 +274,15 @@ int sgpr_spill_count(const std::vector<char>& elf, const char* kernel) {
     }
   }
   return -1;
+}
+// SGPRs / VGPRs a kernel spills
+int sgpr_spill_count(const std::vector<char>& elf, const char* kernel) {
+  static const char k[] = "\xb1.sgpr_spill_count";
+  return metadata_count(elf, kernel, k, sizeof k - 1);
+}
+int vgpr_spill_count(const std::vector<char>& elf, const char* kernel) {
+  static const char k[] = "\xb1.vgpr_spill_count";
+  return metadata_count(elf, kernel, k, sizeof k - 1);
 }
 
 static void describe_build(Variant* s);
@@ -315,9 +324,9 @@ static void describe_build(Variant* s) {
   for (int k = 0; k < K__COUNT; ++k) {
     const std::vector<char>& c = s->use2[k] ? s->code2 : s->code;
     char line[160];
-    std::snprintf(line, sizeof line, "%s build=%s bytes=%zu sgpr_spills=%d\n", kKernelNames[k],
+    std::snprintf(line, sizeof line, "%s build=%s bytes=%zu sgpr_spills=%d vgpr_spills=%d\n", kKernelNames[k],
                   s->use2[k] ? "no-machine-licm" : "default", kernel_code_bytes(c, kKernelNames[k]),
-                  sgpr_spill_count(c, kKernelNames[k]));
+                  sgpr_spill_count(c, kKernelNames[k]), vgpr_spill_count(c, kKernelNames[k]));
     t += line;
   }
   s->build_info = t;

@@ -61,6 +61,19 @@
 #define HAMK_RKF_ROWS_IN_REGS 0 /* parked RKF45 stepper: the rows beyond the LDS share in registers (static indices) instead of scratch;
                                    set by the generator together with HAMK_RKF_MIN_WAVES_LANE 2 and HAMK_RKF_LDS_BUDGET 36 for n <= 7 */
 #endif
+// Parked rows in LDS (RK4 state from n = 14, the adaptive stepper's stage vectors): component j of lane t at
+// row[HAMK_ROW_AT(j)] from the lane's base row + HAMK_ROW_LANE.  HAMK_PAIR_ROWS: components in PAIRS, [j / 2][lane][2] --
+// 16-byte accesses (ds_read_b128 reaches the LDS rate with one wavefront per SIMD, ds_read_b64 needs four).
+#ifndef HAMK_PAIR_ROWS
+#define HAMK_PAIR_ROWS 0
+#endif
+#if HAMK_PAIR_ROWS
+#define HAMK_ROW_AT(j) ((((j) >> 1) * 512) + ((j) & 1))
+#define HAMK_ROW_LANE (2 * threadIdx.x)
+#else
+#define HAMK_ROW_AT(j) ((j) * 256)
+#define HAMK_ROW_LANE (threadIdx.x)
+#endif
 #ifndef HAMK_RK4_PARK
 #define HAMK_RK4_PARK 0       /* RK4 stage loop: y and the running combination parked in LDS across the right-hand side */
 #endif
@@ -1154,11 +1167,11 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
     // ~1 us round trip and one wavefront per SIMD to hide it (chain16: 8 GB of scratch traffic per launch against
     // 34 MB of state).  Here they wait in LDS instead -- [component][lane], conflict-free 8-byte accesses, 2 x 2n x 2 KiB
     // per 256-thread block (128 KiB at n = 16) -- and only yt -> k is in registers while the right-hand side runs.
-    __shared__ double park[2 * D * 256];
-    double* py = park + threadIdx.x;                        // y[j]   at py[j * 256]
-    double* pa = park + D * 256 + threadIdx.x;              // acc[j] at pa[j * 256]
+    __shared__ __attribute__((aligned(16))) double park[2 * D * 256];
+    double* py = park + HAMK_ROW_LANE;                        // y[j]   at py[HAMK_ROW_AT(j)]
+    double* pa = park + D * 256 + HAMK_ROW_LANE;              // acc[j] at pa[HAMK_ROW_AT(j)]
 #pragma unroll
-    for (int j = 0; j < D; ++j) { py[j * 256] = y[j]; pa[j * 256] = y[j]; }
+    for (int j = 0; j < D; ++j) { py[HAMK_ROW_AT(j)] = y[j]; pa[HAMK_ROW_AT(j)] = y[j]; }
     double k[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) k[j] = 0.0;
@@ -1169,7 +1182,7 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
       const double b = (sg == 0 || sg == 3) ? h6 : h3;
       double yt[D];
 #pragma unroll
-      for (int j = 0; j < D; ++j) yt[j] = fma(a, k[j], py[j * 256]);
+      for (int j = 0; j < D; ++j) yt[j] = fma(a, k[j], py[HAMK_ROW_AT(j)]);
       tc.mode = sg;
       if (sg >= 2) tc.mode = 5 - sg;
 #ifndef HAMK_HOST_EMULATION
@@ -1181,14 +1194,14 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
 #endif
       if (sg == 3) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) { const double v = fma(b, k[j], pa[j * 256]); pa[j * 256] = v; py[j * 256] = v; }
+        for (int j = 0; j < D; ++j) { const double v = fma(b, k[j], pa[HAMK_ROW_AT(j)]); pa[HAMK_ROW_AT(j)] = v; py[HAMK_ROW_AT(j)] = v; }
       } else {
 #pragma unroll
-        for (int j = 0; j < D; ++j) pa[j * 256] = fma(b, k[j], pa[j * 256]);
+        for (int j = 0; j < D; ++j) pa[HAMK_ROW_AT(j)] = fma(b, k[j], pa[HAMK_ROW_AT(j)]);
       }
     }
 #pragma unroll
-    for (int j = 0; j < D; ++j) y[j] = py[j * 256];
+    for (int j = 0; j < D; ++j) y[j] = py[HAMK_ROW_AT(j)];
   } else if constexpr (S::RK4_STAGE_LOOP) {
     // one copy of the right-hand side, executed 4 x nsteps times: keeps the live set to a
     // single hamEqs (n >= 3 would otherwise pay for four interleaved copies in VGPRs).
@@ -1435,6 +1448,24 @@ template <int D> HAMK_DEV void probe_pin(double (&x)[D]) {
 #define HAMK_MARK(k) ((void)0)
 #define HAMK_PIN(x) ((void)0)
 #endif
+// scripts/rkf_phase_probe.py: where a wavefront's cycles go inside one launch of the parked adaptive stepper -- probe builds only
+// (-DHAMK_PROBE_CYC=1|2): s_memtime at the phase boundaries of an attempt, summed per lane; the sums leave through the
+// nsub / status arrays (1: stage combination incl. its row loads -> nsub, right-hand side -> status; 2: the stores of a
+// stage's result -> nsub, controller + commit -> status).  Results of such a build are timing only.
+#ifdef HAMK_PROBE_CYC
+#define HAMK_CYC_DECL unsigned long long cyc_[4] = {0, 0, 0, 0}, cyc_prev_ = __builtin_readcyclecounter()
+#define HAMK_CYC(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); \
+                         cyc_[k] += now_ - cyc_prev_; cyc_prev_ = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define HAMK_CYC_PIN(x) hamk::cyc_pin(x)
+template <int D> HAMK_DEV void cyc_pin(double (&x)[D]) {
+#pragma unroll
+  for (int j = 0; j < D; ++j) asm volatile("" : "+v"(x[j]));
+}
+#else
+#define HAMK_CYC_DECL ((void)0)
+#define HAMK_CYC(k) ((void)0)
+#define HAMK_CYC_PIN(x) ((void)0)
+#endif
 #define HAMK_RKF_FLAGS(row0, inplace, gsl_api) (((row0) & 1) | (((inplace) & 3) << 8) | (((gsl_api) & 3) << 16))
 // rkf45_body for the systems whose right-hand side alone wants the whole register file (HAMK_RKF_PARK, with the stage
 // loop).  The stepper's nine vectors -- y, dydt, k2..k6, the trial state and its derivative: 18 n doubles, 576 registers
@@ -1482,27 +1513,36 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
   const bool api2 = gsl_api != 1;
   const double sgn = (!api2 || h0 > 0.0) ? 1.0 : -1.0;
   bool failed = false;
-  __shared__ double rows[NL * D * 256];
-  double* py = rows + threadIdx.x;                         // y[j]    at py[j * 256]
-  double* pf = rows + D * 256 + threadIdx.x;               // dydt[j] at pf[j * 256]
+  __shared__ __attribute__((aligned(16))) double rows[NL * D * 256];
+  double* py = rows + HAMK_ROW_LANE;                         // y[j]    at py[HAMK_ROW_AT(j)]
+  double* pf = rows + D * 256 + HAMK_ROW_LANE;               // dydt[j] at pf[HAMK_ROW_AT(j)]
   // rows 0..4: k2..k6 (those that are not in LDS), 5: the trial state, 6: the error combination -- unless k2 / k3 wait in
   // LDS: stage 6 no longer needs k2 and has just read k3, so the trial state and the error combination take over their LDS
   // rows (two scratch rows less per attempt: chain8-10 +4-5 % stepHam/s; in SCRATCH the same reuse makes the stores wait
   // for the loads of the same addresses, chain16 -5 %: there they keep rows of their own)
   double v[7][D];
-#define HAMK_RKF_YN(j) ((NL >= 3) ? HAMK_RKF_LROW(2)[(j) * 256] : v[5][j])
-#define HAMK_RKF_E(j) ((NL >= 4) ? HAMK_RKF_LROW(3)[(j) * 256] : v[6][j])
+#ifdef HAMK_PROBE_ALIAS_ROWS
+#define HAMK_RKF_YN(j) ((NL >= 3) ? HAMK_RKF_LROW(2)[HAMK_ROW_AT(j)] : py[HAMK_ROW_AT(j)])
+#define HAMK_RKF_E(j) ((NL >= 4) ? HAMK_RKF_LROW(3)[HAMK_ROW_AT(j)] : pf[HAMK_ROW_AT(j)])
+#else
+#define HAMK_RKF_YN(j) ((NL >= 3) ? HAMK_RKF_LROW(2)[HAMK_ROW_AT(j)] : v[5][j])
+#define HAMK_RKF_E(j) ((NL >= 4) ? HAMK_RKF_LROW(3)[HAMK_ROW_AT(j)] : v[6][j])
+#endif
   // k_{2 + KR} at the top of stage KR + 1: the result of the right-hand side just evaluated
   // (one base pointer per LDS row, each "array + constant + lane": offsets from a shared base beyond the 64 KiB a ds
   // instruction can encode make the compiler keep several derived bases alive through the right-hand side -- chain16: 66
   // spilled registers instead of 24, 7.8e7 -> 6.1e7 stepHam/s)
-#define HAMK_RKF_LROW(r) (rows + (r) * D * 256 + threadIdx.x)
-#define HAMK_RKF_K(KR, j) ((2 + (KR) < NL) ? HAMK_RKF_LROW(2 + (KR))[(j) * 256] : v[KR][j])      /* k_{2 + KR}[j] */
+#define HAMK_RKF_LROW(r) (rows + (r) * D * 256 + HAMK_ROW_LANE)
+#ifdef HAMK_PROBE_ALIAS_ROWS                                /* timing probe: what the scratch rows cost -- their reads come from the dydt row in LDS, their stores are dropped */
+#define HAMK_RKF_K(KR, j) ((2 + (KR) < NL) ? HAMK_RKF_LROW(2 + (KR))[HAMK_ROW_AT(j)] : pf[HAMK_ROW_AT(j)])
+#else
+#define HAMK_RKF_K(KR, j) ((2 + (KR) < NL) ? HAMK_RKF_LROW(2 + (KR))[HAMK_ROW_AT(j)] : v[KR][j])      /* k_{2 + KR}[j] */
+#endif
 #define HAMK_RKF_RECENT(KR, j) (out[j])                  /* a right-hand side's result is used from the registers by the stage that follows it */
   auto put_k = [&](int kr, const double (&x)[D]) {         // k_{2 + kr}; kr: a run-time value (the stage counter)
     if (NL > 2 && 2 + kr < NL) {
 #pragma unroll
-      for (int j = 0; j < D; ++j) HAMK_RKF_LROW(2 + kr)[j * 256] = x[j];
+      for (int j = 0; j < D; ++j) HAMK_RKF_LROW(2 + kr)[HAMK_ROW_AT(j)] = x[j];
     } else {
 #if HAMK_RKF_ROWS_IN_REGS
       // small systems at two wavefronts per SIMD: the rows that do not fit the (halved) LDS share stay in REGISTERS -- every
@@ -1525,6 +1565,8 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
           for (int j = 0; j < D; ++j) v[3][j] = x[j];
           break;
       }
+#elif defined(HAMK_PROBE_ALIAS_ROWS)
+      (void)x;
 #else
 #pragma unroll
       for (int j = 0; j < D; ++j) v[kr][j] = x[j];
@@ -1534,6 +1576,7 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
   int st = 0, attempts = 0;
   double t = ts ? ts[0] : ts0, h = h0;
   TrigCache<S::NTRIG_F> tc;
+  HAMK_CYC_DECL;
   {
     double y0[D];
 #pragma unroll
@@ -1543,7 +1586,7 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
       for (int j = 0; j < N; ++j) { qout[(i64)j * B + i] = y0[j]; pout[(i64)j * B + i] = y0[N + j]; }
     }
 #pragma unroll
-    for (int j = 0; j < D; ++j) py[j * 256] = y0[j];
+    for (int j = 0; j < D; ++j) py[HAMK_ROW_AT(j)] = y0[j];
   }
   it_every = park_in_vgpr(it_every);
   int until_frame = it_every;
@@ -1559,14 +1602,19 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
     // calls one by one is by construction, for one right-hand side in ~30 per call.
     double y0[D], f0[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) y0[j] = py[j * 256];
+    for (int j = 0; j < D; ++j) y0[j] = py[HAMK_ROW_AT(j)];
     rhs<S, StageTrig<S>::anchor>(y0, f0, st, tc);
 #pragma unroll
-    for (int j = 0; j < D; ++j) pf[j * 256] = f0[j];
+    for (int j = 0; j < D; ++j) pf[HAMK_ROW_AT(j)] = f0[j];
   }
   for (int r = 1; r < nt; ++r) {
     const double ti = ts ? ts[r] : ts1;
+#ifdef HAMK_PROBE_FIXED                                     /* timing probe: HAMK_PROBE_FIXED attempts per call for every lane, each accepted, h = interval / HAMK_PROBE_FIXED */
+    h = (ti - t) * (1.0 / HAMK_PROBE_FIXED);
+    for (int fx_ = 0; fx_ < HAMK_PROBE_FIXED; ++fx_) {
+#else
     while (sgn * (ti - t) > 0.0 && budget > 0 && !failed) {
+#endif
       ++attempts; --budget;
       HAMK_MARK(1);
       const double dt = ti - t;
@@ -1576,33 +1624,34 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
       double out[D];                                        // the last right-hand side's result: k_{sg + 1} at the top of stage sg
 #pragma unroll
       for (int j = 0; j < D; ++j) out[j] = 0.0;
+      HAMK_CYC(3);
 #pragma unroll 1
       for (int sg = 0; sg < 6; ++sg) {
         double yt[D];
         switch (sg) {
           case 0:
 #pragma unroll
-            for (int j = 0; j < D; ++j) yt[j] = py[j * 256] + (1.0 / 4.0) * hh * pf[j * 256];
+            for (int j = 0; j < D; ++j) yt[j] = py[HAMK_ROW_AT(j)] + (1.0 / 4.0) * hh * pf[HAMK_ROW_AT(j)];
             break;
           case 1:
 #pragma unroll
-            for (int j = 0; j < D; ++j) yt[j] = py[j * 256] + hh * ((3.0 / 32.0) * pf[j * 256] + (9.0 / 32.0) * HAMK_RKF_RECENT(0, j));
+            for (int j = 0; j < D; ++j) yt[j] = py[HAMK_ROW_AT(j)] + hh * ((3.0 / 32.0) * pf[HAMK_ROW_AT(j)] + (9.0 / 32.0) * HAMK_RKF_RECENT(0, j));
             break;
           case 2:
 #pragma unroll
             for (int j = 0; j < D; ++j)
-              yt[j] = py[j * 256] + hh * ((1932.0 / 2197.0) * pf[j * 256] + (-7200.0 / 2197.0) * HAMK_RKF_K(0, j) + (7296.0 / 2197.0) * HAMK_RKF_RECENT(1, j));
+              yt[j] = py[HAMK_ROW_AT(j)] + hh * ((1932.0 / 2197.0) * pf[HAMK_ROW_AT(j)] + (-7200.0 / 2197.0) * HAMK_RKF_K(0, j) + (7296.0 / 2197.0) * HAMK_RKF_RECENT(1, j));
             break;
           case 3:
 #pragma unroll
             for (int j = 0; j < D; ++j)
-              yt[j] = py[j * 256] + hh * ((8341.0 / 4104.0) * pf[j * 256] + (-32832.0 / 4104.0) * HAMK_RKF_K(0, j) +
+              yt[j] = py[HAMK_ROW_AT(j)] + hh * ((8341.0 / 4104.0) * pf[HAMK_ROW_AT(j)] + (-32832.0 / 4104.0) * HAMK_RKF_K(0, j) +
                                           (29440.0 / 4104.0) * HAMK_RKF_K(1, j) + (-845.0 / 4104.0) * HAMK_RKF_RECENT(2, j));
             break;
           case 4:
 #pragma unroll
             for (int j = 0; j < D; ++j)
-              yt[j] = py[j * 256] + hh * ((-6080.0 / 20520.0) * pf[j * 256] + (41040.0 / 20520.0) * HAMK_RKF_K(0, j) +
+              yt[j] = py[HAMK_ROW_AT(j)] + hh * ((-6080.0 / 20520.0) * pf[HAMK_ROW_AT(j)] + (41040.0 / 20520.0) * HAMK_RKF_K(0, j) +
                                           (-28352.0 / 20520.0) * HAMK_RKF_K(1, j) + (9295.0 / 20520.0) * HAMK_RKF_K(2, j) +
                                           (-5643.0 / 20520.0) * HAMK_RKF_RECENT(3, j));
             break;
@@ -1610,22 +1659,38 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
             double ye[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-              const double f0 = pf[j * 256], k3 = HAMK_RKF_K(1, j), k4 = HAMK_RKF_K(2, j), k5 = HAMK_RKF_K(3, j), k6 = HAMK_RKF_RECENT(4, j);
+              const double f0 = pf[HAMK_ROW_AT(j)], k3 = HAMK_RKF_K(1, j), k4 = HAMK_RKF_K(2, j), k5 = HAMK_RKF_K(3, j), k6 = HAMK_RKF_RECENT(4, j);
               const double di = (902880.0 / 7618050.0) * f0 + (3953664.0 / 7618050.0) * k3 +
                                 (3855735.0 / 7618050.0) * k4 + (-1371249.0 / 7618050.0) * k5 +
                                 (277020.0 / 7618050.0) * k6;
-              yt[j] = py[j * 256] + hh * di;
+              yt[j] = py[HAMK_ROW_AT(j)] + hh * di;
               ye[j] = hh * ((1.0 / 360.0) * f0 + (-128.0 / 4275.0) * k3 + (-2197.0 / 75240.0) * k4 + (1.0 / 50.0) * k5 + (2.0 / 55.0) * k6);
             }
+#ifdef HAMK_PROBE_ALIAS_ROWS
+            if constexpr (NL >= 3) {
+#pragma unroll
+              for (int j = 0; j < D; ++j) HAMK_RKF_YN(j) = yt[j];
+            }
+            if constexpr (NL >= 4) {
+#pragma unroll
+              for (int j = 0; j < D; ++j) HAMK_RKF_E(j) = ye[j];
+            } else {
+#pragma unroll
+              for (int j = 0; j < D; ++j) asm volatile("" : : "v"(ye[j]));
+            }
+#else
 #pragma unroll
             for (int j = 0; j < D; ++j) HAMK_RKF_YN(j) = yt[j];
 #pragma unroll
             for (int j = 0; j < D; ++j) HAMK_RKF_E(j) = ye[j];
+#endif
             break;
           }
         }
         HAMK_MARK(3);
         HAMK_PIN(yt);
+        HAMK_CYC_PIN(yt);
+        HAMK_CYC(0);
 #ifndef HAMK_HOST_EMULATION
         __builtin_amdgcn_sched_barrier(0);                  // no row is fetched early into the right-hand side
 #endif
@@ -1635,7 +1700,10 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
 #endif
         HAMK_PIN(out);
         HAMK_MARK(0);
+        HAMK_CYC_PIN(out);
+        HAMK_CYC(1);
         if (sg < 4) put_k(sg, out);                         // k2..k5; k6 and dydt_out are used from the registers and never stored
+        HAMK_CYC(2);
       }
       // --- cstd.c: std_control_hadjust, ord = 5 ------------------------------
       double yn[D];
@@ -1662,12 +1730,16 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
         if (rr < 1.0) rr = 1.0;
         hh = rr * h_old;
       }
+#ifdef HAMK_PROBE_FIXED
+      reject = false; failed = false; hh = h_old;
+      asm volatile("" : "+v"(rmax));
+#endif
       if (reject || failed || !api2 || !final_step) h = hh;
       if (!reject) {
         if (!(sgn * (tnew - t) > 0.0)) st |= ST_UNDERFLOW;
         t = tnew;
 #pragma unroll
-        for (int j = 0; j < D; ++j) { py[j * 256] = yn[j]; pf[j * 256] = out[j]; }
+        for (int j = 0; j < D; ++j) { py[HAMK_ROW_AT(j)] = yn[j]; pf[HAMK_ROW_AT(j)] = out[j]; }
       }
       HAMK_MARK(2);
     }
@@ -1676,20 +1748,25 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
       double* qo = (inplace == 2) ? const_cast<double*>(q0) : (inplace ? qout : qout + (i64)r * N * B);
       double* po = (inplace == 2) ? const_cast<double*>(p0) : (inplace ? pout : pout + (i64)r * N * B);
 #pragma unroll
-      for (int j = 0; j < N; ++j) { qo[(i64)j * B + i] = py[j * 256]; po[(i64)j * B + i] = py[(N + j) * 256]; }
+      for (int j = 0; j < N; ++j) { qo[(i64)j * B + i] = py[HAMK_ROW_AT(j)]; po[(i64)j * B + i] = py[HAMK_ROW_AT(N + j)]; }
     }
   }
   if (it_every > 0 && --until_frame == 0) {
     until_frame = it_every;
 #pragma unroll
-    for (int j = 0; j < N; ++j) { qout[(i64)j * B + i] = py[j * 256]; pout[(i64)j * B + i] = py[(N + j) * 256]; }
+    for (int j = 0; j < N; ++j) { qout[(i64)j * B + i] = py[HAMK_ROW_AT(j)]; pout[(i64)j * B + i] = py[HAMK_ROW_AT(N + j)]; }
     qout += (i64)N * B; pout += (i64)N * B;
   }
   }
   bool bad = false;
 #pragma unroll
-  for (int j = 0; j < D; ++j) bad = bad || is_nonfinite_bits(py[j * 256]);
+  for (int j = 0; j < D; ++j) bad = bad || is_nonfinite_bits(py[HAMK_ROW_AT(j)]);
   if (bad) st |= ST_NONFINITE;
+#ifdef HAMK_PROBE_CYC
+  HAMK_CYC(3);
+  st = (int)cyc_[HAMK_PROBE_CYC == 1 ? 1 : 3];
+  attempts = (int)cyc_[HAMK_PROBE_CYC == 1 ? 0 : 2];
+#endif
   if (status) status[i] = st;
   if (nsub) nsub[i] = attempts;
 #undef HAMK_RKF_RECENT

@@ -22,11 +22,16 @@
 using namespace hamk_host;
 
 namespace hamk_host {
+const char* test_env(const char* name) {
+  const char* on = std::getenv("HAMK_TEST_OVERRIDES");
+  return (on && on[0] == '1' && on[1] == 0) ? std::getenv(name) : nullptr;
+}
+
 // hamk_options::build, else HAMK_NOLICM (tests), else per kernel
 int build_force(const hamk_system* s) {                      // hamk_options::build, else HAMK_NOLICM (tests), else per kernel
   if (s->opt.build == HAMK_BUILD_DEFAULT) return 0;
   if (s->opt.build == HAMK_BUILD_NOLICM) return 1;
-  if (const char* e = std::getenv("HAMK_NOLICM")) return (e[0] == '1') ? 1 : (e[0] == '0' ? 0 : -1);
+  if (const char* e = test_env("HAMK_NOLICM")) return (e[0] == '1') ? 1 : (e[0] == '0' ? 0 : -1);
   return -1;
 }
 
@@ -258,12 +263,14 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
     hipFree(e_q); hipFree(e_p); hipFree(e_st); hipFree(e_ns);
     (void)hipGetLastError();
   }
-  if (const char* e = std::getenv("HAMK_SELFCHECK_FAULT")) {        // test hook: pretend the unrolled body is wrong
+  if (const char* e = test_env("HAMK_SELFCHECK_FAULT")) {        // test hook: pretend the unrolled body is wrong
     if (std::strstr(e, "rk4") && !s->curv->desc.rk4_stage_loop) *rk4_ok = false;
     if (std::strstr(e, "rkf") && !s->curv->desc.rkf_stage_loop) *rkf_ok = false;
   }
   return rc;
 }
+
+static void derive_body_fields(const hamk_system* s, SystemDesc& d);
 
 static int self_check(hamk_system* s) {
   if (!s->self_check_on) return HAMK_OK;
@@ -282,6 +289,7 @@ static int self_check(hamk_system* s) {
                                         (g_selfcheck_detail.empty() ? "" : " [" + g_selfcheck_detail + "]"));
     if (!rk4_ok) v->desc.rk4_stage_loop = true;            // rebuild with the stage-loop bodies
     if (!rkf_ok) v->desc.rkf_stage_loop = true;
+    derive_body_fields(s, v->desc);
     v->source = generate_source(v->desc);
     rc = build_code(v, s->cache_on, build_force(s));
     if (rc != HAMK_OK) return rc;
@@ -381,7 +389,7 @@ static int64_t quad_below(int n) {
 }
 
 static bool env_flag(const char* name, bool* value) {           // "0" / "1" test overrides
-  const char* e = std::getenv(name);
+  const char* e = test_env(name);
   if (!e || (e[0] != '0' && e[0] != '1')) return false;
   *value = e[0] == '1';
   return true;
@@ -398,7 +406,7 @@ std::string check_options(const hamk_options& o, int n) {
   if (!in(o.trig, {HAMK_AUTO, HAMK_TRIG_DIRECT, HAMK_TRIG_TABLE, HAMK_TRIG_TABLE_ROTATE})) return "trig must be HAMK_AUTO or a HAMK_TRIG_* value";
   if (!in(o.gsl_api, {HAMK_AUTO, 1, 2})) return "gsl_api must be HAMK_AUTO, 1 (gsl_odeiv) or 2 (gsl_odeiv2)";
   if (!in(o.build, {HAMK_AUTO, HAMK_BUILD_DEFAULT, HAMK_BUILD_NOLICM})) return "build must be HAMK_AUTO or a HAMK_BUILD_* value";
-  for (int v : {o.self_check, o.wave_blocked, o.k_reassoc, o.rk4_park, o.rkf_park, o.cache})
+  for (int v : {o.self_check, o.k_reassoc, o.rk4_park, o.rkf_park, o.cache})
     if (!in(v, {HAMK_AUTO, HAMK_ON, HAMK_OFF})) return "switches must be HAMK_AUTO, HAMK_ON or HAMK_OFF";
   if (o.rk4_min_waves < 0 || o.rk4_min_waves > 8) return "rk4_min_waves must be 0 (auto) .. 8";
   if (o.max_substeps < 0) return "max_substeps must be >= 0";
@@ -449,40 +457,13 @@ static int choose_mapping(hamk_system* s, int64_t B, int kernel) {
   return HAMK_MAP_LANE;
 }
 
-static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4, bool* forced_rkf) {
+// What follows from the choice of stepping bodies.  make_desc ends with it; the two places that switch a built variant to the
+// stage-loop bodies afterwards (the > 64 KiB fallback of variant_for, the self-check's one rebuild) call it again, so that the
+// rebuilt module is the configuration the stage-loop body ships in and hamk_system_get_options reports what runs.
+static void derive_body_fields(const hamk_system* s, SystemDesc& d) {
   const hamk_options& o = s->opt;
-  SystemDesc d = s->base;
-  const int n = d.n, m = d.m;
+  const int n = d.n, mapping = d.mapping;
   bool b = false;
-  d.mapping = mapping;
-  d.wave = mapping == HAMK_MAP_WAVE;
-  // second-order AD: measured on MI355X (scripts/sweep.py): H >= D up to n = 3, D ahead from n = 4; the reverse sweep
-  // pays from n = 8 (chain8 +4 %, chain16 +12 %); below, the compiler already strips the structural zeros of the
-  // directional jets and Jet2 is as cheap
-  d.mode_h = (n <= 3);
-  d.mode_r = (n >= 8);
-  int ad = o.ad_mode;
-  if (ad == HAMK_AUTO) if (const char* e = std::getenv("HAMK_AD_MODE")) ad = (e[0] == 'H' || e[0] == 'h') ? HAMK_AD_H : (e[0] == 'D' || e[0] == 'd') ? HAMK_AD_D : (e[0] == 'R' || e[0] == 'r') ? HAMK_AD_R : HAMK_AUTO;
-  if (ad == HAMK_AD_H) { d.mode_h = true; d.mode_r = false; }
-  if (ad == HAMK_AD_D) { d.mode_h = false; d.mode_r = false; }
-  if (ad == HAMK_AD_R) { d.mode_h = false; d.mode_r = true; }
-  d.wave_blocked = true;                                    // (the panel factorisation is the only one since round 4; hamk_options::wave_blocked is ignored)
-  d.rk4_stage_loop = (n >= 7);
-  *forced_rk4 = true;
-  if (o.rk4_body != HAMK_AUTO) d.rk4_stage_loop = o.rk4_body == HAMK_BODY_STAGE_LOOP;
-  else if (env_flag("HAMK_RK4_LOOP", &b)) d.rk4_stage_loop = b;
-  else *forced_rk4 = false;
-  d.rkf_stage_loop = (n >= 4);
-  *forced_rkf = true;
-  if (o.rkf_body != HAMK_AUTO) d.rkf_stage_loop = o.rkf_body == HAMK_BODY_STAGE_LOOP;
-  else if (env_flag("HAMK_RKF_LOOP", &b)) d.rkf_stage_loop = b;
-  else *forced_rkf = false;
-  // n > 32 (one trajectory per wavefront): the RK4 kernel capped at 256 VGPRs -- two wavefronts per SIMD, ~160
-  // spilled registers -- beats one wavefront with everything in registers: chain48 1.05e7 -> 1.45e7, chain64
-  // 7.6e6 -> 9.5e6 RK4 steps/s on MI355X (profiles/r02_wave_blocked.jsonl)
-  d.rk4_min_waves = 1;
-  if (d.wave && n > 32) d.rk4_min_waves = 2;
-  if (o.rk4_min_waves > 0) d.rk4_min_waves = o.rk4_min_waves;
   // RK4 stage loop with y / acc parked in LDS (hamk_device.hpp rk4_body): where one right-hand side alone fills the
   // register file the waiting state is what spills; chain16 300 spilled registers -> 34, none in the loop.  Measured
   // at B = 65 536 (profiles/r03_rules_probe.jsonl; RK4 steps/s parked / not): chain16 2.09e9 / 1.01e9, chain14
@@ -514,8 +495,46 @@ static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4,
   // wavefront / two (profiles/r04_rkf_hybrid_ab.jsonl): chain4 1.57e9 / 2.01e9, chain5 1.27e9 / 1.62e9, chain6 1.05e9 /
   // 1.32e9, threeBodyPolar 1.15e9 / 1.41e9, chain7 8.8e8 / 9.4e8; states equal to 4e-16, sub-step counts identical.  (Without
   // the sincos table to make room: 1.34e9; two LDS rows: 1.19e9; three wavefronts: 8.5e8.  From n = 8 the right-hand side
-  // alone needs more than 256 registers.)
-  d.rkf_two_waves = mapping == HAMK_MAP_LANE && d.rkf_stage_loop && n <= 7;
+  // alone needs more than 256 registers.)  The rule was measured on the chains and threeBodyPolar: a small-n system with a
+  // heavy tape may not fit 256 registers -- variant_for looks at the built kernel and goes back to one wavefront where the
+  // cap made it spill (rkf_two_waves_off); HAMK_RKF_TWO_WAVES=0|1 is the test override.
+  d.rkf_two_waves = mapping == HAMK_MAP_LANE && d.rkf_stage_loop && n <= 7 && !d.rkf_two_waves_off;
+  if (env_flag("HAMK_RKF_TWO_WAVES", &b)) d.rkf_two_waves = b && mapping == HAMK_MAP_LANE && d.rkf_stage_loop && n <= 7;
+}
+
+static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4, bool* forced_rkf) {
+  const hamk_options& o = s->opt;
+  SystemDesc d = s->base;
+  const int n = d.n, m = d.m;
+  bool b = false;
+  d.mapping = mapping;
+  d.wave = mapping == HAMK_MAP_WAVE;
+  // second-order AD: measured on MI355X (scripts/sweep.py): H >= D up to n = 3, D ahead from n = 4; the reverse sweep
+  // pays from n = 8 (chain8 +4 %, chain16 +12 %); below, the compiler already strips the structural zeros of the
+  // directional jets and Jet2 is as cheap
+  d.mode_h = (n <= 3);
+  d.mode_r = (n >= 8);
+  int ad = o.ad_mode;
+  if (ad == HAMK_AUTO) if (const char* e = test_env("HAMK_AD_MODE")) ad = (e[0] == 'H' || e[0] == 'h') ? HAMK_AD_H : (e[0] == 'D' || e[0] == 'd') ? HAMK_AD_D : (e[0] == 'R' || e[0] == 'r') ? HAMK_AD_R : HAMK_AUTO;
+  if (ad == HAMK_AD_H) { d.mode_h = true; d.mode_r = false; }
+  if (ad == HAMK_AD_D) { d.mode_h = false; d.mode_r = false; }
+  if (ad == HAMK_AD_R) { d.mode_h = false; d.mode_r = true; }
+  d.rk4_stage_loop = (n >= 7);
+  *forced_rk4 = true;
+  if (o.rk4_body != HAMK_AUTO) d.rk4_stage_loop = o.rk4_body == HAMK_BODY_STAGE_LOOP;
+  else if (env_flag("HAMK_RK4_LOOP", &b)) d.rk4_stage_loop = b;
+  else *forced_rk4 = false;
+  d.rkf_stage_loop = (n >= 4);
+  *forced_rkf = true;
+  if (o.rkf_body != HAMK_AUTO) d.rkf_stage_loop = o.rkf_body == HAMK_BODY_STAGE_LOOP;
+  else if (env_flag("HAMK_RKF_LOOP", &b)) d.rkf_stage_loop = b;
+  else *forced_rkf = false;
+  // n > 32 (one trajectory per wavefront): the RK4 kernel capped at 256 VGPRs -- two wavefronts per SIMD, ~160
+  // spilled registers -- beats one wavefront with everything in registers: chain48 1.05e7 -> 1.45e7, chain64
+  // 7.6e6 -> 9.5e6 RK4 steps/s on MI355X (profiles/r02_wave_blocked.jsonl)
+  d.rk4_min_waves = 1;
+  if (d.wave && n > 32) d.rk4_min_waves = 2;
+  if (o.rk4_min_waves > 0) d.rk4_min_waves = o.rk4_min_waves;
   d.k_reassoc = true;
   if (o.k_reassoc != HAMK_AUTO) d.k_reassoc = o.k_reassoc == HAMK_ON;
   {
@@ -549,8 +568,10 @@ static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4,
   // +4 %, chain12 +4 % / +5 %, chain14 +5 % / +1 %; chain16 +3 % / -2 %, chain6 and threeBodyPolar +-1 %, doublePendulum
   // -6 % / -6 % (18 more registers where occupancy pays) -- so: 8 <= n <= 14.
   d.trig_const_vgpr = mapping == HAMK_MAP_LANE && n >= 8 && n <= 14;
+  if (env_flag("HAMK_TRIG_CONST_VGPR", &b)) d.trig_const_vgpr = b && mapping == HAMK_MAP_LANE;      // test override (the rule above was measured on the chains)
   if (o.trig != HAMK_AUTO) d.use_lut = o.trig == HAMK_TRIG_DIRECT ? 0 : (o.trig == HAMK_TRIG_TABLE ? 1 : 2);
-  else if (const char* e = std::getenv("HAMK_TRIG_LUT")) { if (e[0] >= '0' && e[0] <= '2') d.use_lut = e[0] - '0'; }
+  else if (const char* e = test_env("HAMK_TRIG_LUT")) { if (e[0] >= '0' && e[0] <= '2') d.use_lut = e[0] - '0'; }
+  derive_body_fields(s, d);
   return d;
 }
 
@@ -560,17 +581,38 @@ int variant_for(hamk_system* s, int64_t B, int kernel, Variant** out) {
   Variant* v = new Variant();
   v->mapping = mapping;
   v->desc = make_desc(s, mapping, &v->forced_rk4_body, &v->forced_rkf_body);
+  // an explicitly set option that this specialisation cannot honour is refused, not silently replaced (the lane mapping's
+  // stage-loop stepper IS the parked one, its unrolled stepper keeps everything in registers: rkf_park follows rkf_body there)
+  if (mapping == HAMK_MAP_LANE && s->opt.rkf_park != HAMK_AUTO && (s->opt.rkf_park == HAMK_ON) != v->desc.rkf_stage_loop) {
+    const bool on = s->opt.rkf_park == HAMK_ON;
+    delete v;
+    return fail(HAMK_ERR_UNSUPPORTED, std::string("hamk_options: rkf_park = ") + (on ? "ON" : "OFF") + " cannot be honoured on the lane mapping: its " +
+                                          (on ? "unrolled adaptive body keeps every vector in registers" : "stage-loop adaptive body is the parked one") +
+                                          " (set rkf_body instead, or leave rkf_park AUTO)");
+  }
   v->source = generate_source(v->desc);
   int rc = build_code(v, s->cache_on, build_force(s));
   if (rc != HAMK_OK) { delete v; return rc; }
   // keep every kernel comfortably inside SOPP branch reach: fall back to the stage-loop bodies
   const size_t kLimit = 64 * 1024;
   const bool lane = mapping == HAMK_MAP_LANE;
+  bool lane_flag_ = false;
   const bool big_rkf = lane && !v->forced_rkf_body && !v->desc.rkf_stage_loop && chosen_kernel_bytes(v, K_RKF45) > kLimit;
   const bool big_rk4 = lane && !v->forced_rk4_body && !v->desc.rk4_stage_loop && chosen_kernel_bytes(v, K_RK4) > kLimit;
   if (big_rkf || big_rk4) {
     if (big_rkf) v->desc.rkf_stage_loop = true;
     if (big_rk4) v->desc.rk4_stage_loop = true;
+    derive_body_fields(s, v->desc);
+    v->source = generate_source(v->desc);
+    rc = build_code(v, s->cache_on, build_force(s));
+    if (rc != HAMK_OK) { delete v; return rc; }
+  }
+  // the two-wavefront stepper caps hamk_rkf45_k at 256 registers: where THIS system's right-hand side does not fit (a heavy
+  // tape at small n) the cap turns into spill code inside the attempt loop -- back to one wavefront with every row in LDS
+  if (lane && v->desc.rkf_two_waves && !env_flag("HAMK_RKF_TWO_WAVES", &lane_flag_) &&
+      vgpr_spill_count(v->use2[K_RKF45] ? v->code2 : v->code, kKernelNames[K_RKF45]) > 32) {
+    v->desc.rkf_two_waves_off = true;
+    derive_body_fields(s, v->desc);
     v->source = generate_source(v->desc);
     rc = build_code(v, s->cache_on, build_force(s));
     if (rc != HAMK_OK) { delete v; return rc; }

@@ -16,6 +16,11 @@
 
 namespace hamk_host {
 
+// Environment overrides of the library's own choices (which mapping, which body, which sincos ...) exist for the test suites and
+// the A/B scripts.  They are read ONLY when HAMK_TEST_OVERRIDES=1 is set (tests/conftest.py and the scripts set it): a host
+// process that happens to carry a HAMK_QUAD or HAMK_AD_MODE variable runs what hamk_options says, nothing else.  Not gated:
+// HAMK_CACHE / HAMK_CACHE_DIR (where compiled code objects are kept) and HAMK_SELFCHECK_VERBOSE (diagnostics).
+const char* test_env(const char* name);                    // getenv(name) under HAMK_TEST_OVERRIDES=1, else nullptr
 int fail(int code, const std::string& msg);                // sets the thread's hamk_last_error text, returns code
 const std::string& last_error_text();
 
@@ -187,6 +192,7 @@ int build_code(Variant* s, bool cache_on, int force);      // force: 0 default b
 size_t kernel_code_bytes(const std::vector<char>& elf, const char* name);
 size_t chosen_kernel_bytes(const Variant* s, int k);
 int sgpr_spill_count(const std::vector<char>& elf, const char* kernel);
+int vgpr_spill_count(const std::vector<char>& elf, const char* kernel);
 int sample_code(bool cache_on, const std::vector<char>** out);        // hamk_sample.hpp's code object, compiled once per process
 
 // ---- hamk_dispatch.cpp ------------------------------------------------------------------------------------------------

@@ -293,6 +293,41 @@ def chain(N: int) -> SystemSpec:
         cite="SURVEY.md section 8d C5 (no reference counterpart)")
 
 
+def dense(N: int) -> SystemSpec:
+    """`denseN`: a System N N whose coordinate map has a DENSE Jacobian (build-defined benchmark workload for the
+    wave-cooperative / matrix-core kernels, BASELINE.json configs[4] "larger-n dense solve / MFMA crossover").
+
+    x_k = 2 q_k + sum_j (a_kj sin q_j + b_kj cos q_j) with small fixed a, b: every dx_k/dq_j is non-zero and distinct (n^2
+    Jacobian entries, so the four-lane mapping is never chosen), n sincos evaluations per right-hand side, K = J^T J stays
+    well conditioned (J = 2 I + O(0.1 n^(1/2))); U = 1/2 |x|^2 keeps the motion bounded."""
+    s = 1.0 / N
+
+    def f(q, o):
+        sn = [o.sin(q[j]) for j in range(N)]
+        cs = [o.cos(q[j]) for j in range(N)]
+        out = []
+        for k in range(N):
+            acc = 2.0 * q[k]
+            for j in range(N):
+                a = s * (0.2 + 0.1 * ((3 * k + 7 * j) % 11))
+                b = s * (0.15 + 0.1 * ((5 * k + 2 * j) % 7))
+                acc = acc + a * sn[j] + b * cs[j]
+            out.append(acc)
+        return out
+
+    def u(x, o):
+        acc = 0.0
+        for k in range(N):
+            acc = acc + x[k] * x[k]
+        return 0.5 * acc
+
+    return SystemSpec(
+        name=f"dense{N}", m=N, n=N, inertia=(1.0,) * N, f=f, u=u, u_space=U_CARTESIAN,
+        q0=tuple(0.1 for _ in range(N)), qd0=(0.0,) * N,
+        q_box=tuple((-1.0, 1.0) for _ in range(N)), qd_box=tuple((-0.5, 0.5) for _ in range(N)), dt=0.01,
+        cite="build-defined (dense-Jacobian benchmark system; no reference counterpart)")
+
+
 REGISTRY = {
     "pendulum": pendulum,
     "doublePendulum": double_pendulum,
@@ -325,6 +360,8 @@ def get(name: str) -> SystemSpec:
         return mixed_inertia(name[:-6])
     if name.startswith("chain"):
         return chain(int(name[5:]))
+    if name.startswith("dense"):
+        return dense(int(name[5:]))
     return REGISTRY[name]()
 
 

@@ -150,8 +150,9 @@ typedef struct hamk_system hamk_system;   /* opaque */
 /* ---- options of a system (hamk_system_create_ex) -----------------------------------------------------
  * Everything the library decides for itself when it specialises its kernels for a system can be fixed by the host
  * instead.  HAMK_AUTO (0) in a field leaves that decision to the library; a zero-filled struct with `size` set is
- * "all defaults".  The environment variables of DESIGN.md section 7 are TEST overrides: they apply only where the
- * field is HAMK_AUTO.  hamk_system_get_options reports what was actually chosen.                                  */
+ * "all defaults" -- hamk_options_init also sets `version`.  The environment variables of DESIGN.md section 7 are TEST
+ * overrides: they are read only in a process that sets HAMK_TEST_OVERRIDES=1, and apply only where the field is
+ * HAMK_AUTO.  hamk_system_get_options reports what was actually chosen.                                           */
 #define HAMK_AUTO 0
 #define HAMK_ON   1
 #define HAMK_OFF  2
@@ -177,8 +178,12 @@ typedef struct hamk_system hamk_system;   /* opaque */
 #define HAMK_BUILD_DEFAULT 1
 #define HAMK_BUILD_NOLICM  2       /* -mllvm -disable-machine-licm                      */
 
+#define HAMK_OPTIONS_VERSION 0x484b0005u   /* layout revision of hamk_options ('H' 'K' 0x0005: round 5 dropped the dead field
+                                              wave_blocked); a struct of another revision is refused with HAMK_ERR_INVALID   */
 typedef struct hamk_options {
   uint32_t size;           /* sizeof(hamk_options) as the caller's header has it (hamk_options_init sets it)           */
+  uint32_t version;        /* HAMK_OPTIONS_VERSION (hamk_options_init sets it): fields were removed since the first layout,
+                              so `size` alone no longer identifies what the caller's header meant                       */
   int32_t mapping;         /* HAMK_MAP_*; AUTO: chosen PER LAUNCH from (n, ensemble size B): a small ensemble of a
                               mid-size system cannot fill the chip with one trajectory per lane.  Two mappings agree to
                               roundoff, not bitwise: pin the mapping where results must not depend on how an ensemble
@@ -190,8 +195,6 @@ typedef struct hamk_options {
   int32_t gsl_api;         /* 1 | 2 (hamk_system_set_gsl_api); AUTO: 2                                                  */
   int32_t self_check;      /* ON | OFF: first-use self-check of the stepping kernels; AUTO: ON                          */
   int32_t build;           /* HAMK_BUILD_*; AUTO: per kernel, the build that spills fewer SGPRs                         */
-  int32_t wave_blocked;    /* ignored since round 4 (kept for layout): the wave mapping's LDL^T always runs in panels of 16
-                              with MFMA trailing updates; hamk_system_get_options reports ON                            */
   int32_t rk4_min_waves;   /* __launch_bounds__ waves per SIMD of the RK4 kernel; AUTO: measured default                */
   int32_t k_reassoc;       /* ON | OFF: K = J^T M J summed with re-association allowed (repeated Jacobian entries are
                               multiplied by their count instead of added up); AUTO: ON                                  */
@@ -204,7 +207,8 @@ typedef struct hamk_options {
   int32_t rkf_park;        /* ON | OFF: QUAD mapping, the adaptive stepper's vectors (y, dydt, k2..k6, trial state) wait in
                               LDS and in a run-time-indexed private array instead of competing with the right-hand side
                               for registers; AUTO: n >= 17.  Lane mapping: follows rkf_body (the stage-loop body IS the
-                              parked one since round 4); reported, not settable                                          */
+                              parked one since round 4): reported; a value that contradicts rkf_body is refused with
+                              HAMK_ERR_UNSUPPORTED when the lane specialisation is built                                 */
   int32_t _align;          /* keeps ensemble_size 8-byte aligned; 0                                                     */
   int64_t ensemble_size;   /* mapping = AUTO only: the size of the WHOLE ensemble this handle's launches are pieces of (a shard
                               of a multi-GPU run, a chunk of a host loop).  AUTO picks the mapping from the ensemble size, and

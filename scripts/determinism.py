@@ -3,6 +3,7 @@ the stage-loop body?  (The unrolled RKF45 kernel of a random test system was fou
 run-to-run different, wrong results on some lanes: a code-generation hazard, not a data race --
 every lane is independent.)   python scripts/determinism.py <system|randomK> [B] [reps]"""
 import os, sys
+os.environ["HAMK_TEST_OVERRIDES"] = "1"               # this script drives libhamk.so through its HAMK_* test overrides (DESIGN.md section 7)
 os.environ.setdefault("HAMK_MAX_SUBSTEPS", "2000")
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -185,7 +185,7 @@ def rk4_step_stats(spec, system=None):
         flags = (os.environ.get("HAMK_HIPRTC_FLAGS", "") + " -DHAMK_PROBE_NO_SLOWPATH").strip()
         if trig is not None:
             flags += f" -DHAMK_PROBE_TRIG={trig}"
-        env = dict(base_env, HAMK_HIPRTC_FLAGS=flags)
+        env = dict(base_env, HAMK_HIPRTC_FLAGS=flags, HAMK_TEST_OVERRIDES="1")
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -244,7 +244,7 @@ def rkf45_attempt_stats(spec, system=None):
     env = {"HAMK_RKF_LOOP": "1" if ("RKF_STAGE_LOOP = true" in src or quad) else "0", "HAMK_WAVE": "0", "HAMK_QUAD": "1" if quad else "0",
            "HAMK_RKF_PARK": "1" if ("HAMK_RKF_PARK 1" in src or "HAMK_QUAD_RKF_PARK 1" in src) else "0",
            "HAMK_AD_MODE": "H" if "MODE_H = true" in src else ("R" if "MODE_R = true" in src else "D"),
-           "HAMK_HIPRTC_FLAGS": (os.environ.get("HAMK_HIPRTC_FLAGS", "") + " -DHAMK_PROBE_NO_SLOWPATH -DHAMK_PROBE_MARK").strip()}
+           "HAMK_TEST_OVERRIDES": "1", "HAMK_HIPRTC_FLAGS": (os.environ.get("HAMK_HIPRTC_FLAGS", "") + " -DHAMK_PROBE_NO_SLOWPATH -DHAMK_PROBE_MARK").strip()}
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:

@@ -4,6 +4,7 @@
 # traces).  Results land in gpurun_out/prof_<tag>_<system>/ ; scripts/summarize_profile.py turns them
 # into profiles/<tag>_<system>_* and profiles/pmc_traffic_<system>.json.
 set -u
+export HAMK_TEST_OVERRIDES=1   # HAMK_SELFCHECK / HAMK_HIPRTC_FLAGS below are test overrides: read only when asked for
 TAG=${1:-r02}
 SYS=${2:-doublePendulum}
 shift 2 2>/dev/null

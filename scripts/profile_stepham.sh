@@ -2,6 +2,7 @@
 # GPU box: rocprofv3 passes for the reference's own stepper (hamk_rkf45_k, bench.py --integrator stepham).
 # usage: scripts/profile_stepham.sh <tag> <system> [bench args...]; results in gpurun_out/prof_<tag>_<system>_stepham/
 set -u
+export HAMK_TEST_OVERRIDES=1   # HAMK_SELFCHECK / HAMK_HIPRTC_FLAGS below are test overrides: read only when asked for
 TAG=${1:-r03}
 SYS=${2:-doublePendulum}
 shift 2 2>/dev/null

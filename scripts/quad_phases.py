@@ -5,6 +5,7 @@ prints the instruction classes between consecutive markers.
   python scripts/quad_phases.py chain32"""
 import collections
 import os
+os.environ["HAMK_TEST_OVERRIDES"] = "1"               # this script drives libhamk.so through its HAMK_* test overrides (DESIGN.md section 7)
 import sys
 import tempfile
 

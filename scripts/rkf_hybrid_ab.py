@@ -4,6 +4,7 @@
 every row in LDS.  python scripts/rkf_hybrid_ab.py [--compile-only] > gpurun_out/r04_rkf_hybrid_ab.jsonl"""
 import json
 import os
+os.environ["HAMK_TEST_OVERRIDES"] = "1"               # this script drives libhamk.so through its HAMK_* test overrides (DESIGN.md section 7)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

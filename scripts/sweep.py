@@ -1,6 +1,7 @@
 """GPU: throughput of hamk_rk4_steps per system x code-generation variant
 (HAMK_AD_MODE = H|D, HAMK_RK4_LOOP = 0|1; read by hamk_system_create)."""
 import os, sys, time, json
+os.environ["HAMK_TEST_OVERRIDES"] = "1"               # this script drives libhamk.so through its HAMK_* test overrides
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hamilton_amd import api, examples as E

@@ -15,6 +15,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+os.environ["HAMK_TEST_OVERRIDES"] = "1"               # this script drives libhamk.so through its HAMK_* test overrides
 import sys
 import time
 

@@ -3,6 +3,7 @@ default) against the anchor scheme it replaces (HAMK_TRIG_LUT=0: full evaluation
 step's midpoint for 1-4 sincos sites, full evaluations beyond): RK4 steps/s at BASELINE ensemble size.
 Output: one JSON line per measurement (profiles/r02_sweep_trig.jsonl)."""
 import json, os, sys
+os.environ["HAMK_TEST_OVERRIDES"] = "1"               # drives libhamk.so through its HAMK_* test overrides (DESIGN.md section 7)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hamilton_amd import api, examples as E

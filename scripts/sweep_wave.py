@@ -1,6 +1,7 @@
 """GPU: throughput of the wave-cooperative path (BASELINE.json config 5: N-link chain,
 B = 65,536, dt = 0.005) and the lane path on the sizes both support."""
 import os, sys, time, json
+os.environ["HAMK_TEST_OVERRIDES"] = "1"               # this script drives libhamk.so through its HAMK_* test overrides
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hamilton_amd import api, examples as E

@@ -5,6 +5,7 @@ compiling.  Use on the GPU side with HAMK_CACHE_DIR=$PWD/.hamk_cache.
   python scripts/warm_cache.py [-j 8] [--tests-only]"""
 import multiprocessing as mp
 import os
+os.environ["HAMK_TEST_OVERRIDES"] = "1"               # this script drives libhamk.so through its HAMK_* test overrides (DESIGN.md section 7)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -12,6 +12,9 @@ if ROOT not in sys.path:
 # a kernel gone wrong must end: cap the adaptive stepper's sub-step budget for the whole suite
 # (the default, 2^24 attempts per trajectory and call, can keep a GPU busy for minutes)
 os.environ.setdefault("HAMK_MAX_SUBSTEPS", "20000")
+# the HAMK_* environment overrides (which mapping, which body, which sincos ...) are read by libhamk.so only in a process that
+# asks for them: the test suites do; a product host does not
+os.environ["HAMK_TEST_OVERRIDES"] = "1"
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 REFERENCE_SYSTEMS = ["pendulum", "doublePendulum", "room", "twoBody", "spring", "bezier"]

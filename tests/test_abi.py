@@ -84,7 +84,7 @@ def test_defaults_of_the_wave_kernels(hamk_lib, monkeypatch):
     n = 32 the RK4 kernel capped for two wavefronts per SIMD."""
     from hamilton_amd import _abi, api
     mid = api.system_from_spec(E.get("chain20"), {"mapping": _abi.MAP_WAVE})
-    assert "hamk_wave.hpp" in mid.source and "HAMK_RK4_MIN_WAVES_BIG" not in mid.source and mid.options()["wave_blocked"] == _abi.ON
+    assert "hamk_wave.hpp" in mid.source and "HAMK_RK4_MIN_WAVES_BIG" not in mid.source
     big = api.system_from_spec(E.get("chain33")).source
     assert "#define HAMK_RK4_MIN_WAVES_BIG 2" in big
     monkeypatch.setenv("HAMK_WAVE", "1")
@@ -247,7 +247,12 @@ def test_mapping_defaults_by_size_and_structure(hamk_lib):
     for name, want in (("spring", _abi.OFF), ("chain4", _abi.ON), ("threeBodyPolar", _abi.ON), ("chain8", _abi.ON), ("chain16", _abi.ON), ("chain20", _abi.ON), ("chain33", _abi.OFF)):
         assert api.system_from_spec(E.get(name)).options(65536)["rkf_park"] == want, name
     assert api.system_from_spec(E.get("chain14")).options(8192)["rkf_park"] == _abi.OFF          # (the quad module of a small ensemble: n < 17)
-    assert api.system_from_spec(E.get("chain8"), {"rkf_park": _abi.OFF}).options()["rkf_park"] == _abi.ON
+    # lane mapping: rkf_park follows rkf_body; an explicit value that contradicts it is REFUSED (round 5; it used to be ignored)
+    with pytest.raises(api.HamkError, match="rkf_park = OFF cannot be honoured"):
+        api.system_from_spec(E.get("chain8"), {"rkf_park": _abi.OFF})
+    with pytest.raises(api.HamkError, match="rkf_park = ON cannot be honoured"):
+        api.system_from_spec(E.get("doublePendulum"), {"rkf_park": _abi.ON})
+    assert api.system_from_spec(E.get("chain8"), {"rkf_park": _abi.ON}).options()["rkf_park"] == _abi.ON
     assert api.system_from_spec(E.get("chain20"), {"rkf_park": _abi.OFF}).options()["rkf_park"] == _abi.OFF
     s = api.system_from_spec(E.get("chain20"))
     assert s.options()["mapping"] == _abi.MAP_QUAD and s.lanes_per_trajectory == 4 and "hamk_quad.hpp" in s.source
@@ -275,3 +280,39 @@ def test_systems_with_a_non_positive_inertia_run_on_kernels_that_pivot(hamk_lib,
     assert e.value.code == _abi.HAMK_ERR_UNSUPPORTED and "pivot" in str(e.value)
     monkeypatch.setenv("HAMK_QUAD", "1")                       # the test override does not reach such a system either
     assert api.system_from_spec(E.get("chain12~mixed")).options(8192)["mapping"] == _abi.MAP_LANE
+
+
+def test_environment_overrides_need_the_test_switch(hamk_lib):
+    """HAMK_WAVE / HAMK_AD_MODE / ... change what libhamk.so runs ONLY in a process that sets HAMK_TEST_OVERRIDES=1 (this
+    suite's conftest does); a host process that merely carries such a variable gets what hamk_options says."""
+    import subprocess
+    import sys
+    prog = ("import sys; sys.path.insert(0, %r)\n"
+            "from hamilton_amd import api, examples\n"
+            "o = api.system_from_spec(examples.get('spring')).options()\n"
+            "print(o['mapping'], o['ad_mode'], o['rk4_body'])\n") % ROOT
+    base = {k: v for k, v in os.environ.items() if not k.startswith("HAMK_") or k in ("HAMK_CACHE_DIR",)}
+    forced = dict(base, HAMK_WAVE="1", HAMK_AD_MODE="D", HAMK_RK4_LOOP="1")
+    plain = subprocess.check_output([sys.executable, "-c", prog], env=base, text=True).split()
+    ungated = subprocess.check_output([sys.executable, "-c", prog], env=forced, text=True).split()
+    gated = subprocess.check_output([sys.executable, "-c", prog], env=dict(forced, HAMK_TEST_OVERRIDES="1"), text=True).split()
+    from hamilton_amd import _abi
+    assert ungated == plain == [str(_abi.MAP_LANE), str(_abi.AD_H), str(_abi.BODY_UNROLLED)]
+    assert gated == [str(_abi.MAP_WAVE), str(_abi.AD_D), str(_abi.BODY_STAGE_LOOP)]
+
+
+def test_options_of_another_layout_revision_are_refused(hamk_lib):
+    """hamk_options carries its layout revision (HAMK_OPTIONS_VERSION; round 5 removed the dead field wave_blocked): a struct
+    filled in against another header -- or never initialised -- is refused instead of being read field-shifted."""
+    from hamilton_amd import _abi, api
+    o = _abi.HamkOptions()
+    hamk_lib.hamk_options_init(ctypes.byref(o))
+    assert o.size == 128 and o.version == _abi.OPTIONS_VERSION
+    assert "wave_blocked" not in dict(_abi.HamkOptions._fields_)
+    spec = E.get("pendulum")
+    good = api.system_from_spec(spec, {"mapping": _abi.MAP_LANE})
+    assert good.options()["mapping"] == _abi.MAP_LANE
+    bad = _abi.HamkOptions(mapping=_abi.MAP_LANE)
+    bad.version = 3                                          # e.g. a round-4 struct whose second word was `mapping = QUAD`
+    with pytest.raises(api.HamkError, match="layout revision"):
+        api.system_from_spec(spec, bad)
