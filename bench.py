@@ -57,6 +57,45 @@ BASELINE_CONFIG = {"doublePendulum": ("configs[1]", 1 << 20), "twoBody": ("confi
                    "chain32": ("configs[4]", 1 << 16)}
 
 
+class ClockSampler:
+    """Shader clock of one GPU during the timed region, from the driver's own table (sysfs pp_dpm_sclk: the level marked `*`),
+    sampled from a host thread every few milliseconds.  The chip clocks to its power budget (fp64-dense kernels sustain ~1.9-2.0
+    of the nominal 2.4 GHz), so issue fractions priced at the nominal clock understate what the SIMDs really did."""
+    def __init__(self, index: int):
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.path = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        self.samples, self._stop, self._t = [], False, None
+
+    def _read(self):
+        try:
+            for ln in open(self.path).read().splitlines():
+                if ln.strip().endswith("*"):
+                    return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except Exception:                                        # noqa: BLE001
+            return None
+        return None
+
+    def _run(self):
+        while not self._stop:
+            v = self._read()
+            if v:
+                self.samples.append(v)
+            time.sleep(0.002)
+
+    def start(self):
+        if self.path:
+            import threading
+            self._t = threading.Thread(target=self._run, daemon=True)
+            self._t.start()
+
+    def stop(self):
+        self._stop = True
+        if self._t:
+            self._t.join(timeout=1.0)
+        return (sum(self.samples) / len(self.samples)) if self.samples else None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +120,11 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path "
                          "(barrier, max-over-ranks, final all_gather) on a 1-GPU box")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of a multi-rank run: nccl (= RCCL over xGMI; the driver's 1/2/4/8-GPU runs) or gloo -- "
+                         "collectives on host copies, ranks may SHARE a GPU (rank r uses cuda:(r mod device count)): the whole "
+                         "WORLD_SIZE > 1 path on a 1-GPU box (tests/test_gpu_configs.py)")
+    ap.add_argument("--dump-state", default=None, help="rank 0 writes the final state of the WHOLE ensemble (after the gather) to this .npz")
     ap.add_argument("--drift-tol", type=float, default=1e-3,
                     help="per-launch energy check of the timed launches (HAMK_ST_DRIFT); 0 = plain hamk_rk4_steps")
     a = ap.parse_args()
@@ -242,9 +286,46 @@ def probe_reference_toolchain():
     if not available:
         out["note"] = "reference_haskell: unavailable (toolchain absent) -- cpu_baseline is the C restatement (kind: port)"
     else:
-        out["note"] = ("toolchain present; building hamilton needs its Hackage dependencies (ad, hmatrix, hmatrix-gsl, vector-sized) "
-                       "offline -- not attempted by bench.py; see bindings/haskell/ and INTEGRATION.md")
+        out.update(time_reference_haskell())
     return out
+
+
+def time_reference_haskell(timeout_s: float = 900.0):
+    """SURVEY.md section 8d, CPU-baseline step (1), for a box that HAS the reference's toolchain: build
+    bindings/haskell/bench (C1.hs: the reference's double pendulum through the reference's own `stepHam` / `hamEqs`, i.e. ad +
+    hmatrix + hmatrix-gsl) against a checkout of mstksg/hamilton (HAMILTON_SRC, default /root/reference) with
+    `cabal build --offline` in a scratch copy, run it, and return its JSON line as `measured`.  Mechanical on purpose: any
+    failure (no Hackage packages offline, no checkout) is reported with the tail of cabal's output, never raised.  This image
+    has no GHC: the function has never run here."""
+    import shutil
+    import subprocess
+    import tempfile
+    src = os.environ.get("HAMILTON_SRC", "/root/reference")
+    bench_dir = os.path.join(ROOT, "bindings", "haskell", "bench")
+    if not os.path.exists(os.path.join(src, "hamilton.cabal")):
+        return {"note": f"toolchain present, but no checkout of mstksg/hamilton at {src} (set HAMILTON_SRC)"}
+    work = tempfile.mkdtemp(prefix="hamk_c1_")
+    try:
+        for f in ("C1.hs", "hamilton-bench.cabal", "cabal.project"):
+            shutil.copy(os.path.join(bench_dir, f), work)
+        with open(os.path.join(work, "cabal.project.local"), "w") as fh:
+            fh.write(f"packages: {src}\n")
+        t0 = time.perf_counter()
+        b = subprocess.run(["cabal", "build", "--offline", "c1"], cwd=work, capture_output=True, text=True, timeout=timeout_s)
+        if b.returncode != 0:
+            return {"note": "toolchain present; `cabal build --offline c1` failed (Hackage dependencies of hamilton not available offline?)",
+                    "cabal_tail": (b.stdout + b.stderr)[-1500:]}
+        exe = subprocess.run(["cabal", "list-bin", "c1"], cwd=work, capture_output=True, text=True, timeout=120).stdout.strip()
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=timeout_s)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"note": "c1 built but did not produce its line", "stderr_tail": r.stderr[-800:]}
+        return {"note": "measured: the reference's own ad + hmatrix + hmatrix-gsl path on this box (bindings/haskell/bench/C1.hs)",
+                "measured": json.loads(line[-1]), "build_seconds": time.perf_counter() - t0}
+    except Exception as e:                                       # noqa: BLE001 -- reported, not raised
+        return {"note": f"toolchain present; building / running the Haskell bench failed: {e!r}"}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def c1_leg(spec, s):
@@ -392,9 +473,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if a.dist_backend == "gloo":
+            local_rank = local_rank % max(1, torch.cuda.device_count())      # ranks may share a GPU; collectives run on host copies
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if (dist is not None and a.dist_backend == "gloo") else dev        # where collective buffers live
 
     spec = examples.get(a.system)
     dt = a.dt if a.dt is not None else spec.dt
@@ -440,6 +526,8 @@ def main():
     status_or.zero_()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    clk = ClockSampler(local_rank)
+    clk.start()
     t0 = time.perf_counter()
     ev0.record()                                          # kernels launch on torch's current stream
     for _ in range(a.steps):
@@ -448,10 +536,11 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    sclk_mhz = clk.stop()
     barrier()
     kernel_s = ev0.elapsed_time(ev1) * 1e-3 / max(1, a.steps)     # avg launch duration, HIP events
     if dist is not None:
-        t = torch.tensor([elapsed, kernel_s], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, kernel_s], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_s = float(t[0]), float(t[1])
 
@@ -468,16 +557,20 @@ def main():
     if dist is not None:                                  # the path's only collective: final gather over xGMI
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        gq, gp = ensemble.gather_state(state.positions, state.momenta, dist, world)
+        gq, gp = ensemble.gather_state(state.positions.to(cdev), state.momenta.to(cdev), dist, world)
         assert gq.shape == (n, world * B)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        t = torch.tensor([bad, drift_flagged, bad_drift], dtype=torch.int64, device=dev)
+        t = torch.tensor([bad, drift_flagged, bad_drift], dtype=torch.int64, device=cdev)
         dist.all_reduce(t)
         bad, drift_flagged, bad_drift = int(t[0]), int(t[1]), int(t[2])
-        t = torch.tensor([drift], dtype=torch.float64, device=dev)
+        t = torch.tensor([drift], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         drift = float(t[0])
+    else:
+        gq, gp = state.positions, state.momenta
+    if rank == 0 and a.dump_state:
+        np.savez(a.dump_state, q=gq.cpu().numpy(), p=gp.cpu().numpy())
 
     if rank == 0:
         total = a.batch if a.scaling == "strong" else world * a.batch
@@ -519,7 +612,10 @@ def main():
                     "mfma_insts_per_wave_step": isa["mfma_per_wave_step"], "lds_insts_per_wave_step": isa["lds_per_wave_step"],
                     "scratch_insts_per_wave_step": isa["scratch_per_wave_step"],
                     "valu_issue_frac": wave_steps_per_s * isa["valu_per_wave_step"] * 4.0 / (N_SIMD * NOMINAL_HZ),
-                    "valu_issue_frac_note": "VALU wave-instructions/s x 4 cycles / (1024 SIMDs x 2.4 GHz nominal); the chip sustains ~1.96 GHz under fp64 load (profiles/r01_summary.json)",
+                    "valu_issue_frac_at_measured_clock": (wave_steps_per_s * isa["valu_per_wave_step"] * 4.0 / (N_SIMD * sclk_mhz * 1e6)) if sclk_mhz else None,
+                    "sclk_mhz_during_timed_region": sclk_mhz,
+                    "valu_issue_frac_note": "VALU wave-instructions/s x 4 cycles / (1024 SIMDs x clock): at the 2.4 GHz nominal clock, and at the shader clock the "
+                                            "driver reported while the timed launches ran (sysfs pp_dpm_sclk, sampled every 2 ms; null where the file is absent)",
                     "count_source": isa["source"], "loop": isa["loop_is"]})
         cfg_id, cfg_B = BASELINE_CONFIG.get(a.system, (None, None))
         out = {
@@ -533,7 +629,10 @@ def main():
                        "kernel_path": "wave-cooperative" if wave else ("four lanes per trajectory" if lanes_per_traj == 4 else "one trajectory per lane"),
                        "parallelism": f"ensemble-shard x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # the fraction that BINDS, next to the yardstick's (details in roofline.fp64)
+                         "fp64_frac_of_peak": fp64.get("frac_of_peak"), "fp64_valu_issue_frac_at_measured_clock": fp64.get("valu_issue_frac_at_measured_clock"),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "hamk_rk4_steps_k", "kernel_ms": kernel_s * 1e3,
                          "algorithmic_bytes_per_trajectory_step": alg_bytes,
                          "algorithmic_bytes_per_launch": alg_bytes * B * a.rk4_per_step,

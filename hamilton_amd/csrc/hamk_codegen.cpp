@@ -94,7 +94,7 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
                      const std::vector<std::vector<int>>* sink_outs = nullptr,
                      const std::vector<std::string>* input_exprs = nullptr, const char* tc_name = "tc",
                      std::vector<int>* slot_operand = nullptr, const char* trig_mode = "TRIG",
-                     const std::vector<int>* shared_f_slot = nullptr) {
+                     const std::vector<int>* shared_f_slot = nullptr, std::vector<int>* put_order = nullptr) {
   // pair SIN/COS of a shared operand: one sincos
   std::vector<int> sin_of(nops, -1), cos_of(nops, -1);
   for (int i = 0; i < nops; ++i) {
@@ -162,7 +162,10 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
       // a fused sincos defines two values at once: flush every defined value's outputs
       for (int j = 0; j < nops; ++j)
         if (done[j] == 1) {
-          for (int k : (*sink_outs)[j]) o << "    sink.template put<" << k << ", " << put_seq++ << ">(hamk::lift<A>(" << v(j) << "));\n";
+          for (int k : (*sink_outs)[j]) {
+            o << "    sink.template put<" << k << ", " << put_seq++ << ">(hamk::lift<A>(" << v(j) << "));\n";
+            if (put_order) put_order->push_back(k);
+          }
           done[j] = 2;
         }
     }
@@ -483,13 +486,14 @@ int distinct_jacobian_entries(const SystemDesc& d) {
 std::string generate_source(const SystemDesc& d) {
   std::ostringstream o;
   o << "// generated by libhamk (hamk_codegen.cpp) from the expression tape of one System " << d.m << " " << d.n << "\n";
-  if (d.rk4_min_waves > 1) o << "#define HAMK_RK4_MIN_WAVES " << d.rk4_min_waves << "\n#define HAMK_RK4_MIN_WAVES_BIG " << d.rk4_min_waves << "\n";
+  if (d.rk4_min_waves > 1 || d.wave) o << "#define HAMK_RK4_MIN_WAVES " << d.rk4_min_waves << "\n#define HAMK_RK4_MIN_WAVES_BIG " << d.rk4_min_waves << "\n";
   if (d.wave && d.n > 32 && d.rk4_min_waves > 1) o << "#define HAMK_RKF_MIN_WAVES " << d.rk4_min_waves << "\n";
   o << "#define HAMK_USE_LUT " << d.use_lut << "\n";
   o << "#define HAMK_K_REASSOC " << (d.k_reassoc ? 1 : 0) << "\n";
   if (d.rk4_park && !d.wave) o << "#define HAMK_RK4_PARK 1\n";
   if (d.mapping == HAMK_MAP_QUAD) o << "#define HAMK_QUAD_RKF_PARK " << (d.rkf_park ? 1 : 0) << "\n";
   if (d.mapping == HAMK_MAP_LANE && d.trig_const_vgpr && d.use_lut != 0) o << "#define HAMK_TRIG_CONST_VGPR 1\n";
+  if (d.mapping == HAMK_MAP_LANE && d.pair_rows) o << "#define HAMK_PAIR_ROWS 1\n";
   if (d.mapping == HAMK_MAP_LANE && d.rkf_two_waves)
     o << "#define HAMK_RKF_MIN_WAVES_LANE 2\n#define HAMK_RKF_LDS_BUDGET 36\n#define HAMK_RKF_ROWS_IN_REGS 1\n";
   // (sin, cos)(i 2pi/512), correctly rounded from 80-bit: the constant data behind sincos_lut's LDS table
@@ -556,7 +560,8 @@ std::string generate_source(const SystemDesc& d) {
   o << "  template <class A, int TRIG, class IN, class TC, class Sink> __device__ __forceinline__ static void coords_sink(const IN& in, TC& tc, Sink& sink) {\n";
   std::vector<std::vector<int>> sink_outs(d.f_ops.size());
   for (int k = 0; k < d.m; ++k) sink_outs[d.f_outs[k]].push_back(k);
-  emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f", &sink_outs);
+  std::vector<int> put_order;                               // output index of the SEQ-th put
+  emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f", &sink_outs, nullptr, "tc", nullptr, "TRIG", nullptr, &put_order);
   o << "  }\n";
   // f with a sink, followed by the potential on the same SSA values (u . f when U is cartesian):
   // no array of M outputs is ever materialised
@@ -583,6 +588,31 @@ std::string generate_source(const SystemDesc& d) {
   if (ntrig_f == 0) o << "-1";
   o << "};\n    return w[slot];\n  }\n";
   o << "  static constexpr bool TRIG_ALL_INPUTS = " << (all_inputs ? "true" : "false") << ";\n";
+  if (d.wave) {
+    // Structure of the Jacobian, for the wave kernels' accumulation of K = J^T M J on the matrix cores (hamk_wave.hpp SinkK):
+    // which inputs output k depends on at all, as a range [dep_lo, dep_hi] of input indices (-1 / -1: none), and which output
+    // the SEQ-th put of coords_sink delivers.  A 16-column block in which all four staged rows are structurally zero
+    // contributes nothing and is skipped (an N-link chain: x_k, y_k depend on q_0..q_k -- half the blocks).
+    const int nf = (int)d.f_ops.size();
+    std::vector<int> lo(nf, 1 << 30), hi(nf, -1);
+    for (int i = 0; i < nf; ++i) {
+      const hamk_op& p = d.f_ops[i];
+      if (p.op == HAMK_OP_CONST) continue;
+      if (p.op == HAMK_OP_INPUT) { lo[i] = hi[i] = p.a; continue; }
+      lo[i] = lo[p.a]; hi[i] = hi[p.a];
+      if (is_binary(p.op)) { lo[i] = std::min(lo[i], lo[p.b]); hi[i] = std::max(hi[i], hi[p.b]); }
+    }
+    auto table = [&](const char* name, const std::vector<int>& w) {
+      o << "  __device__ __forceinline__ static constexpr int " << name << "(int k) {\n    constexpr int w[" << w.size() << "] = {";
+      for (size_t k = 0; k < w.size(); ++k) o << (k ? ", " : "") << w[k];
+      o << "};\n    return w[k];\n  }\n";
+    };
+    std::vector<int> dlo(d.m), dhi(d.m);
+    for (int k = 0; k < d.m; ++k) { const int v = d.f_outs[k]; dlo[k] = hi[v] < 0 ? -1 : lo[v]; dhi[k] = hi[v]; }
+    table("dep_lo", dlo);
+    table("dep_hi", dhi);
+    table("seq_out", put_order);                            // (recorded by emit_body as it numbered the puts)
+  }
   emit_reverse(o, d);
   o << "  static constexpr int NTRIG_F = " << ntrig_f << ";\n";
   o << "  static constexpr int NTRIG_U = " << ntrig_u << ";\n";

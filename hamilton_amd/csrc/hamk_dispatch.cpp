@@ -499,6 +499,14 @@ static void derive_body_fields(const hamk_system* s, SystemDesc& d) {
   // heavy tape may not fit 256 registers -- variant_for looks at the built kernel and goes back to one wavefront where the
   // cap made it spill (rkf_two_waves_off); HAMK_RKF_TWO_WAVES=0|1 is the test override.
   d.rkf_two_waves = mapping == HAMK_MAP_LANE && d.rkf_stage_loop && n <= 7 && !d.rkf_two_waves_off;
+  // Parked stepper, n = 8, 9 (four rows of 2n doubles in LDS: y, dydt, k2, k3 -- the systems whose attempt moves the most LDS
+  // bytes per right-hand side): components stored in PAIRS, [j / 2][lane][2], so that a row is read by ds_read_b128 instead of
+  // ds_read2st64_b64 -- the same 16 bytes per lane at half the LDS-array cycles, and the one-wavefront-per-SIMD rate of the
+  // 16-byte read is the higher one.  Measured (profiles/r05b_pair_rows_stepham.jsonl, stepHam dt, B = 65 536, bitwise equal
+  // results): chain8 +3.1 %, chain9 +5.9 %; chain10 -1.3 %, chain11..13 +1.1 / +1.5 / 0 % (three and two LDS rows: left alone);
+  // the RK4 kernel that parks its state (n >= 14) loses 1-4 % to the 16-byte stores (r05a_pair_rows_ab.jsonl): not there.
+  d.pair_rows = mapping == HAMK_MAP_LANE && d.rkf_stage_loop && (n == 8 || n == 9);
+  if (env_flag("HAMK_PAIR_ROWS", &b)) d.pair_rows = b && mapping == HAMK_MAP_LANE;
   if (env_flag("HAMK_RKF_TWO_WAVES", &b)) d.rkf_two_waves = b && mapping == HAMK_MAP_LANE && d.rkf_stage_loop && n <= 7;
 }
 
@@ -533,7 +541,7 @@ static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4,
   // spilled registers -- beats one wavefront with everything in registers: chain48 1.05e7 -> 1.45e7, chain64
   // 7.6e6 -> 9.5e6 RK4 steps/s on MI355X (profiles/r02_wave_blocked.jsonl)
   d.rk4_min_waves = 1;
-  if (d.wave && n > 32) d.rk4_min_waves = 2;
+  if (d.wave) d.rk4_min_waves = 2;                          // (n <= 32: two trajectories per wavefront at 228 registers, hamk_wave.hpp)
   if (o.rk4_min_waves > 0) d.rk4_min_waves = o.rk4_min_waves;
   d.k_reassoc = true;
   if (o.k_reassoc != HAMK_AUTO) d.k_reassoc = o.k_reassoc == HAMK_ON;
@@ -613,6 +621,18 @@ int variant_for(hamk_system* s, int64_t B, int kernel, Variant** out) {
       vgpr_spill_count(v->use2[K_RKF45] ? v->code2 : v->code, kKernelNames[K_RKF45]) > 32) {
     v->desc.rkf_two_waves_off = true;
     derive_body_fields(s, v->desc);
+    v->source = generate_source(v->desc);
+    rc = build_code(v, s->cache_on, build_force(s));
+    if (rc != HAMK_OK) { delete v; return rc; }
+  }
+  // wave-cooperative RK4 kernel: two wavefronts per SIMD (256 registers) is the measured default -- the chains spill a few hundred
+  // registers under the cap and still gain (chain48 1.32e7 vs 1.06e7 steps/s, chain64 8.1e6 vs 7.6e6) -- but a system whose tape
+  // is heavy (a dense coordinate map: every lane carries one-direction jets of n^2 terms) spills by the thousand and waits on
+  // scratch for three quarters of its cycles: dense32 967 spilled registers, 490 GB of HBM traffic per launch, 4.4e6 steps/s at
+  // two wavefronts against 1.30e7 at one with 6 spilled (profiles/r05c_wave_probe.jsonl; dense24, 241 spilled: a tie).
+  if (mapping == HAMK_MAP_WAVE && s->opt.rk4_min_waves == 0 && v->desc.rk4_min_waves > 1 &&
+      vgpr_spill_count(v->use2[K_RK4] ? v->code2 : v->code, kKernelNames[K_RK4]) > 512) {
+    v->desc.rk4_min_waves = 1;
     v->source = generate_source(v->desc);
     rc = build_code(v, s->cache_on, build_force(s));
     if (rc != HAMK_OK) { delete v; return rc; }

@@ -27,6 +27,7 @@ struct SystemDesc {
   bool rk4_park = false;        // lane mapping: RK4 stage loop parks y / acc in LDS across the right-hand side
   bool trig_const_vgpr = false; // lane mapping, 8 <= n <= 14: sincos_lut's fp64 literals live in vector registers (hamk_device.hpp LutK)
   bool rkf_two_waves = false;   // lane mapping, n <= 7: the parked RKF45 stepper at two wavefronts per SIMD (rows beyond a halved LDS share in registers)
+  bool pair_rows = false;       // lane mapping, n = 8, 9: the parked stepper's LDS rows hold components in pairs (16-byte accesses; hamk_device.hpp HAMK_PAIR_ROWS)
   bool rkf_two_waves_off = false;  // ... built that way, its 256-register cap made THIS system's stepper spill: one wavefront (hamk_dispatch.cpp variant_for)
   std::vector<double> inertia;
   std::vector<hamk_op> f_ops;

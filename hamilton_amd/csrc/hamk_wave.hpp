@@ -89,6 +89,18 @@ HAMK_DEV double bcast4(double x, int grp4, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// Value of lane `lane` (wave-uniform, here always a literal) for every lane of the wavefront: two v_readlane_b32 into a scalar
+// register pair -- no LDS, no counter to wait for.  One trajectory per wavefront (n > 32) exchanges its pivot rows this way.
+HAMK_DEV double read_lane(double x, int lane) {
+#ifdef HAMK_HOST_EMULATION
+  return emu_read_lane(x, lane);
+#else
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+  return __hiloint2double(hi, lo);
+#endif
+}
+
 template <int NP> HAMK_DEV double group_max(double x) {
 #pragma unroll
   for (int off = NP / 2; off > 0; off >>= 1) { const double y = __shfl_xor(x, off, NP); x = (y > x) ? y : x; }
@@ -167,7 +179,7 @@ template <class S, int NP> struct SinkK {
 #endif
     mine[(SEQ & 3) * NP] = v.d[0];
     set_m<SEQ & 3>(S::inertia(K));
-    if constexpr ((SEQ & 3) == 3) flush();
+    if constexpr ((SEQ & 3) == 3) flush<cols_lo(SEQ - 3, SEQ), cols_hi(SEQ - 3, SEQ)>();
   }
   HAMK_DEV void finish() {                                 // M not a multiple of four: zero rows
     if constexpr ((S::M & 3) != 0) {
@@ -176,10 +188,27 @@ template <class S, int NP> struct SinkK {
       if constexpr ((S::M & 3) <= 1) m1 = 0.0;
       if constexpr ((S::M & 3) <= 2) m2 = 0.0;
       m3 = 0.0;
-      flush();
+      flush<cols_lo(S::M - (S::M & 3), S::M - 1), cols_hi(S::M - (S::M & 3), S::M - 1)>();
     }
   }
-  HAMK_DEV void flush() {
+  // Columns in which the rows delivered by puts s0..s1 can be non-zero: output k = S::seq_out(s) depends on the inputs
+  // S::dep_lo(k)..S::dep_hi(k) (generated tables: the structure of the coordinate map, known when the kernels are specialised).
+  HAMK_DEV static constexpr int cols_lo(int s0, int s1) {
+    int lo = NP;
+    for (int s = s0; s <= s1; ++s) { const int k = S::seq_out(s); if (S::dep_hi(k) >= 0 && S::dep_lo(k) < lo) lo = S::dep_lo(k); }
+    return lo;
+  }
+  HAMK_DEV static constexpr int cols_hi(int s0, int s1) {
+    int hi = -1;
+    for (int s = s0; s <= s1; ++s) { const int k = S::seq_out(s); if (S::dep_hi(k) > hi) hi = S::dep_hi(k); }
+    return hi;
+  }
+  // LO..HI: the columns in which the four staged rows can be non-zero.  A 16-column block outside it multiplies zeros: its
+  // operand is not read and its matrix instructions are not issued -- K += J[rows]^T M J[rows] touches only the blocks
+  // (ib, jb) inside the range.  An N-link chain (x_k, y_k depend on q_0..q_k) issues half the MFMAs of a dense map; the
+  // accumulation is bound by the f64 matrix rate (64 cycles per 16x16x4 block product), so that is half its time.
+  template <int LO, int HI> HAMK_DEV void flush() {
+    constexpr int B0 = (HI < 0) ? 0 : LO / 16, B1 = (HI < 0) ? -1 : HI / 16;      // blocks B0..B1 (none: the rows are constants)
     lds_sync();
     // inertia of the row this lane feeds (folds when all are equal).  All four are read
     // unconditionally and blended as VALUES: a conditional read is turned into one read through a
@@ -191,12 +220,13 @@ template <class S, int NP> struct SinkK {
     for (int g = 0; g < G; ++g) {
       double a[NB], am[NB];
 #pragma unroll
-      for (int cb = 0; cb < NB; ++cb) { a[cb] = rd[g * PER + 16 * cb]; am[cb] = m * a[cb]; }
+      for (int cb = 0; cb < NB; ++cb) if (cb >= B0 && cb <= B1) { a[cb] = rd[g * PER + 16 * cb]; am[cb] = m * a[cb]; }
 #pragma unroll
       for (int ib = 0; ib < NB; ++ib)
 #pragma unroll
         for (int jb = ib; jb < NB; ++jb)
-          acc[g][blk_of(ib, jb)] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[ib], a[jb], acc[g][blk_of(ib, jb)], 0, 0, 0);
+          if (ib >= B0 && jb <= B1)
+            acc[g][blk_of(ib, jb)] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[ib], a[jb], acc[g][blk_of(ib, jb)], 0, 0, 0);
     }
     lds_sync();                                            // the next rows overwrite the staging area
   }
@@ -349,6 +379,60 @@ HAMK_DEV void factor_blocked(const Ctx<S>& c, double& dinv, int& st, double& z) 
       }
       lds_sync();
     }
+    if constexpr (G == 1) {
+      // ONE TRAJECTORY PER WAVEFRONT (n > 32): lane i = row i, and the pivot rows travel through SCALAR registers.  Every lane
+      // keeps its WHOLE row segment of the panel -- S[i][c] for the panel's 16 columns c, on both sides of the diagonal (the
+      // mirrored entry of the packed triangle where c > i) -- and eliminates it in full: after the steps before j, lane j's
+      // segment is row j of the Schur complement, and "column j as seen by every row" is that row read lane by lane
+      // (v_readlane_b32, the lane a literal): S[k][j] = S[j][k].  No LDS exchange, no lds_sync per pivot pair -- the panel
+      // version below pays a write -> fence -> broadcast-read round trip per pair of pivots, 32 of them in a row at n = 64, each
+      // of which also drains the scratch traffic of the kernel's spilled registers (the fence waits for every counter):
+      // profiles/r05d_wave_probe.jsonl, the factorisation was 63 % of chain64's launch.  (Rows eliminate with their OWN
+      // multipliers against the pivot ROW: plain Gaussian elimination, L D L^T up to the roundoff by which the two copies of a
+      // symmetric entry differ; the results agree with the exchange version to roundoff, not bitwise.)
+      double row[16];
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        const int cidx = J0 + b;
+        const int hi_ = (li > cidx) ? li : cidx, lo_ = (li > cidx) ? cidx : li;      // (v_max / v_min: no lane mask per column)
+        row[b] = (cidx < N) ? c.tile()[hi_ * (hi_ + 1) / 2 + lo_] : 0.0;
+      }
+#pragma unroll
+      for (int j = J0; j + 1 < J1; j += 2) {
+        const double a = read_lane(row[j - J0], j), b = read_lane(row[j + 1 - J0], j), cc = read_lane(row[j + 1 - J0], j + 1);
+        const double zj = read_lane(z, j), zj1 = read_lane(z, j + 1);
+        const double det = fma(a, cc, -(b * b));
+        ok = ok && (a > 0.0) && (det > 0.0);
+        const double inv_a = frcp(a), inv_det = frcp(det);
+        const double inv_c = a * inv_det;
+        const double l = b * inv_a;
+        const double zj1p = fma(-l, zj, zj1);
+        const double l0 = (li > j) ? row[j - J0] * inv_a : 0.0;
+        const double l1 = (li > j + 1) ? fma(-l0, b, row[j + 1 - J0]) * inv_c : 0.0;
+        if (li == j) { dinv = inv_a; dmine = a; }
+        if (li == j + 1) { dinv = inv_c; dmine = det * inv_a; }
+        z = fma(-l1, zj1p, fma(-l0, zj, z));
+        const double al = fma(-l1, l, l0);
+#pragma unroll
+        for (int k = j + 2; k < J1; ++k) {
+          const double ak = read_lane(row[k - J0], j), bk = read_lane(row[k - J0], j + 1);
+          row[k - J0] = fma(-al, ak, fma(-l1, bk, row[k - J0]));
+#ifndef HAMK_HOST_EMULATION
+          // four columns' worth of scalar pairs at a time: left alone the scheduler reads the whole pivot rows first (56 scalar
+          // registers on top of the kernel's own) and the kernel spills SGPRs by the hundred
+          if (((k - j) & 3) == 1) __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        Lrow[(li > j) ? j : li] = l0;
+        Lrow[(li > j + 1) ? j + 1 : li] = l1;
+      }
+      if (((J1 - J0) & 1) != 0) {                            // last pivot of an odd N: nothing below it
+        const double dj = read_lane(row[J1 - 1 - J0], J1 - 1);
+        ok = ok && (dj > 0.0);
+        if (li == J1 - 1) { dinv = frcp(dj); dmine = dj; }
+      }
+      continue;
+    }
     double row[16];                                          // this lane's entries in the panel's columns (entries beyond li: never used)
 #pragma unroll
     for (int b = 0; b < 16; ++b) row[b] = (J0 + b < N) ? Lrow[J0 + b] : 0.0;
@@ -498,6 +582,10 @@ HAMK_DEV void factor(const Ctx<S>& c, double qi, double& dinv, double& gU, doubl
     dinv = 1.0;
     return;
   }
+#ifdef HAMK_PROBE_SKIP_FACTOR                              // timing probe (scripts/wave_probe.py): wrong results
+  dinv = 1.0;
+  return;
+#endif
   factor_blocked<S>(c, dinv, st, z);
 }
 
@@ -516,6 +604,33 @@ HAMK_DEV double solve_back(const Ctx<S>& c, double dinv, double z) {
   double v = z * dinv;                                     // D y = z
   double* cV = c.gb();
   const double* T = c.tile();
+  if constexpr (Geo<N>::G == 1) {
+    // one trajectory per wavefront: the unknowns already resolved travel through scalar registers (read_lane), L^T is read
+    // from the packed triangle, which is final -- no exchange buffer, no fence between the blocks of four
+#pragma unroll
+    for (int k = N - 1; k >= N - R; --k) {
+      const double vk = read_lane(v, k);
+      if (li < k) v = fma(-T[tri(k, li)], vk, v);
+    }
+#pragma unroll
+    for (int kb = N - R - 4; kb >= 0; kb -= 4) {
+      const double p0 = read_lane(v, kb), p1 = read_lane(v, kb + 1), p2 = read_lane(v, kb + 2), v3 = read_lane(v, kb + 3);
+      const double v2 = fma(-T[tri(kb + 3, kb + 2)], v3, p2);
+      const double v1 = fma(-T[tri(kb + 2, kb + 1)], v2, fma(-T[tri(kb + 3, kb + 1)], v3, p1));
+      const double v0 = fma(-T[tri(kb + 1, kb)], v1, fma(-T[tri(kb + 2, kb)], v2, fma(-T[tri(kb + 3, kb)], v3, p0)));
+      if (li < kb) {
+        v = fma(-T[tri(kb + 3, li)], v3, v);
+        v = fma(-T[tri(kb + 2, li)], v2, v);
+        v = fma(-T[tri(kb + 1, li)], v1, v);
+        v = fma(-T[tri(kb, li)], v0, v);
+      } else {
+        if (li == kb) v = v0;
+        if (li == kb + 1) v = v1;
+        if (li == kb + 2) v = v2;
+      }
+    }
+    return v;
+  }
 #pragma unroll
   for (int k = N - 1; k >= N - R; --k) {                   // the top N mod 4 unknowns one at a time
     HAMK_LOCKSTEP();

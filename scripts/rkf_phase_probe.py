@@ -31,8 +31,8 @@ for a in sys.argv[1:]:
     if a.startswith("--candidate="):                        # --candidate=tag:flags
         tag, fl = a.split("=", 1)[1].split(":", 1)
         CANDIDATES.append((tag, fl.replace("_-D", " -D")))      # "_-D" stands for " -D" (shell quoting)
-PROBES = [("cyc1", "-DHAMK_PROBE_CYC=1"), ("cyc2", "-DHAMK_PROBE_CYC=2")]
-SIZES = [16384, 32768, 65536, 131072]
+PROBES = [] if "--no-probes" in sys.argv else [("cyc1", "-DHAMK_PROBE_CYC=1"), ("cyc2", "-DHAMK_PROBE_CYC=2")]
+SIZES = [65536] if "--one-size" in sys.argv else [16384, 32768, 65536, 131072]
 if not COMPILE_ONLY:
     import torch
 
@@ -97,6 +97,8 @@ for name in SYSTEMS:
             same = bool(torch.equal(s.last_nsub, ref.last_nsub))
             print(json.dumps({"what": "candidate", "system": name, "B": B, "variant": tag, "flags": fl, "ms_best": b2, "ms_median": m2,
                               "calls_per_s": B / (b2 * 1e-3), "vs_shipped": best / b2, "max_abs_diff_to_shipped": d, "same_substeps": same}), flush=True)
+        if not PROBES:
+            continue
         cyc = {}
         for tag, fl in PROBES:
             s = built[tag]

@@ -55,6 +55,13 @@ static inline int __builtin_amdgcn_ds_bpermute(int byte_index, int v) {
   emu_wave_barrier();
   return r;
 }
+static inline double emu_read_lane(double x, int lane) {     // v_readlane_b32 x 2: lane `lane`'s value for every lane
+  emu_wave->xd[emu_lane] = x;
+  emu_wave_barrier();
+  const double r = emu_wave->xd[lane & 63];
+  emu_wave_barrier();
+  return r;
+}
 static inline double __shfl_xor(double x, int off, int width) {
   emu_wave->xd[emu_lane] = x;
   emu_wave_barrier();
