@@ -58,18 +58,30 @@ BASELINE_CONFIG = {"doublePendulum": ("configs[1]", 1 << 20), "twoBody": ("confi
 
 
 class ClockSampler:
-    """Shader clock of one GPU during the timed region, from the driver's own table (sysfs pp_dpm_sclk: the level marked `*`),
+    """Shader clock of one GPU during the timed region, from the driver's own table (sysfs hwmon freq1_input, else pp_dpm_sclk's `*` level, of the card whose PCI address is the CUDA device's),
     sampled from a host thread every few milliseconds.  The chip clocks to its power budget (fp64-dense kernels sustain ~1.9-2.0
     of the nominal 2.4 GHz), so issue fractions priced at the nominal clock understate what the SIMDs really did."""
     def __init__(self, index: int):
         import glob
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.path = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        self.path = None
+        try:                                                     # the card whose PCI address is cuda:index's
+            pr = torch.cuda.get_device_properties(index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+                if os.path.realpath(card).endswith(bdf):
+                    hw = sorted(glob.glob(os.path.join(card, "hwmon", "hwmon*", "freq1_input")))      # current gfx clock, Hz
+                    self.path = hw[0] if hw else os.path.join(card, "pp_dpm_sclk")
+                    break
+        except Exception:                                        # noqa: BLE001 -- no sysfs, older torch: no clock figure
+            self.path = None
         self.samples, self._stop, self._t = [], False, None
 
     def _read(self):
         try:
-            for ln in open(self.path).read().splitlines():
+            txt = open(self.path).read()
+            if self.path.endswith("freq1_input"):
+                return float(txt.strip()) / 1e6
+            for ln in txt.splitlines():
                 if ln.strip().endswith("*"):
                     return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
         except Exception:                                        # noqa: BLE001

@@ -328,6 +328,30 @@ def dense(N: int) -> SystemSpec:
         cite="build-defined (dense-Jacobian benchmark system; no reference counterpart)")
 
 
+def pendulums(N: int) -> SystemSpec:
+    """`pendulumsN`: N UNCOUPLED unit pendulums as one System (2N) N (build-defined test workload): x_k = sin q_k, y_k = -cos q_k,
+    U = 5 sum y_k.  Every output depends on exactly one input, K is diagonal: the wave kernels' accumulation of K issues one
+    16-column block per four rows, at a block offset that grows with k -- the case of `SinkK::flush<LO, HI>` a chain (LO = 0)
+    and a dense map (everything) never reach."""
+    def f(q, o):
+        out = []
+        for k in range(N):
+            out += [o.sin(q[k]), -o.cos(q[k])]
+        return out
+
+    def u(x, o):
+        acc = 0.0
+        for k in range(N):
+            acc = acc + x[2 * k + 1]
+        return 5 * acc
+
+    return SystemSpec(
+        name=f"pendulums{N}", m=2 * N, n=N, inertia=tuple(1.0 + 0.25 * (k % 3) for k in range(2 * N)), f=f, u=u, u_space=U_CARTESIAN,
+        q0=tuple(0.3 for _ in range(N)), qd0=(0.0,) * N,
+        q_box=tuple((-1.5, 1.5) for _ in range(N)), qd_box=tuple((-1.0, 1.0) for _ in range(N)), dt=0.01,
+        cite="build-defined (block-sparse Jacobian test system; no reference counterpart)")
+
+
 REGISTRY = {
     "pendulum": pendulum,
     "doublePendulum": double_pendulum,
@@ -362,6 +386,8 @@ def get(name: str) -> SystemSpec:
         return chain(int(name[5:]))
     if name.startswith("dense"):
         return dense(int(name[5:]))
+    if name.startswith("pendulums"):
+        return pendulums(int(name[9:]))
     return REGISTRY[name]()
 
 

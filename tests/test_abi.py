@@ -80,13 +80,22 @@ def test_sizes_beyond_the_kernels_are_refused(hamk_lib):
 
 def test_defaults_of_the_wave_kernels(hamk_lib, monkeypatch):
     """What the library chooses for n > 16 on the wave mapping (each choice measured on MI355X): LDL^T in panels of 16
-    with MFMA trailing updates -- the only factorisation since round 4, a small forced system being one panel --; beyond
-    n = 32 the RK4 kernel capped for two wavefronts per SIMD."""
+    with MFMA trailing updates -- the only factorisation since round 4, a small forced system being one panel --; the RK4
+    kernel capped for two wavefronts per SIMD (stated in the generated source and reported since round 5), unless the host asks
+    for one; the structure of the Jacobian handed to the matrix-core accumulation of K."""
     from hamilton_amd import _abi, api
     mid = api.system_from_spec(E.get("chain20"), {"mapping": _abi.MAP_WAVE})
-    assert "hamk_wave.hpp" in mid.source and "HAMK_RK4_MIN_WAVES_BIG" not in mid.source
+    assert "hamk_wave.hpp" in mid.source and "#define HAMK_RK4_MIN_WAVES 2" in mid.source and mid.options()["rk4_min_waves"] == 2
+    one = api.system_from_spec(E.get("chain20"), {"mapping": _abi.MAP_WAVE, "rk4_min_waves": 1})
+    assert "#define HAMK_RK4_MIN_WAVES 1" in one.source and one.options()["rk4_min_waves"] == 1
     big = api.system_from_spec(E.get("chain33")).source
     assert "#define HAMK_RK4_MIN_WAVES_BIG 2" in big
+    # chain: x_k, y_k depend on q_0..q_k -- the tables SinkK::flush reads its block range from
+    import re
+    hi = [int(x) for x in re.search(r"dep_hi\(int k\) \{\s*constexpr int w\[\d+\] = \{([^}]*)\}", mid.source).group(1).split(",")]
+    lo = [int(x) for x in re.search(r"dep_lo\(int k\) \{\s*constexpr int w\[\d+\] = \{([^}]*)\}", mid.source).group(1).split(",")]
+    seq = [int(x) for x in re.search(r"seq_out\(int k\) \{\s*constexpr int w\[\d+\] = \{([^}]*)\}", mid.source).group(1).split(",")]
+    assert hi == [k // 2 for k in range(40)] and lo == [0] * 40 and sorted(seq) == list(range(40))
     monkeypatch.setenv("HAMK_WAVE", "1")
     small = api.system_from_spec(E.get("chain8"))
     assert "hamk_wave.hpp" in small.source and small.lanes_per_trajectory == 16

@@ -673,7 +673,7 @@ def test_c5_multi_step_parity_at_a_resolved_step(api, oracle_lib, name, B, nsamp
     """BASELINE config 5 at SURVEY's dt = 0.005 under-resolves links of length 1/N: over the config's 200 steps GPU and oracle
     amplify their roundoff by many orders and `test_full_size` can only ask for finiteness there (ORACLE_BOUNDS (None, None)).
     At dt / 4 the fast modes are resolved, and the same comparison is a PARITY statement: 200 RK4 steps of a strided sample
-    against the oracle, median <= 1e-10 and max <= 1e-7 over the lanes the launch does not flag.  Run at the 1-GPU ensemble
+    against the oracle, median <= 1e-10 and max <= 1e-7 over ALL sampled lanes.  Run at the 1-GPU ensemble
     size and at the 8-GPU shard size (8 192), each on the mapping the library uses there when the host states the whole
     ensemble's size (lane / quad for the full ensemble; hamk_options::ensemble_size keeps a shard on the same kernels)."""
     import torch
@@ -698,6 +698,8 @@ def test_c5_multi_step_parity_at_a_resolved_step(api, oracle_lib, name, B, nsamp
     per_lane = np.maximum((np.abs(gq - oq) / np.maximum(1.0, np.abs(oq))).max(0), (np.abs(gp - op) / np.maximum(1.0, np.abs(op))).max(0))
     record(test="c5_resolved_step_parity", name=name, B=B, dt=dt, nsteps=nsteps, kept=float(keep.mean()), flagged_frac_launch=float((st != 0).double().mean()),
            err_median=float(np.median(per_lane)), err_max_kept=float(per_lane[keep].max()) if keep.any() else None, err_max_all=float(per_lane.max()))
-    assert keep.mean() >= 0.5, (name, B, float(keep.mean()))         # most of the sample keeps its energy to 1e-6 at this step
+    # measured on MI355X (profiles/r05f_test_record.jsonl): chain16 median 2.1e-14 / max 5.6e-14, chain32 9.1e-14 / 1.7e-13 over ALL
+    # sampled lanes -- including the ones whose energy drifts by more than 1e-6 over these 200 steps (chain32: most of them;
+    # `kept` is recorded, not asserted): at this step the comparison no longer depends on which lanes are left out
     assert np.median(per_lane) <= 1e-10, (name, B, float(np.median(per_lane)))
-    assert per_lane[keep].max() <= 1e-7, (name, B, float(per_lane[keep].max()))
+    assert per_lane.max() <= 1e-7, (name, B, float(per_lane.max()))

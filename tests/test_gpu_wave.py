@@ -33,7 +33,10 @@ def relerr(a, b):
 
 CASES = [("spring", True), ("threeBodyPolar", True), ("chain4", True), ("opcodeZoo", True),
          ("chain8", True), ("chain16", True), ("chain32", False),
-         ("chain33", False), ("chain48", False), ("chain64", False)]      # n > 32: one trajectory per wavefront
+         ("chain33", False), ("chain48", False), ("chain64", False),      # n > 32: one trajectory per wavefront (pivot rows through scalar registers)
+         ("pendulums40", False),                                          # block-diagonal Jacobian: one matrix-core block per four rows, at a growing offset
+         ("dense24", False), ("dense32", False)]                           # dense Jacobians (round 5): no matrix-core block is skipped; dense32's
+                                                                            # RK4 kernel is the one-wavefront build (hamk_dispatch.cpp variant_for)
 
 
 @pytest.mark.parametrize("name,force", CASES)
@@ -245,6 +248,15 @@ def test_parked_adaptive_stepper_takes_the_reference_steps(api, oracle_lib, name
         assert max(relerr(np.stack([r.positions for r in rows]), oq), relerr(np.stack([r.momenta for r in rows]), op)) < 1e-9
     finally:
         on.gsl_api = 2
+
+
+def test_heavy_tapes_leave_the_two_wavefront_rk4_kernel(api):
+    """The wave mapping's RK4 kernel is capped for two wavefronts per SIMD; where a system's tape spills by the thousand under
+    that cap (dense32: 967 registers, 490 GB of HBM traffic per launch) the library rebuilds it for one -- a chain keeps two."""
+    assert api.system_from_spec(E.get("dense32")).options()["rk4_min_waves"] == 1
+    assert api.system_from_spec(E.get("chain48")).options()["rk4_min_waves"] == 2
+    from hamilton_amd import _abi
+    assert api.system_from_spec(E.get("dense32"), {"rk4_min_waves": 2}).options()["rk4_min_waves"] == 2      # the host's word stands
 
 
 def test_dense_jacobians_stay_on_the_wave_kernels(api):

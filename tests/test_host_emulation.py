@@ -527,7 +527,7 @@ def emulate_wave(hamk_lib, tmp_path_factory):
 
 @pytest.mark.parametrize("name,force,B", [("spring", True, 9), ("opcodeZoo", True, 6), ("threeBodyPolar", True, 5),
                                           ("chain8", True, 5), ("chain17", False, 3), ("chain18", False, 2), ("chain32", False, 2),
-                                          ("chain33", False, 1),
+                                          ("chain33", False, 1), ("pendulums40", False, 1), ("dense18", False, 2),
                                           pytest.param("chain64", False, 1, marks=pytest.mark.skipif(
                                               not os.environ.get("HAMK_TEST_SLOW"), reason="68 s of emulated lanes; set HAMK_TEST_SLOW=1 (the GPU suite runs chain64 against the oracle)"))])
 def test_wave_kernels_on_host_match_oracle(emulate_wave, oracle_lib, name, force, B):
@@ -536,7 +536,9 @@ def test_wave_kernels_on_host_match_oracle(emulate_wave, oracle_lib, name, force
     group-uniform RKF45 control -- against the oracle, incl. group sizes 16, 32 and 64 (one trajectory per wavefront), padded lanes,
     panels of 16 pivots with the trailing blocks updated by MFMA (two panels at n <= 32, up to four beyond; a second
     panel of ONE pivot at n = 17), odd N (single last pivot), N mod 4 != 0 (scalar head of the back substitution), M mod 4 != 0
-    (zero-padded MFMA rows), unequal inertias, and ensembles that do not fill the last block."""
+    (zero-padded MFMA rows), unequal inertias, and ensembles that do not fill the last block; one trajectory per wavefront with the
+    pivot rows read lane by lane (n > 32); matrix-core blocks skipped where the Jacobian's structure makes them zero -- a chain's
+    upper blocks, all but one block per four rows of a block-diagonal map (pendulums40), none of a dense map (dense18)."""
     spec = E.get(name)
     L = emulate_wave(spec, force)
     check_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=B, steps=2, tol=1e-10)
