@@ -65,9 +65,18 @@ class ClockSampler:
         import glob
         self.path = None
         try:                                                     # the card whose PCI address is cuda:index's
-            pr = torch.cuda.get_device_properties(index)
-            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
-            for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+            bdf = None
+            try:
+                pr = torch.cuda.get_device_properties(index)
+                bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            except Exception:                                    # noqa: BLE001 -- a torch without the pci_* fields: ask the HIP runtime
+                import ctypes
+                hip = [ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln]      # the runtime ALREADY mapped (never a second one)
+                lib = ctypes.CDLL(hip[0])
+                buf = ctypes.create_string_buffer(64)
+                if lib.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+                    bdf = buf.value.decode().lower()
+            for card in sorted(glob.glob("/sys/class/drm/card*/device")) if bdf else []:
                 if os.path.realpath(card).endswith(bdf):
                     hw = sorted(glob.glob(os.path.join(card, "hwmon", "hwmon*", "freq1_input")))      # current gfx clock, Hz
                     self.path = hw[0] if hw else os.path.join(card, "pp_dpm_sclk")
@@ -625,7 +634,7 @@ def main():
                     "scratch_insts_per_wave_step": isa["scratch_per_wave_step"],
                     "valu_issue_frac": wave_steps_per_s * isa["valu_per_wave_step"] * 4.0 / (N_SIMD * NOMINAL_HZ),
                     "valu_issue_frac_at_measured_clock": (wave_steps_per_s * isa["valu_per_wave_step"] * 4.0 / (N_SIMD * sclk_mhz * 1e6)) if sclk_mhz else None,
-                    "sclk_mhz_during_timed_region": sclk_mhz,
+                    "sclk_mhz_during_timed_region": sclk_mhz, "sclk_source": clk.path,
                     "valu_issue_frac_note": "VALU wave-instructions/s x 4 cycles / (1024 SIMDs x clock): at the 2.4 GHz nominal clock, and at the shader clock the "
                                             "driver reported while the timed launches ran (sysfs pp_dpm_sclk, sampled every 2 ms; null where the file is absent)",
                     "count_source": isa["source"], "loop": isa["loop_is"]})

@@ -23,9 +23,9 @@
 //   * classic RK4 (BASELINE.json north_star) and GSL-semantics adaptive RKF45
 //     (stepHam/evolveHam, Hamilton.hs:390-462) stepping loops around it;
 //   * an fp64 sincos written for this path (sincos_f64), and what the stepping
-//     kernels make of it: a 512-pair table in LDS (sincos_lut: 22 instructions per
+//     kernels make of it: a 512-pair table in LDS (sincos_lut: 20 instructions per
 //     full-accuracy evaluation) and rotations about the RK4 step's midpoint
-//     (rotate_pair: 20-23 instructions, no memory traffic) -- see StageTrig.
+//     (rotate_pair: 14-18 instructions since round 5 -- Horner sums, two-FMA angle addition -- no memory traffic) -- see StageTrig.
 // Systems with more than 16 coordinates use the wave-cooperative kernels of
 // hamk_wave.hpp instead (same generated f/U code, one AD direction per lane).
 //
@@ -465,6 +465,10 @@ HAMK_DEV void lut_load() {
 // wave-call against 21 k VALU; the RK4 kernel of the same system, built with the hoisting, executes 49 per right-hand
 // side).  LutK keeps them in VECTOR registers instead (18 VGPRs, filled once per kernel behind an opaque statement);
 // kernels with registers to spare take their operands from there (HAMK_TRIG_CONST_VGPR, set by the generator).
+// Rotations and the table evaluation in the form with the fewest instructions (Horner sums, two-FMA angle addition): see rotate_pair.
+#ifndef HAMK_ROTATE_HORNER
+#define HAMK_ROTATE_HORNER 1
+#endif
 struct LutK {
   double inv_step, w0, w1, w2, s5, s3, c6, c4, lim;
   HAMK_DEV LutK() {
@@ -503,8 +507,13 @@ template <class KC> HAMK_DEV void sincos_lut_fast(double x, double& s, double& c
   double pc = fma(kc.c6, z, kc.c4);
   pc = fma(pc, z, -0.5);
   const double cm1 = z * pc;                                     // cos r - 1
+#if HAMK_ROTATE_HORNER
+  s = fma(ca, sd, fma(sa, cm1, sa));                             // two FMAs per component instead of multiply + FMA + add (rotate_pair does the same)
+  c = fma(-sa, sd, fma(ca, cm1, ca));
+#else
   s = sa + fma(sa, cm1, ca * sd);
   c = ca + fma(ca, cm1, -(sa * sd));
+#endif
 }
 template <class KC> HAMK_DEV void sincos_lut(double x, double& s, double& c, const KC& kc) {
   sincos_lut_fast(x, s, c, kc);
@@ -526,7 +535,7 @@ template <class TC> HAMK_DEV LutLiterals lut_consts(const TC&, long) { return Lu
 //   TRIG_ANCHOR  as FULL, and remember (operand, sin, cos) as this site's anchor
 //   TRIG_INCR    the operand is close to the anchor (an RK stage point y + a h k next to y):
 //                rotate the anchor pair by delta = operand - anchor with short Taylor kernels
-//                (|delta| < 1/4: 26 fp64 instructions, no range reduction, no integer
+//                (|delta| < 1/4: 18 fp64 instructions, no range reduction, no integer
 //                quadrant logic, absolute error < 3e-18 + rounding); otherwise as FULL.
 //                Always relative to the anchor of the current step, so nothing accumulates.
 //   TRIG_DYN     decided per evaluation by the WAVE-UNIFORM field `mode` of the cache (a scalar
@@ -537,7 +546,7 @@ template <class TC> HAMK_DEV LutLiterals lut_consts(const TC&, long) { return Lu
 //                                            and make the result the anchor            DYN_NARROW_ANCHOR
 //                    stage 3  y + h/2 k2     delta = h/2 (k2 - k1) ~ h^2/4 |qdd| < 1/32  DYN_SHORT
 //                    stage 4  y + h k3       delta = h k3 - h/2 k1 ~ h/2 |qd| < 1/8      DYN_NARROW
-//                -- 42 + 23 + 20 + 23 instructions per sincos site and step instead of 42 + 3 x 23 with
+//                -- 42 + 23 + 20 + 23 instructions per sincos site and step (round 5, Horner form: 42 + 16 + 14 + 16) instead of 42 + 3 x 23 with
 //                every stage measured from y, where stage 4 sits a full h |qd| away.  The ranges are
 //                matched to what each stage really moves because a lane beyond its range re-evaluates
 //                in full and a wavefront executes what ANY of its lanes needs: rare lanes make common
@@ -577,6 +586,39 @@ template <int RANGE> HAMK_DEV constexpr double incr_limit() {
   return (RANGE == INCR_WIDE) ? 0.25 : ((RANGE == INCR_NARROW) ? 0.125 : 0.03125);
 }
 template <int RANGE> HAMK_DEV void rotate_pair(double d, double sa, double ca, double& s, double& c) {
+#if HAMK_ROTATE_HORNER
+  // Horner form: one FMA per coefficient and no powers of z -- fewer instructions, a longer dependent chain.  The kernels that
+  // rotate are the small systems' (1-4 sincos sites), which run several wavefronts per SIMD and are bound by VALU ISSUE, not by
+  // latency; inside their stepping loops the coefficients are loop-invariant scalar registers, so every step is ONE v_fma_f64.
+  // (sincos_f64 keeps its power-basis sums: outside a loop the compiler copied every constant into the accumulator first.)
+  // Angle addition as fma(ca, sd, fma(sa, cm1, sa)): two instructions per component instead of multiply + FMA + add, at half an
+  // ulp more rounding (tests/test_host_emulation.py test_rotation_ranges: < 3e-16 over every range, unchanged bounds).
+  // Measured on MI355X, same box back to back (profiles/r05i_horner_ab.jsonl): doublePendulum 372 -> 328 VALU instructions per
+  // wavefront-step, 8.48e10 -> 9.05e10 RK4 steps/s; pendulum +5 %; the systems that only take the table's two-FMA form +1-2 %.
+  const double z = d * d;
+  double ps, pc;
+  if constexpr (RANGE == INCR_WIDE) {
+    ps = fma(-2.50507602534068634195e-08, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    pc = fma(2.08757232129817482790e-09, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+  } else if constexpr (RANGE == INCR_NARROW) {
+    ps = fma(2.75573137070700676789e-06, z, -1.98412698298579493134e-04);
+    pc = fma(-2.75573143513906633035e-07, z, 2.48015872894767294178e-05);
+  } else {
+    ps = -1.98412698298579493134e-04;
+    pc = 2.48015872894767294178e-05;
+  }
+  ps = fma(ps, z, 8.33333333332248946124e-03);
+  ps = fma(ps, z, -1.66666666666666324348e-01);
+  const double sd = fma(d * z, ps, d);                    // sin(d)
+  pc = fma(pc, z, -1.38888888888741095749e-03);
+  pc = fma(pc, z, 4.16666666666666019037e-02);
+  pc = fma(pc, z, -0.5);
+  const double cm1 = z * pc;                              // cos(d) - 1
+  s = fma(ca, sd, fma(sa, cm1, sa));
+  c = fma(-sa, sd, fma(ca, cm1, ca));
+#else
   const double z = d * d, z2 = z * z, z3 = z2 * z;
   // the leading coefficients of sincos_f64's kernels serve here too (they differ from the Taylor
   // coefficients by < 4e-15, i.e. < 1e-17 in the result for |d| < 1/4): no extra fp64
@@ -609,6 +651,7 @@ template <int RANGE> HAMK_DEV void rotate_pair(double d, double sa, double ca, d
   const double cm1 = z * pc;                              // cos(d) - 1
   s = sa + fma(sa, cm1, ca * sd);
   c = ca + fma(ca, cm1, -(sa * sd));
+#endif
 }
 
 // sincos(x) from the anchor (xa, sa, ca); beyond the range (or NaN) the full evaluation, in a
@@ -647,7 +690,7 @@ template <int MODE, class TC> HAMK_DEV void trig_pair(double x, TC& tc, int k) {
       if (mode == DYN_SHORT) { rotate_pair<INCR_SHORT>(d, tc.as[k], tc.ac[k], tc.s[k], tc.c[k]); full = !(fabs(d) < incr_limit<INCR_SHORT>()); }
       else { rotate_pair<INCR_NARROW>(d, tc.as[k], tc.ac[k], tc.s[k], tc.c[k]); full = !(fabs(d) < incr_limit<INCR_NARROW>()); }
     }
-    // (with the LDS table loaded -- HAMK_USE_LUT -- the full evaluation is sincos_lut: 22 instructions)
+    // (with the LDS table loaded -- HAMK_USE_LUT -- the full evaluation is sincos_lut: 20 instructions)
 #ifdef HAMK_PROBE_NO_SLOWPATH
     if (mode == DYN_FULL_ANCHOR) { if constexpr (HAMK_USE_LUT != 0) sincos_lut(x, tc.s[k], tc.c[k], lut_consts(tc, 0)); else sincos_f64(x, tc.s[k], tc.c[k]); }
 #else
@@ -675,22 +718,22 @@ template <int MODE, class A, class TC> HAMK_DEV A cos(const A& x, TC& tc, int k)
 // (hamk_codegen.cpp, MODE_R) both use them.
 HAMK_DEV void d2_recip(double x, double& g0, double& g1, double& g2) { const double r = frcp(x), r2 = r * r; g0 = r; g1 = -r2; g2 = 2.0 * r2 * r; }
 HAMK_DEV void d2_tan(double x, double& g0, double& g1, double& g2) { const double t = ::tan(x), d = fma(t, t, 1.0); g0 = t; g1 = d; g2 = 2.0 * t * d; }
-HAMK_DEV void d2_asin(double x, double& g0, double& g1, double& g2) { const double w = fma(-x, x, 1.0), r = ::rsqrt(w); g0 = ::asin(x); g1 = r; g2 = x * r / w; }
-HAMK_DEV void d2_acos(double x, double& g0, double& g1, double& g2) { const double w = fma(-x, x, 1.0), r = ::rsqrt(w); g0 = ::acos(x); g1 = -r; g2 = -x * r / w; }
-HAMK_DEV void d2_atan(double x, double& g0, double& g1, double& g2) { const double w = 1.0 / fma(x, x, 1.0); g0 = ::atan(x); g1 = w; g2 = -2.0 * x * w * w; }
+HAMK_DEV void d2_asin(double x, double& g0, double& g1, double& g2) { const double w = fma(-x, x, 1.0), r = ::rsqrt(w); g0 = ::asin(x); g1 = r; g2 = x * r * frcp(w); }
+HAMK_DEV void d2_acos(double x, double& g0, double& g1, double& g2) { const double w = fma(-x, x, 1.0), r = ::rsqrt(w); g0 = ::acos(x); g1 = -r; g2 = -x * r * frcp(w); }
+HAMK_DEV void d2_atan(double x, double& g0, double& g1, double& g2) { const double w = frcp(fma(x, x, 1.0)); g0 = ::atan(x); g1 = w; g2 = -2.0 * x * w * w; }
 HAMK_DEV void d2_sinh(double x, double& g0, double& g1, double& g2) { const double s = ::sinh(x), c = ::cosh(x); g0 = s; g1 = c; g2 = s; }
 HAMK_DEV void d2_cosh(double x, double& g0, double& g1, double& g2) { const double s = ::sinh(x), c = ::cosh(x); g0 = c; g1 = s; g2 = c; }
 HAMK_DEV void d2_tanh(double x, double& g0, double& g1, double& g2) { const double t = ::tanh(x), d = fma(-t, t, 1.0); g0 = t; g1 = d; g2 = -2.0 * t * d; }
-HAMK_DEV void d2_asinh(double x, double& g0, double& g1, double& g2) { const double w = fma(x, x, 1.0), r = ::rsqrt(w); g0 = ::asinh(x); g1 = r; g2 = -x * r / w; }
-HAMK_DEV void d2_acosh(double x, double& g0, double& g1, double& g2) { const double w = fma(x, x, -1.0), r = ::rsqrt(w); g0 = ::acosh(x); g1 = r; g2 = -x * r / w; }
-HAMK_DEV void d2_atanh(double x, double& g0, double& g1, double& g2) { const double w = 1.0 / fma(-x, x, 1.0); g0 = ::atanh(x); g1 = w; g2 = 2.0 * x * w * w; }
+HAMK_DEV void d2_asinh(double x, double& g0, double& g1, double& g2) { const double w = fma(x, x, 1.0), r = ::rsqrt(w); g0 = ::asinh(x); g1 = r; g2 = -x * r * frcp(w); }
+HAMK_DEV void d2_acosh(double x, double& g0, double& g1, double& g2) { const double w = fma(x, x, -1.0), r = ::rsqrt(w); g0 = ::acosh(x); g1 = r; g2 = -x * r * frcp(w); }
+HAMK_DEV void d2_atanh(double x, double& g0, double& g1, double& g2) { const double w = frcp(fma(-x, x, 1.0)); g0 = ::atanh(x); g1 = w; g2 = 2.0 * x * w * w; }
 // |x| and signum x (Num methods): derivative of |x| is signum x, every higher derivative 0 (at x = 0: signum 0 = 0, as `ad` has it)
 HAMK_DEV double signum_f64(double x) { return (x > 0.0) ? 1.0 : ((x < 0.0) ? -1.0 : 0.0); }
 HAMK_DEV void d2_abs(double x, double& g0, double& g1, double& g2) { g0 = fabs(x); g1 = signum_f64(x); g2 = 0.0; }
 HAMK_DEV void d2_signum(double x, double& g0, double& g1, double& g2) { g0 = signum_f64(x); g1 = 0.0; g2 = 0.0; }
 HAMK_DEV void d2_exp(double x, double& g0, double& g1, double& g2) { const double e = ::exp(x); g0 = e; g1 = e; g2 = e; }
-HAMK_DEV void d2_log(double x, double& g0, double& g1, double& g2) { const double r = 1.0 / x; g0 = ::log(x); g1 = r; g2 = -r * r; }
-HAMK_DEV void d2_sqrt(double x, double& g0, double& g1, double& g2) { const double r = ::sqrt(x); g0 = r; g1 = 0.5 / r; g2 = -0.5 * g1 / x; }
+HAMK_DEV void d2_log(double x, double& g0, double& g1, double& g2) { const double r = frcp(x); g0 = ::log(x); g1 = r; g2 = -r * r; }
+HAMK_DEV void d2_sqrt(double x, double& g0, double& g1, double& g2) { const double r = ::sqrt(x), i = frcp(r); g0 = r; g1 = 0.5 * i; g2 = -0.5 * g1 * (i * i); }      // 1/r by rcp + two Newton steps (5 instructions; an IEEE division is 11, and there were two)
 
 // k is a literal after inlining: folds to a multiply chain.  No recursion -- a recursive helper
 // is not inlined and becomes a real device function call (call frame in scratch).
@@ -714,7 +757,7 @@ HAMK_DEV void d2_pow(double a, double b, double& f0, double& fa, double& fb, dou
   f0 = z; fa = b * z * ia; fb = z * la; faa = b * (b - 1.0) * z * ia * ia; fab = z * ia * fma(b, la, 1.0); fbb = z * la * la;
 }
 HAMK_DEV void d2_atan2(double y, double x, double& f0, double& fa, double& fb, double& faa, double& fab, double& fbb) {
-  const double i2 = 1.0 / fma(y, y, x * x);
+  const double i2 = frcp(fma(y, y, x * x));
   f0 = ::atan2(y, x); fa = x * i2; fb = -y * i2; faa = -2.0 * y * x * i2 * i2; fab = (y * y - x * x) * i2 * i2; fbb = -faa;
 }
 
@@ -1075,15 +1118,15 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
 // TRIG_INCR pays only where sincos is a large share of the right-hand side and the anchors fit
 // in registers; elsewhere the stage evaluations stay TRIG_FULL.
 // How the stepping kernels evaluate sincos (measured on MI355X, profiles/r02_sweep_trig.jsonl):
-//   * the LDS table makes a full-accuracy evaluation cost 22 instructions instead of 42, but every
+//   * the LDS table makes a full-accuracy evaluation cost 20 instructions instead of 42, but every
 //     evaluation is a 16-byte gather at a lane-dependent address: ~20-25 LDS cycles per wavefront
 //     (bank conflicts), and one LDS unit serves the 16 resident wavefronts of a CU.  A kernel whose
 //     step is short and trig-dense (config 2: 8 evaluations per 370-instruction step) would keep that
 //     unit ~2/3 busy and gains little;
-//   * rotations about the step's midpoint (TRIG_DYN) cost 20-23 instructions and no LDS traffic, but
+//   * rotations about the step's midpoint (TRIG_DYN) cost 14-16 instructions and no LDS traffic, but
 //     need 3 registers per site and one full evaluation per step.
 //   HAMK_USE_LUT = 2 (default): 1-4 sites -> the step's ONE full evaluation through the table, stages
-//     2-4 by rotation (88 instructions per site and step, 2 gathers per step in config 2);
+//     2-4 by rotation (66 instructions per site and step, 2 gathers per step in config 2);
 //     5 or more sites (the chains: anchors do not fit in registers) -> every evaluation through the table;
 //   HAMK_USE_LUT = 1: every evaluation through the table;  0: no table (round-1 arithmetic).
 // The adaptive stepper (RKF45) takes every evaluation through the table when there is one.

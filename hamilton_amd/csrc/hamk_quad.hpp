@@ -176,9 +176,6 @@ template <class S> struct TrigLdsQ {
   TrigSite<S> s, c;
   double* ax; double* as; double* ac;       // unused (TRIG_REUSE never touches them)
 };
-template <class S> HAMK_DEV TrigLdsQ<S> reverse_trig(const TrigLdsQ<S>& t) {
-  TrigLdsQ<S> u = t; u.s.base = relaunder(t.s.base); u.c.base = relaunder(t.c.base); return u;
-}
 // The same rows read in ONE BURST into registers.  A wavefront alone on its SIMD pays every LDS round trip it waits for, and
 // left to itself the compiler issues each ds_read a few instructions before its first use (it schedules for register
 // pressure): the sweeps then stop ~50 (first sweep) + ~100 (reverse sweep) times per right-hand side for ~100 cycles -- a

@@ -21,7 +21,7 @@ def jobs():
     for n in base:
         out.append((n, {}, True))
         out.append((n, {"HAMK_GSL_API": "1"}, False))
-    for n in ("dense24", "dense32", "chain13", "chain14"):  # round 5: the dense-Jacobian benchmark systems (wave kernels), bench lines with instruction counts
+    for n in ("dense18", "pendulums40", "dense24", "dense32", "chain13", "chain14"):  # round 5: the dense-Jacobian benchmark systems (wave kernels), bench lines with instruction counts
         out.append((n, {}, True))
     for n in ("spring", "threeBodyPolar", "chain4", "opcodeZoo", "chain8", "chain16"):
         out.append((n, {"HAMK_WAVE": "1"}, False))

@@ -264,13 +264,7 @@ def test_dense_jacobians_stay_on_the_wave_kernels(api):
     coordinate map of the same size is left on the wave-cooperative kernels."""
     from hamilton_amd import _abi
     assert api.system_from_spec(E.get("chain24")).options()["mapping"] == _abi.MAP_QUAD
-    import hamilton_amd.examples as EX
-    n, m = 18, 18
-
-    def f(q, o):
-        return [sum((0.1 + 0.05 * ((3 * k + 7 * j) % 11)) * o.sin(q[j] * (1 + 0.1 * k)) for j in range(n)) for k in range(m)]
-    spec = EX.SystemSpec(name="dense18", m=m, n=n, inertia=(1.0,) * m, f=f, u=lambda x, o: x[0] * 0.0 + 1.0 * x[1], u_space=EX.U_CARTESIAN,
-                         q0=(0.1,) * n, qd0=(0.0,) * n, q_box=((-1.0, 1.0),) * n, qd_box=((-1.0, 1.0),) * n)
+    spec = E.get("dense18")                                   # x = 2 q + A sin q + B cos q: n^2 distinct Jacobian entries
     assert api.system_from_spec(spec).options()["mapping"] == _abi.MAP_WAVE
 
 
