@@ -628,7 +628,9 @@ def main():
                 wave_steps_per_s = per_gpu_rate * lanes_per_traj / 64.0
                 fp64.update({
                     "flops_per_step": flops_step, "achieved_tflops": per_gpu_rate * flops_step / 1e12,
-                    "frac_of_peak": per_gpu_rate * flops_step / 1e12 / FP64_PEAK_TFLOPS,
+                    # a kernel that also issues v_mfma_f64 has two fp64 pipes to fill: vector 78.6 + matrix 78.6 TFLOP/s
+                    "peak_tflops": FP64_PEAK_TFLOPS * (2.0 if isa["mfma_per_wave_step"] else 1.0),
+                    "frac_of_peak": per_gpu_rate * flops_step / 1e12 / (FP64_PEAK_TFLOPS * (2.0 if isa["mfma_per_wave_step"] else 1.0)),
                     "valu_insts_per_wave_step": isa["valu_per_wave_step"], "valu_f64_insts_per_wave_step": isa["valu_f64_per_wave_step"],
                     "mfma_insts_per_wave_step": isa["mfma_per_wave_step"], "lds_insts_per_wave_step": isa["lds_per_wave_step"],
                     "scratch_insts_per_wave_step": isa["scratch_per_wave_step"],
@@ -636,7 +638,7 @@ def main():
                     "valu_issue_frac_at_measured_clock": (wave_steps_per_s * isa["valu_per_wave_step"] * 4.0 / (N_SIMD * sclk_mhz * 1e6)) if sclk_mhz else None,
                     "sclk_mhz_during_timed_region": sclk_mhz, "sclk_source": clk.path,
                     "valu_issue_frac_note": "VALU wave-instructions/s x 4 cycles / (1024 SIMDs x clock): at the 2.4 GHz nominal clock, and at the shader clock the "
-                                            "driver reported while the timed launches ran (sysfs pp_dpm_sclk, sampled every 2 ms; null where the file is absent)",
+                                            "driver reported while the timed launches ran (sysfs hwmon freq1_input of the device's card, sampled every 2 ms; null where absent)",
                     "count_source": isa["source"], "loop": isa["loop_is"]})
         cfg_id, cfg_B = BASELINE_CONFIG.get(a.system, (None, None))
         out = {
