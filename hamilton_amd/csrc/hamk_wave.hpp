@@ -339,7 +339,7 @@ HAMK_DEV void factor_blocked(const Ctx<S>& c, double& dinv, int& st, double& z) 
     const int J0 = 16 * pb, J1 = (16 * pb + 16 < N) ? 16 * pb + 16 : N;     // this panel's pivots [J0, J1)
     if (pb > 0) {
       HAMK_LOCKSTEP();
-      c.piv()[li] = dmine;                                   // every lane its own slot; final for lanes < J0
+      if constexpr (G != 1) c.piv()[li] = dmine;             // every lane its own slot; final for lanes < J0 (one trajectory per wavefront: written as found)
       lds_sync();                                            // L of the earlier panels and their pivots are in LDS
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -409,8 +409,11 @@ HAMK_DEV void factor_blocked(const Ctx<S>& c, double& dinv, int& st, double& z) 
         const double zj1p = fma(-l, zj, zj1);
         const double l0 = (li > j) ? row[j - J0] * inv_a : 0.0;
         const double l1 = (li > j + 1) ? fma(-l0, b, row[j + 1 - J0]) * inv_c : 0.0;
-        if (li == j) { dinv = inv_a; dmine = a; }
-        if (li == j + 1) { dinv = inv_c; dmine = det * inv_a; }
+        // the two pivots are the same number in every lane (they came through scalar registers): every lane stores them into the
+        // trajectory's pivot buffer, and lane i picks d_i up ONCE after the last panel -- instead of a chain of 2 x n lane-masked
+        // selects that carries (dinv, dmine) through the whole factorisation and keeps a scalar pair per pivot alive for it
+        c.piv()[j] = a;
+        c.piv()[j + 1] = det * inv_a;
         z = fma(-l1, zj1p, fma(-l0, zj, z));
         const double al = fma(-l1, l, l0);
 #pragma unroll
@@ -429,7 +432,7 @@ HAMK_DEV void factor_blocked(const Ctx<S>& c, double& dinv, int& st, double& z) 
       if (((J1 - J0) & 1) != 0) {                            // last pivot of an odd N: nothing below it
         const double dj = read_lane(row[J1 - 1 - J0], J1 - 1);
         ok = ok && (dj > 0.0);
-        if (li == J1 - 1) { dinv = frcp(dj); dmine = dj; }
+        c.piv()[J1 - 1] = dj;
       }
       continue;
     }
@@ -472,6 +475,7 @@ HAMK_DEV void factor_blocked(const Ctx<S>& c, double& dinv, int& st, double& z) 
   }
   if (!ok && li < N) st |= ST_SINGULAR;
   lds_sync();
+  if constexpr (G == 1) dinv = (li < N) ? frcp(c.piv()[li]) : 0.0;       // lane i's 1 / d_i (see the pivot stores above)
 }
 
 template <int NP> HAMK_DEV int group_min(int x) {
@@ -614,6 +618,11 @@ HAMK_DEV double solve_back(const Ctx<S>& c, double dinv, double z) {
     }
 #pragma unroll
     for (int kb = N - R - 4; kb >= 0; kb -= 4) {
+#ifndef HAMK_HOST_EMULATION
+      // one block of four at a time: L^T is final, so nothing orders its ten reads per block against the chain of v -- left alone
+      // the scheduler issues the reads of MANY blocks ahead (they hide latency) and pays for it in registers the kernel does not have
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       const double p0 = read_lane(v, kb), p1 = read_lane(v, kb + 1), p2 = read_lane(v, kb + 2), v3 = read_lane(v, kb + 3);
       const double v2 = fma(-T[tri(kb + 3, kb + 2)], v3, p2);
       const double v1 = fma(-T[tri(kb + 2, kb + 1)], v2, fma(-T[tri(kb + 3, kb + 1)], v3, p1));
