@@ -329,7 +329,6 @@ HAMK_DEV void factor_blocked(const Ctx<S>& c, double& dinv, int& st, double& z) 
   const int kq = c.lw >> 4, l16 = c.lw & 15;
   bool ok = true;
   dinv = 0.0;
-  double dmine = 1.0;
   double* Lrow = c.tile() + li * (li + 1) / 2;
   double* cA = c.rowbuf();
   double* cB = c.rowbuf() + NP;
@@ -339,8 +338,7 @@ HAMK_DEV void factor_blocked(const Ctx<S>& c, double& dinv, int& st, double& z) 
     const int J0 = 16 * pb, J1 = (16 * pb + 16 < N) ? 16 * pb + 16 : N;     // this panel's pivots [J0, J1)
     if (pb > 0) {
       HAMK_LOCKSTEP();
-      if constexpr (G != 1) c.piv()[li] = dmine;             // every lane its own slot; final for lanes < J0 (one trajectory per wavefront: written as found)
-      lds_sync();                                            // L of the earlier panels and their pivots are in LDS
+      lds_sync();                                            // (the pivots of the earlier panels went to c.piv() as they were found)                                            // L of the earlier panels and their pivots are in LDS
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const double* T = c.smem + c.offw + g * PER;         // trajectory g of the wavefront: all 64 lanes serve it
@@ -455,8 +453,8 @@ HAMK_DEV void factor_blocked(const Ctx<S>& c, double& dinv, int& st, double& z) 
       const double zj1p = fma(-l, zj, zj1);
       const double l0 = (li > j) ? row[j - J0] * inv_a : 0.0;
       const double l1 = (li > j + 1) ? fma(-l0, b, row[j + 1 - J0]) * inv_c : 0.0;
-      if (li == j) { dinv = inv_a; dmine = a; }
-      if (li == j + 1) { dinv = inv_c; dmine = det * inv_a; }
+      c.piv()[j] = a;                                         // (group-uniform: every lane of the trajectory stores the same two numbers;
+      c.piv()[j + 1] = det * inv_a;                           //  lane i reads d_i after the last panel -- see the one-trajectory branch above)
       z = fma(-l1, zj1p, fma(-l0, zj, z));
       const double al = fma(-l1, l, l0);
 #pragma unroll
@@ -470,12 +468,12 @@ HAMK_DEV void factor_blocked(const Ctx<S>& c, double& dinv, int& st, double& z) 
       lds_sync();
       const double dj = cA[J1 - 1];
       ok = ok && (dj > 0.0);
-      if (li == J1 - 1) { dinv = frcp(dj); dmine = dj; }
+      c.piv()[J1 - 1] = dj;
     }
   }
   if (!ok && li < N) st |= ST_SINGULAR;
   lds_sync();
-  if constexpr (G == 1) dinv = (li < N) ? frcp(c.piv()[li]) : 0.0;       // lane i's 1 / d_i (see the pivot stores above)
+  dinv = (li < N) ? frcp(c.piv()[li]) : 0.0;               // lane i's 1 / d_i (see the pivot stores above)
 }
 
 template <int NP> HAMK_DEV int group_min(int x) {
