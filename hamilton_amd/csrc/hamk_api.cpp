@@ -523,6 +523,57 @@ int hamk_hameqs_batch(hamk_system* s, int64_t B, const double* q, const double* 
 
 namespace { struct HamkBoxes { double q_lo[64], q_hi[64], qd_lo[64], qd_hi[64]; }; }     // = hamk_sample.hpp
 
+// The sampler is the one JIT product that every other check of the library takes on trust (shard invariance, bench parity and the
+// CPU tests' numpy sampler all rest on "index -> bits" being what hamk_sample.hpp says): on its first use per device, eight
+// trajectories of a two-coordinate box are drawn and compared BIT FOR BIT with the same arithmetic on the host -- splitmix64 of
+// (seed, global index, field), 53 bits to [0, 1), lo + (hi - lo) u in three separately rounded operations.
+static uint64_t host_splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  uint64_t z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static double host_sample(uint64_t seed, uint64_t index, int field, double lo, double hi) {
+  const uint64_t key = seed ^ (index * 0xD1342543DE82EF95ull);
+  const uint64_t z = host_splitmix64(key + (uint64_t)field * 0x2545F4914F6CDD1Dull);
+  const double u = (double)(z >> 11) * 0x1p-53;
+  volatile double t = (hi - lo) * u;                        // (volatile: the product is rounded before the sum, whatever the host compiler contracts)
+  return lo + t;
+}
+static int sample_self_check(DevState* d) {
+  constexpr int n = 2, B = 8;
+  const long long first = 123456789012ll;
+  const unsigned long long seed = 0x5eedull;
+  HamkBoxes bx;
+  std::memset(&bx, 0, sizeof bx);
+  bx.q_lo[0] = -1.25; bx.q_hi[0] = 2.5; bx.q_lo[1] = 0.5; bx.q_hi[1] = 0.75;
+  bx.qd_lo[0] = -3.0; bx.qd_hi[0] = 3.0; bx.qd_lo[1] = 1e-3; bx.qd_hi[1] = 1e3;
+  double* dev = nullptr;
+  HIP_TRY(hipMalloc((void**)&dev, 2 * n * B * sizeof(double)));
+  double *xq = dev, *xqd = dev + n * B;
+  long long b = B, f0 = first;
+  unsigned long long sd = seed;
+  int nn = n;
+  void* args[] = {&xq, &xqd, &b, &f0, &sd, &nn, &bx};
+  double got[2 * n * B];
+  hipError_t e = hipModuleLaunchKernel(d->sample_fn, 1, 1, 1, 256, 1, 1, 0, d->stream, args, nullptr);
+  if (e == hipSuccess) e = hipMemcpyAsync(got, dev, sizeof got, hipMemcpyDeviceToHost, d->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+  hipFree(dev);
+  if (e != hipSuccess) return fail(HAMK_ERR_HIP, std::string("sampler self-check: ") + hipGetErrorString(e));
+  if (const char* f = test_env("HAMK_SELFCHECK_FAULT")) if (std::strstr(f, "sample")) got[3] = std::nextafter(got[3], 4.0);      // test hook: one bit off
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < B; ++i) {
+      const double q = host_sample(seed, (uint64_t)(first + i), 2 * j, bx.q_lo[j], bx.q_hi[j]);
+      const double v = host_sample(seed, (uint64_t)(first + i), 2 * j + 1, bx.qd_lo[j], bx.qd_hi[j]);
+      if (std::memcmp(&q, &got[j * B + i], 8) != 0 || std::memcmp(&v, &got[n * B + j * B + i], 8) != 0)
+        return fail(HAMK_ERR_COMPILE, "self-check failed: hamk_sample_k does not draw the bits of the host's evaluation of the same "
+                                      "(seed, index, field) -> value map (miscompiled sampler module?)");
+    }
+  return HAMK_OK;
+}
+
 int hamk_sample_batch(hamk_system* s, int64_t B, int64_t first_index, uint64_t seed, const double* q_lo, const double* q_hi,
                       const double* qd_lo, const double* qd_hi, double* q, double* qd, int32_t mem) {
   TRY(check_call(s, B, mem));
@@ -537,6 +588,10 @@ int hamk_sample_batch(hamk_system* s, int64_t B, int64_t first_index, uint64_t s
   if (!d->sample_fn) {
     HIP_TRY(hipModuleLoadData(&d->sample_module, code->data()));
     HIP_TRY(hipModuleGetFunction(&d->sample_fn, d->sample_module, "hamk_sample_k"));
+    if (s->self_check_on) {                                 // first use on this device: a few draws against the host's own evaluation
+      const int rc0 = sample_self_check(d);
+      if (rc0 != HAMK_OK) { hipModuleUnload(d->sample_module); d->sample_module = nullptr; d->sample_fn = nullptr; return rc0; }
+    }
   }
   HamkBoxes bx;
   std::memset(&bx, 0, sizeof bx);

@@ -703,3 +703,24 @@ def test_c5_multi_step_parity_at_a_resolved_step(api, oracle_lib, name, B, nsamp
     # `kept` is recorded, not asserted): at this step the comparison no longer depends on which lanes are left out
     assert np.median(per_lane) <= 1e-10, (name, B, float(np.median(per_lane)))
     assert per_lane.max() <= 1e-7, (name, B, float(per_lane.max()))
+
+
+@pytest.mark.gpu
+def test_sampler_self_check_catches_a_wrong_bit(tmp_path):
+    """The device sampler is compared bit for bit with the host's evaluation of the same (seed, index, field) -> value map on its
+    first use per device (hamk_api.cpp sample_self_check); with one returned value moved by an ulp (test hook) the call fails loudly."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    prog = ("import sys; sys.path.insert(0, %r)\n"
+            "import torch\n"
+            "from hamilton_amd import api, examples\n"
+            "spec = examples.get('pendulum'); s = api.system_from_spec(spec)\n"
+            "try:\n"
+            "    api.sampleConfig(s, spec.q_box, spec.qd_box, 0, 64, 1, torch.device('cuda', 0)); print('DREW')\n"
+            "except api.HamkError as e:\n"
+            "    print('REFUSED', e)\n") % ROOT
+    ok = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=dict(os.environ))
+    assert "DREW" in ok.stdout, ok.stdout + ok.stderr
+    bad = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=dict(os.environ, HAMK_SELFCHECK_FAULT="sample"))
+    assert "REFUSED" in bad.stdout and "hamk_sample_k does not draw the bits" in bad.stdout, bad.stdout + bad.stderr
