@@ -719,3 +719,31 @@ def test_initial_conditions_are_drawn_on_the_device_from_the_global_index(api):
         assert np.array_equal(far.positions, wq) and np.array_equal(far.velocities, wqd)
     with pytest.raises(ValueError):
         api.sampleConfig(s, spec.q_box[:-1], spec.qd_box, 0, 4, 1)
+
+
+def test_cold_path_compiles_on_the_gpu_box(api, oracle_lib):
+    """Every other GPU test loads code objects that were cross-compiled ahead and travelled with the snapshot (`.hamk_cache/`).
+    This one switches the cache OFF (hamk_options::cache): tape -> source -> hiprtc for gfx950 happens HERE, on the box, and the
+    freshly compiled module goes through the first-use self-check and the oracle like any other -- the path a host without a
+    warm cache takes (a system of its own so that no earlier test has left a handle to the same module around)."""
+    import time
+    from hamilton_amd import _abi
+    spec = E.double_pendulum(m1=1.5, m2=0.7)               # a small tape no other test builds (other masses): a few seconds of hiprtc
+    t0 = time.time()
+    s = api.system_from_spec(spec, {"cache": _abi.OFF})
+    t_compile = time.time() - t0
+    assert s.options()["cache"] == _abi.OFF and s.code_size > 0
+    o = oracle_lib.OracleSystem(spec)
+    q, qd = E.sample_config(spec, 3, 200)
+    p = o.to_phase_batch(q, qd)
+    assert relerr(api.momenta(s, api.Config(q, qd)), p) < 1e-12
+    dq, dp = api.hamEqs(s, api.Phase(q, p))
+    odq, odp, _ = o.hameqs_batch(q, p)
+    assert relerr(dq, odq) < 1e-10 and relerr(dp, odp) < 1e-10
+    ph = api.rk4Steps(spec.dt, 10, s, api.Phase(q, p))
+    oq, op = o.rk4_steps_batch(q, p, spec.dt, 10)
+    assert relerr(ph.positions, oq) < 1e-10 and relerr(ph.momenta, op) < 1e-10
+    st = api.stepHam(spec.dt, s, api.Phase(q, p))
+    sq, sp, sns = o.step_ham_batch(q, p, spec.dt)
+    assert np.array_equal(np.asarray(s.last_nsub), sns) and relerr(st.positions, sq) < 1e-9
+    assert t_compile > 0.2, "served from a cache after all?"
