@@ -1564,12 +1564,25 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
   // rows (two scratch rows less per attempt: chain8-10 +4-5 % stepHam/s; in SCRATCH the same reuse makes the stores wait
   // for the loads of the same addresses, chain16 -5 %: there they keep rows of their own)
   double v[7][D];
+  // NL == 2 (n = 13..16: only y and dydt fit the CU's LDS): across the LAST right-hand side of an attempt the trial state and the
+  // error combination wait in the LDS rows of y and dydt, and the old y / dydt -- read again only if the attempt is REJECTED --
+  // go to the scratch rows instead.  Same values, same arithmetic; two scratch row reads less per accepted attempt, and the reads
+  // that remain after the last right-hand side are LDS reads (the scratch round trip there was fully exposed: one wavefront per
+  // SIMD, nothing to overlap it with).  HAMK_RKF_SWAP_LAST=0 restores the round-4 placement (A/B).
+#ifndef HAMK_RKF_SWAP_LAST
+#define HAMK_RKF_SWAP_LAST 1
+#endif
+#if defined(HAMK_PROBE_ALIAS_ROWS) || HAMK_RKF_ROWS_IN_REGS
+  constexpr bool SWAP_LAST = false;
+#else
+  constexpr bool SWAP_LAST = HAMK_RKF_SWAP_LAST && NL == 2;
+#endif
 #ifdef HAMK_PROBE_ALIAS_ROWS
 #define HAMK_RKF_YN(j) ((NL >= 3) ? HAMK_RKF_LROW(2)[HAMK_ROW_AT(j)] : py[HAMK_ROW_AT(j)])
 #define HAMK_RKF_E(j) ((NL >= 4) ? HAMK_RKF_LROW(3)[HAMK_ROW_AT(j)] : pf[HAMK_ROW_AT(j)])
 #else
-#define HAMK_RKF_YN(j) ((NL >= 3) ? HAMK_RKF_LROW(2)[HAMK_ROW_AT(j)] : v[5][j])
-#define HAMK_RKF_E(j) ((NL >= 4) ? HAMK_RKF_LROW(3)[HAMK_ROW_AT(j)] : v[6][j])
+#define HAMK_RKF_YN(j) ((NL >= 3) ? HAMK_RKF_LROW(2)[HAMK_ROW_AT(j)] : (SWAP_LAST ? py[HAMK_ROW_AT(j)] : v[5][j]))
+#define HAMK_RKF_E(j) ((NL >= 4) ? HAMK_RKF_LROW(3)[HAMK_ROW_AT(j)] : (SWAP_LAST ? pf[HAMK_ROW_AT(j)] : v[6][j]))
 #endif
   // k_{2 + KR} at the top of stage KR + 1: the result of the right-hand side just evaluated
   // (one base pointer per LDS row, each "array + constant + lane": offsets from a shared base beyond the 64 KiB a ds
@@ -1706,8 +1719,10 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
               const double di = (902880.0 / 7618050.0) * f0 + (3953664.0 / 7618050.0) * k3 +
                                 (3855735.0 / 7618050.0) * k4 + (-1371249.0 / 7618050.0) * k5 +
                                 (277020.0 / 7618050.0) * k6;
-              yt[j] = py[HAMK_ROW_AT(j)] + hh * di;
+              const double y_old = py[HAMK_ROW_AT(j)];
+              yt[j] = y_old + hh * di;
               ye[j] = hh * ((1.0 / 360.0) * f0 + (-128.0 / 4275.0) * k3 + (-2197.0 / 75240.0) * k4 + (1.0 / 50.0) * k5 + (2.0 / 55.0) * k6);
+              if constexpr (SWAP_LAST) { v[5][j] = y_old; v[6][j] = f0; }        // what a rejected attempt restarts from
             }
 #ifdef HAMK_PROBE_ALIAS_ROWS
             if constexpr (NL >= 3) {
@@ -1781,8 +1796,16 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
       if (!reject) {
         if (!(sgn * (tnew - t) > 0.0)) st |= ST_UNDERFLOW;
         t = tnew;
+        if constexpr (SWAP_LAST) {                          // y's row already holds the accepted state
 #pragma unroll
-        for (int j = 0; j < D; ++j) { py[HAMK_ROW_AT(j)] = yn[j]; pf[HAMK_ROW_AT(j)] = out[j]; }
+          for (int j = 0; j < D; ++j) pf[HAMK_ROW_AT(j)] = out[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < D; ++j) { py[HAMK_ROW_AT(j)] = yn[j]; pf[HAMK_ROW_AT(j)] = out[j]; }
+        }
+      } else if constexpr (SWAP_LAST) {                     // rejected: y and dydt come back from the scratch rows (rare)
+#pragma unroll
+        for (int j = 0; j < D; ++j) { py[HAMK_ROW_AT(j)] = v[5][j]; pf[HAMK_ROW_AT(j)] = v[6][j]; }
       }
       HAMK_MARK(2);
     }

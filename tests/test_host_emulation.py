@@ -797,3 +797,28 @@ def test_device_sampler_draws_the_numpy_samplers_bits(tmp_path):
             L.emu_sample(P(q), P(qd), LL(count), LL(start), ctypes.c_ulonglong(seed), spec.n, P(box[0]), P(box[1]), P(box[2]), P(box[3]))
             wq, wqd = E.sample_config(spec, start, count, seed)
             assert np.array_equal(q, wq) and np.array_equal(qd, wqd), (name, start)
+
+
+def test_rejected_attempts_restart_from_the_parked_state_on_host(emulate, oracle_lib):
+    """n = 13 (y and dydt are the only rows in LDS): across the last right-hand side of an attempt the trial state and the error
+    combination wait in THEIR rows, the old y / dydt in scratch (round 5) -- so a REJECTED attempt must bring them back.  A long
+    interval from a kicked start makes the controller reject (checked on the oracle's per-attempt trace); sub-step counts and states
+    against the oracle, trajectory by trajectory."""
+    spec = E.get("chain13")
+    o = oracle_lib.OracleSystem(spec)
+    L, _ = emulate(spec)
+    B = 6
+    q, qd = E.sample_config(spec, 5, B)
+    qd = qd + 2.5 * np.cos(1.0 + np.arange(spec.n * B, dtype=np.float64).reshape(spec.n, B))
+    p = o.to_phase_batch(q, qd)
+    dth = 0.25
+    rejected = 0
+    for i in range(B):
+        tr = o.evolve_ham_trace(q[:, i], p[:, i], np.array([0.0, dth]))[3]
+        rejected += sum(1 for (_, _, acc) in tr if acc == 0)
+    assert rejected >= 3, rejected                           # the path under test is taken
+    q3, p3, ns, st = q.copy(), p.copy(), np.zeros(B, np.int32), np.zeros(B, np.int32)
+    L.emu_step_ham(P(q3), P(p3), LL(B), ctypes.c_double(dth), I(st), I(ns))
+    sq, sp, sns = o.step_ham_batch(q, p, dth)
+    assert np.array_equal(ns, sns), (ns, sns)
+    assert relerr(q3, sq) < 1e-8 and relerr(p3, sp) < 1e-8
