@@ -612,6 +612,117 @@ int hamk_sample_batch(hamk_system* s, int64_t B, int64_t first_index, uint64_t s
   return st.finish();
 }
 
+// ---- a large ensemble in HOST arrays: its transfers under its own kernels ----------------------------------------------
+// Copy in -> kernel -> copy out back to back leaves the GPU idle for the PCIe time (C2's 64 MiB both ways: 1.3 ms around
+// an 11 ms launch of 1000 steps, around a 1.3 ms launch of 100).  Trajectories do not interact, so the ensemble is stepped
+// in pieces of piece_size() trajectories: piece c + 1 travels in and piece c - 1 travels out on the copy stream while piece c
+// steps on the handle's stream; only the first copy in and the last copy out are exposed.  Every piece runs the variant
+// bound for the WHOLE ensemble (bind_device saw B), one trajectory's arithmetic does not depend on its neighbours', so
+// the results are bitwise those of the single launch (tests/test_gpu_configs.py).  The host arrays are pageable, where
+// hipMemcpyAsync holds the calling thread for the length of the copy: the order of the calls below is the overlap.
+// Piece size, measured on MI355X (C2, B = 2^20, host-array call in ms at 32 / 100 / 1000 steps; one launch 1.75 / 2.66 / 13.6):
+// 2^17 4.28 / 4.32 / 13.2, 2^18 1.93 / 2.16 / 13.1, 2^19 1.53 / 2.12 / 12.8 (profiles/r05_host_pieces_sweep.txt).  A pageable
+// copy costs tens of microseconds before its first byte moves, and a piece of 2^18 trajectories runs its kernel at 0.91 of
+// the full launch's rate (2^19: 0.97): few, large pieces.
+static int64_t piece_size() {
+  static const int64_t v = [] {
+    const char* e = test_env("HAMK_HOST_PIECE");                  // (test override: another size, a multiple of 256)
+    const long long x = e ? std::atoll(e) : 0;
+    return (int64_t)((x >= 256 && x % 256 == 0) ? x : (1 << 19));
+  }();
+  return v;
+}
+static bool host_pieces_on() {
+  static const bool off = [] { const char* e = test_env("HAMK_HOST_PIECES"); return e && e[0] == '0'; }();
+  return !off;
+}
+
+static int stage_slot(hamk_system* s, size_t slot, size_t bytes, void** dev) {
+  DevState* d = s->cur;
+  while (slot >= d->stage_buf.size()) { d->stage_buf.push_back(nullptr); d->stage_cap.push_back(0); }
+  if (d->stage_cap[slot] < bytes) {
+    HIP_TRY(hipStreamSynchronize(d->stream));                  // nobody may still be using the old block
+    if (d->stage_buf[slot]) hipFree(d->stage_buf[slot]);
+    d->stage_buf[slot] = nullptr; d->stage_cap[slot] = 0;
+    HIP_TRY(hipMalloc(&d->stage_buf[slot], bytes));
+    d->stage_cap[slot] = bytes;
+  }
+  *dev = d->stage_buf[slot];
+  return HAMK_OK;
+}
+
+static int rk4_steps_host_pieces(hamk_system* s, int64_t B, double* q, double* p, double dt, int32_t nsteps, double drift_tol,
+                                 int32_t* status) {
+  DevState* d = s->cur;
+  const int n = s->base.n;
+  const int64_t kPiece = piece_size();
+  const int npieces = (int)((B + kPiece - 1) / kPiece);
+  if (!d->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+  while ((int)d->piece_events.size() < 2 * npieces + 1) {
+    hipEvent_t e = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    d->piece_events.push_back(e);
+  }
+  void *vq = nullptr, *vp = nullptr, *vs = nullptr;
+  TRY(stage_slot(s, 0, sizeof(double) * (size_t)n * B, &vq));
+  TRY(stage_slot(s, 1, sizeof(double) * (size_t)n * B, &vp));
+  if (status) TRY(stage_slot(s, 2, sizeof(int32_t) * (size_t)B, &vs));
+  double *dq = (double*)vq, *dp = (double*)vp;
+  int32_t* dst = (int32_t*)vs;
+  hipStream_t S = d->stream, C = d->copy_stream;
+  // what the handle's stream was doing with the staging blocks comes first
+  hipEvent_t start = d->piece_events[2 * npieces];
+  HIP_TRY(hipEventRecord(start, S));
+  HIP_TRY(hipStreamWaitEvent(C, start, 0));
+  // piece c: trajectories [c kPiece, c kPiece + bc) -- on the device a compact [n][bc] block at offset n c kPiece
+  auto count = [&](int c) { return std::min<int64_t>(kPiece, B - (int64_t)c * kPiece); };
+  auto copy_in = [&](int c) -> int {
+    const int64_t at = (int64_t)c * kPiece, bc = count(c);
+    for (int j = 0; j < n; ++j) {
+      HIP_TRY(hipMemcpyAsync(dq + (size_t)n * at + (size_t)j * bc, q + (size_t)j * B + at, sizeof(double) * bc, hipMemcpyHostToDevice, C));
+      HIP_TRY(hipMemcpyAsync(dp + (size_t)n * at + (size_t)j * bc, p + (size_t)j * B + at, sizeof(double) * bc, hipMemcpyHostToDevice, C));
+    }
+    HIP_TRY(hipEventRecord(d->piece_events[2 * c], C));
+    return HAMK_OK;
+  };
+  auto step = [&](int c) -> int {
+    const int64_t at = (int64_t)c * kPiece;
+    double *xq = dq + (size_t)n * at, *xp = dp + (size_t)n * at;
+    int32_t* xs = dst ? dst + at : nullptr;
+    long long b = count(c);
+    int ns = nsteps;
+    void* args[] = {&xq, &xp, &b, &dt, &ns, &drift_tol, &xs};
+    HIP_TRY(hipStreamWaitEvent(S, d->piece_events[2 * c], 0));
+    TRY(launch(s, K_RK4, b, args));
+    HIP_TRY(hipEventRecord(d->piece_events[2 * c + 1], S));
+    return HAMK_OK;
+  };
+  auto copy_out = [&](int c) -> int {
+    const int64_t at = (int64_t)c * kPiece, bc = count(c);
+    HIP_TRY(hipStreamWaitEvent(C, d->piece_events[2 * c + 1], 0));
+    for (int j = 0; j < n; ++j) {
+      HIP_TRY(hipMemcpyAsync(q + (size_t)j * B + at, dq + (size_t)n * at + (size_t)j * bc, sizeof(double) * bc, hipMemcpyDeviceToHost, C));
+      HIP_TRY(hipMemcpyAsync(p + (size_t)j * B + at, dp + (size_t)n * at + (size_t)j * bc, sizeof(double) * bc, hipMemcpyDeviceToHost, C));
+    }
+    if (status) HIP_TRY(hipMemcpyAsync(status + at, dst + at, sizeof(int32_t) * bc, hipMemcpyDeviceToHost, C));
+    return HAMK_OK;
+  };
+  int rc = copy_in(0);
+  if (rc == HAMK_OK) rc = step(0);
+  for (int c = 1; c < npieces && rc == HAMK_OK; ++c) {
+    rc = copy_in(c);
+    if (rc == HAMK_OK) rc = step(c);
+    if (rc == HAMK_OK) rc = copy_out(c - 1);
+  }
+  if (rc == HAMK_OK) rc = copy_out(npieces - 1);
+  // the call returns with both streams drained, on the failure paths too: the host arrays are the caller's again
+  const hipError_t e1 = hipStreamSynchronize(C), e2 = hipStreamSynchronize(S);
+  if (rc != HAMK_OK) return rc;
+  HIP_TRY(e1);
+  HIP_TRY(e2);
+  return HAMK_OK;
+}
+
 int hamk_rk4_steps_checked(hamk_system* s, int64_t B, double* q, double* p, double dt, int32_t nsteps, double drift_tol,
                            int32_t* status, int32_t mem) {
   TRY(check_call(s, B, mem));
@@ -620,6 +731,7 @@ int hamk_rk4_steps_checked(hamk_system* s, int64_t B, double* q, double* p, doub
   if (drift_tol != drift_tol) return fail(HAMK_ERR_INVALID, "drift_tol is NaN");
   if (B == 0) return HAMK_OK;
   TRY(bind_device(s, B, K_RK4));
+  if (mem == HAMK_MEM_HOST && B >= 2 * piece_size() && (int64_t)nsteps * s->base.n >= 64 && host_pieces_on()) return rk4_steps_host_pieces(s, B, q, p, dt, nsteps, drift_tol, status);
   Stager st(s, mem);
   const size_t cnt = (size_t)s->base.n * B;
   double *xq, *xp; int32_t* dst;

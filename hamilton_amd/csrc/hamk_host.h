@@ -137,6 +137,10 @@ struct DevState {
   // where a hipMalloc/hipFree pair per array per call would dominate
   std::vector<void*> stage_buf;
   std::vector<size_t> stage_cap;
+  // a LARGE host-array ensemble is stepped piece by piece, the transfers of one piece under the kernel of another
+  // (hamk_api.cpp rk4_steps_host_pieces): the copies' own stream and the events that order it against `stream`
+  hipStream_t copy_stream = nullptr;
+  std::vector<hipEvent_t> piece_events;
   // pinned, device-mapped arena for SMALL host-pointer calls (the reference's one-trajectory
   // stepHam per frame): the kernel reads and writes host memory directly over PCIe -- a launch
   // and a stream synchronisation per call, no hipMemcpy at all.  The block is allocated COHERENT
@@ -160,6 +164,9 @@ struct DevState {
     for (void*& b : stage_buf) if (b) { hipFree(b); b = nullptr; }
     stage_cap.assign(stage_cap.size(), 0);
     if (pin) { hipHostFree(pin); pin = pin_dev = nullptr; }
+    for (hipEvent_t e : piece_events) hipEventDestroy(e);
+    piece_events.clear();
+    if (copy_stream) { hipStreamDestroy(copy_stream); copy_stream = nullptr; }
   }
 };
 

@@ -724,3 +724,29 @@ def test_sampler_self_check_catches_a_wrong_bit(tmp_path):
     assert "DREW" in ok.stdout, ok.stdout + ok.stderr
     bad = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=dict(os.environ, HAMK_SELFCHECK_FAULT="sample"))
     assert "REFUSED" in bad.stdout and "hamk_sample_k does not draw the bits" in bad.stdout, bad.stdout + bad.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B,nsteps,drift_tol", [("doublePendulum", 2 * 524288 + 777, 40, 1e-13), ("spring", 3 * 524288, 22, 0.0),
+                                                     ("chain8", 2 * 524288 + 64, 8, 0.0)])
+def test_large_host_arrays_are_stepped_in_pieces(api, name, B, nsteps, drift_tol):
+    """A HOST-array RK4 call on a large ensemble runs piece by piece, the transfers of one piece under the kernel of another
+    (hamk_api.cpp rk4_steps_host_pieces): states and status words are bitwise those of the one launch on device-resident
+    tensors -- ragged last piece, status array present, energy check on (its flags are per trajectory)."""
+    import torch
+    spec = E.get(name)
+    s = api.system_from_spec(spec)
+    cfg = api.sampleConfig(s, spec.q_box, spec.qd_box, 0, B, E.SEED, torch.device("cuda", 0))
+    ph = api.toPhase(s, cfg)
+    hq, hp = ph.positions.cpu().numpy().copy(), ph.momenta.cpu().numpy().copy()
+    dev = api.rk4Steps(spec.dt, nsteps, s, ph, drift_tol=drift_tol)
+    dev_status = s.last_status.cpu().numpy().copy()
+    host = api.rk4Steps(spec.dt, nsteps, s, api.Phase(hq, hp), inplace=True, drift_tol=drift_tol)
+    host_status = np.asarray(s.last_status)
+    assert np.shares_memory(host.positions, hq)
+    np.testing.assert_array_equal(hq, dev.positions.cpu().numpy())
+    np.testing.assert_array_equal(hp, dev.momenta.cpu().numpy())
+    np.testing.assert_array_equal(host_status, dev_status)
+    if drift_tol > 0:
+        assert (host_status != 0).any(), "the energy check at this tolerance flags lanes: the status words are not all zero"
+    record(test="host_pieces", system=name, B=B, nsteps=nsteps, flagged=int((host_status != 0).sum()))
