@@ -7,8 +7,9 @@ before the timed region.  Workload at N=1 = BASELINE.json configs[1]: double pen
 (System 4 2, Examples.hs:75-94), 1,048,576 random Phase-2 initial conditions, fp64.
 
   python bench.py --gpus 1 --steps 10 --warmup 2
+  python bench.py --gpus N --steps K --warmup W          (starts its N ranks itself: one process per GPU over RCCL)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W        (the driver's launch; --gpus must equal WORLD_SIZE)
 
 Multi-GPU: the ensemble shards by contiguous global index range (weak scaling: every rank
 owns --batch trajectories); there is no data-path collective; one RCCL all_gather of the
@@ -119,7 +120,9 @@ class ClockSampler:
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node.  Under torch.distributed.run it must equal WORLD_SIZE; without a launcher "
+                         "(no WORLD_SIZE in the environment) N > 1 makes bench.py start N ranks ITSELF (torch.distributed.run on 127.0.0.1)")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--system", default="doublePendulum")
@@ -484,11 +487,33 @@ def stepham_bench(a, s, spec, dt, state, dist, dev, rank, world):
         dist.destroy_process_group()
 
 
+def self_launch(gpus: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here -- the same command the driver
+    uses (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1, a free port) -- and hand its exit code back.
+    Rank 0's JSON line goes to this process's stdout unchanged."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and (a.gpus or 1) > 1:
+        raise SystemExit(self_launch(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus is not None and a.gpus != world:           # a line that says n_gpus = N must have run N ranks
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}, or drop the launcher "
+                         f"and let --gpus start the ranks")
     dist = None
     if world > 1 or a.force_dist:
         import torch.distributed as dist
@@ -498,6 +523,9 @@ def main():
             local_rank = local_rank % max(1, torch.cuda.device_count())      # ranks may share a GPU; collectives run on host copies
             dist.init_process_group(backend="gloo")
         else:
+            if world > torch.cuda.device_count():
+                raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node shows {torch.cuda.device_count()} "
+                                 f"(--dist-backend gloo lets ranks share a GPU)")
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

@@ -133,6 +133,25 @@ def double_pendulum(m1: float = 1.0, m2: float = 1.0) -> SystemSpec:
         cite="app/Examples.hs:75-94")
 
 
+def double_pendulum_readme() -> SystemSpec:
+    """README.md:88-103, the package's worked example: masses (1,1,2,2), y measured from the pivot (`-cos`, no `1 -`), potential
+    `(y1 + 2 * y2) * 5`; config0 = Cfg (1, 0) (0, 0.5) (README.md:124-126).  Same dynamics as `double_pendulum(1, 2)`; U differs by a constant."""
+    def f(q, o):
+        t1, t2 = q
+        return [o.sin(t1), -o.cos(t1), o.sin(t1) + o.sin(t2) / 2, -o.cos(t1) - o.cos(t2) / 2]
+
+    def u(x, o):
+        return (x[1] + 2 * x[3]) * 5
+
+    return SystemSpec(
+        name="doublePendulumReadme", m=4, n=2, inertia=(1.0, 1.0, 2.0, 2.0), f=f, u=u,
+        u_space=U_CARTESIAN,
+        q0=(1.0, 0.0), qd0=(0.0, 0.5),
+        q_box=((-math.pi, math.pi), (-math.pi, math.pi)),
+        qd_box=((-1.0, 1.0), (-1.0, 1.0)),
+        cite="README.md:88-103, :124-126")
+
+
 def room(theta_deg: float = 45.0) -> SystemSpec:
     """Examples.hs:96-116; default :268-278 (-a 45); the app converts degrees to radians."""
     th = theta_deg / 180 * math.pi      # Examples.hs:392
@@ -355,6 +374,7 @@ def pendulums(N: int) -> SystemSpec:
 REGISTRY = {
     "pendulum": pendulum,
     "doublePendulum": double_pendulum,
+    "doublePendulumReadme": double_pendulum_readme,
     "room": room,
     "twoBody": two_body,
     "spring": spring,

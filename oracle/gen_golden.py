@@ -49,6 +49,15 @@ def fmt(x) -> str:
     return mp.nstr(mp.mpf(x), 30, min_fixed=0, max_fixed=0)
 
 
+# Every Python float that meets a sympy expression becomes the exact rational it denotes.  Left to its default, sympy turns the float
+# into a 53-bit Float and does arithmetic on it on the spot -- `beta * (r + 1.5)` is distributed with a ROUNDED beta * 1.5,
+# exp(-21.97 (y + 1)) becomes 2.868e-10 * exp(-21.97 y) -- and the fixture would carry fp64 roundings that exactify() cannot undo
+# (found in round 6 against the hand-written fixtures of gen_golden_byhand.py: up to 1e-15 relative in the wall forces of room / spring / bezier).
+from sympy.core.sympify import converter as _converter   # noqa: E402
+import math as _math                                      # noqa: E402
+_converter[float] = lambda f: sp.Rational(*f.as_integer_ratio()) if _math.isfinite(f) else sp.Float(f)
+
+
 def symbolic(spec: E.SystemSpec):
     q = sp.symbols(f"q0:{spec.n}", real=True)
     ops = E._Ops(sp)

@@ -15,16 +15,10 @@ STEPS=${STEPS:-20}
 WARMUP=${WARMUP:-5}
 GPUS=${GPUS:-"1 2 4 8"}
 mkdir -p "$(dirname "$OUT")"
-port=29600
 run() {   # N, then bench.py arguments
   local n=$1; shift
-  port=$((port + 1))
-  if [ "$n" -eq 1 ]; then
-    python bench.py --gpus 1 --steps "$STEPS" --warmup "$WARMUP" --no-cpu-baseline "$@" | tail -1 >> "$OUT"
-  else
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port "$port" \
-      bench.py --gpus "$n" --steps "$STEPS" --warmup "$WARMUP" --no-cpu-baseline "$@" | tail -1 >> "$OUT"
-  fi
+  # bench.py starts its own ranks for --gpus N > 1 (torch.distributed.run, one process per GPU, 127.0.0.1)
+  python bench.py --gpus "$n" --steps "$STEPS" --warmup "$WARMUP" --no-cpu-baseline "$@" | tail -1 >> "$OUT"
 }
 for n in $GPUS; do
   run "$n" --system doublePendulum --scaling weak

@@ -51,3 +51,35 @@ def test_clock_sampler_without_a_gpu_is_silent(hamk_lib):
     c = b.ClockSampler(0)                                         # no device here: no path, no thread, no figure
     c.start()
     assert c.stop() is None or isinstance(c.stop(), float)
+
+
+def test_gpus_flag_starts_one_rank_per_gpu(hamk_lib, monkeypatch):
+    """`python bench.py --gpus N` with no launcher around it starts N ranks through torch.distributed.run on 127.0.0.1 and passes its own
+    arguments on; under a launcher whose WORLD_SIZE disagrees with --gpus it refuses to print a line."""
+    import subprocess
+
+    import pytest
+    b = _bench()
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        b.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert os.path.samefile(cmd[cmd.index("--master-port") + 2], os.path.join(ROOT, "bench.py"))
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher: --gpus must be the world it was started in
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        b.main()
+    assert "WORLD_SIZE=2" in str(e.value.code)

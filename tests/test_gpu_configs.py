@@ -664,6 +664,35 @@ def test_bench_with_two_ranks_on_one_gpu(api, tmp_path, scaling):
     record(test="bench_two_ranks_one_gpu", scaling=scaling, line=out)
 
 
+@pytest.mark.gpu
+def test_bench_gpus_flag_starts_its_own_ranks(api, tmp_path):
+    """`python bench.py --gpus 2` with NO launcher around it (the shape of the driver's 1-GPU command with another N): bench.py starts the
+    two ranks itself (torch.distributed.run on 127.0.0.1, a free port) and the line says n_gpus = 2 -- round 5's flag was parsed and never
+    read, so such a call measured one GPU and said so only in `n_gpus`.  Same bits as one rank over the same global ensemble."""
+    import json as _json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-isa", "--rk4-per-step", "50"]
+    two, one = str(tmp_path / "two.npz"), str(tmp_path / "one.npz")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--batch", "4096", "--dump-state", two] + common,
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["rccl"]["world"] == 2 and out["config"]["trajectories_per_gpu"] == 4096
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "8192", "--dump-state", one] + common,
+                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    a, b = np.load(two), np.load(one)
+    assert a["q"].shape == (2, 8192) and np.array_equal(a["q"], b["q"]) and np.array_equal(a["p"], b["p"])
+    # a launcher whose world disagrees with --gpus is an error, not a silently smaller run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch", "4096"] + common,
+                         capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+    record(test="bench_self_launch_two_ranks", line=out)
+
+
 # ---------------------------------------------------------------------------------------------
 # C5 multi-step parity where it means something (round 5)
 # ---------------------------------------------------------------------------------------------

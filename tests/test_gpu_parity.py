@@ -11,7 +11,7 @@ results agree to roundoff, not bitwise.
 import numpy as np
 import pytest
 
-from conftest import ALL_GOLDEN_SYSTEMS, CHAIN_GOLDEN_SYSTEMS, REFERENCE_SYSTEMS, fvec, load_golden
+from conftest import ALL_GOLDEN_SYSTEMS, BYHAND_SYSTEMS, CHAIN_GOLDEN_SYSTEMS, REFERENCE_SYSTEMS, fvec, load_golden
 from hamilton_amd import examples as E
 
 pytestmark = pytest.mark.gpu
@@ -74,6 +74,14 @@ def check_golden_points(api, s, name):
 def test_golden_points(api, systems, name):
     spec, s, _ = systems[name]
     check_golden_points(api, s, name)
+
+
+@pytest.mark.parametrize("name", BYHAND_SYSTEMS)
+def test_by_hand_golden_points(api, name):
+    """The reference's own systems against fixtures that share nothing with hamilton_amd/examples.py (hand-written mass matrix,
+    potential and Hamilton's equations from app/Examples.hs / README.md at 50 digits, oracle/gen_golden_byhand.py) -- incl. the
+    README's worked double pendulum (masses 1 1 2 2) at its config0."""
+    check_golden_points(api, api.system_from_spec(E.get(name)), "byhand:" + name)
 
 
 @pytest.mark.parametrize("mapping", ["default", "large-ensemble", "lane", "quad", "wave"])

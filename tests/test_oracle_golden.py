@@ -7,7 +7,7 @@ SURVEY.md section 8c: 1e-12 * max(1, |y|), loosened by cond(K) where K is ill-co
 import numpy as np
 import pytest
 
-from conftest import ALL_GOLDEN_SYSTEMS, CHAIN_GOLDEN_SYSTEMS, REFERENCE_SYSTEMS, fvec, load_golden
+from conftest import ALL_GOLDEN_SYSTEMS, BYHAND_SYSTEMS, CHAIN_GOLDEN_SYSTEMS, REFERENCE_SYSTEMS, fvec, load_golden
 from hamilton_amd import examples as E
 
 T1 = 1e-12
@@ -71,6 +71,51 @@ def test_oracle_matches_the_closed_form_chain_fixtures(oracle_lib, name):
         dq, dp = o.hameqs(q, p)
         np.testing.assert_allclose(dq, fvec(pt["dq"]), rtol=0, atol=tol)
         np.testing.assert_allclose(dp, fvec(pt["dp"]), rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("name", BYHAND_SYSTEMS)
+def test_oracle_matches_the_by_hand_fixtures(oracle_lib, name):
+    """The reference's own systems (app/Examples.hs:61-162, README.md:88-103) against 50-digit values of mass matrix, potential and
+    Hamilton's equations WRITTEN OUT BY HAND (oracle/gen_golden_byhand.py: nothing imported from hamilton_amd, no tape, no AD) -- the
+    only fixtures a transcription error in hamilton_amd/examples.py cannot hide behind."""
+    o, g = oracle_lib.OracleSystem(E.get(name)), load_golden("byhand:" + name)
+    assert len(g["points"]) >= 13
+    for pt in g["points"]:
+        q, qd, p = fvec(pt["q"]), fvec(pt["qd"]), fvec(pt["p"])
+        assert len(q) == o.n and len(pt["x"]) == o.m
+        tol = tol_for(pt, p, fvec(pt["dp"]), fvec(pt["dq"]))
+        np.testing.assert_allclose(o.coords(q), fvec(pt["x"]), rtol=0, atol=tol)
+        np.testing.assert_allclose(o.momenta(q, qd), p, rtol=0, atol=tol)
+        np.testing.assert_allclose(o.velocities(q, p), fvec(pt["vel"]), rtol=0, atol=tol)
+        for f, key, args in ((o.keC, "keC", (q, qd)), (o.keP, "keP", (q, p)), (o.pe, "pe", (q,)),
+                             (o.lagrangian, "lagrangian", (q, qd)), (o.hamiltonian, "hamiltonian", (q, p))):
+            assert abs(f(*args) - float(pt[key])) <= tol, (name, key)
+        dq, dp = o.hameqs(q, p)
+        np.testing.assert_allclose(dq, fvec(pt["dq"]), rtol=0, atol=tol)
+        np.testing.assert_allclose(dp, fvec(pt["dp"]), rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("name", [n for n in BYHAND_SYSTEMS if n != "doublePendulumReadme"])
+def test_by_hand_and_symbolic_fixtures_agree(name):
+    """Two derivations that share no code -- sympy over the Python restatement (gen_golden.py) and the hand-written mechanics
+    (gen_golden_byhand.py) -- at the same points, digit for digit (both files carry 30 digits; 1e-25 leaves room for the last ones)."""
+    import mpmath as mp
+    mp.mp.dps = 40
+    a, b = load_golden(name)["points"], load_golden("byhand:" + name)["points"]
+    assert len(a) == len(b)
+    for pa, pb in zip(a, b):
+        assert pa["q"] == pb["q"] and pa["qd"] == pb["qd"]
+        for key in ("p", "x", "vel", "dq", "dp", "keC", "keP", "pe", "lagrangian", "hamiltonian"):
+            va = pa[key] if isinstance(pa[key], list) else [pa[key]]
+            vb = pb[key] if isinstance(pb[key], list) else [pb[key]]
+            for u, w in zip(va, vb):
+                assert abs(mp.mpf(u) - mp.mpf(w)) <= mp.mpf(10) ** -25 * (1 + abs(mp.mpf(u))), (name, key, u, w)
+
+
+def test_two_body_angle_is_cyclic_in_the_by_hand_fixture():
+    """twoBody's potential depends on r only (app/Examples.hs:138): dp_theta = 0 exactly, in the fixture and in the oracle."""
+    for pt in load_golden("byhand:twoBody")["points"]:
+        assert float(pt["dp"][1]) == 0.0
 
 
 def test_hessian_layout_is_dJ_dqi(systems):
