@@ -90,6 +90,13 @@ std::string validate_tape(const hamk_op* ops, int nops, int n_in, const int32_t*
 // kernels, M up to 64).
 // input_exprs (optional): expression to use for INPUT j instead of in[j] (composition u . f);
 // tc_name: the trig cache variable the body's sincos sites use.
+// Values of the tape being emitted that somebody outside emit_body reads by name (the tape's outputs): set by generate_source
+// before every call.  A value in it is always materialised.
+static std::vector<char> g_emit_is_output;
+static void mark_outputs(size_t nops, const int32_t* outs, int n_out) {
+  g_emit_is_output.assign(nops, 0);
+  for (int k = 0; k < n_out; ++k) g_emit_is_output[(size_t)outs[k]] = 1;
+}
 static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const char* pfx,
                      const std::vector<std::vector<int>>* sink_outs = nullptr,
                      const std::vector<std::string>* input_exprs = nullptr, const char* tc_name = "tc",
@@ -102,6 +109,23 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
     if (ops[i].op == HAMK_OP_COS && cos_of[ops[i].a] < 0) cos_of[ops[i].a] = i;
   }
   std::vector<char> done(nops, 0);
+  // 1 / sqrt(x) -- every inverse distance of a gravitational or electrostatic potential -- as ONE chain through hamk::rsqrt_of
+  // (v_rsq_f64 + one third-order step, derivatives -r^3 / 2 and 3 r^5 / 4 from the same r) instead of a correctly rounded sqrt,
+  // its derivative rule, a reciprocal and ITS rule: where the square root has no other reader and is not an output.  Round 6:
+  // threeBodyPolar 1 398 -> see DESIGN section 4 instructions per RK4 step.
+  std::vector<int> uses(nops, 0), fused_rsqrt(nops, 0);
+  for (int i = 0; i < nops; ++i) {
+    const hamk_op& p = ops[i];
+    if (p.op == HAMK_OP_CONST || p.op == HAMK_OP_INPUT) continue;
+    ++uses[p.a];
+    if (is_binary(p.op)) ++uses[p.b];
+  }
+  for (int i = 0; i < nops; ++i)
+    if (ops[i].op == HAMK_OP_RECIP && ops[ops[i].a].op == HAMK_OP_SQRT && uses[ops[i].a] == 1 &&
+        !((size_t)ops[i].a < g_emit_is_output.size() && g_emit_is_output[(size_t)ops[i].a]) && !(sink_outs && !(*sink_outs)[ops[i].a].empty())) {
+      fused_rsqrt[i] = 1;
+      done[ops[i].a] = 2;                                   // the square root itself is never emitted
+    }
   int put_seq = 0;
   std::vector<int> slot_of(nops, -1);          // operand value id -> trig cache slot
   int nslots = 0;
@@ -155,7 +179,10 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
             << ", " << where << ");\n";
         }
       } break;
-      default: o << "const auto " << v(i) << " = hamk::" << unary_name(p.op) << "(" << v(p.a) << ");\n"; break;
+      default:
+        if (fused_rsqrt[i]) o << "const auto " << v(i) << " = hamk::rsqrt_of(" << v(ops[p.a].a) << ");\n";
+        else o << "const auto " << v(i) << " = hamk::" << unary_name(p.op) << "(" << v(p.a) << ");\n";
+        break;
     }
     done[i] = 1;
     if (sink_outs) {
@@ -483,6 +510,35 @@ int distinct_jacobian_entries(const SystemDesc& d) {
   return (int)distinct.size();
 }
 
+// What one first-order forward sweep of f costs a lane that runs it with COMPILE-TIME seeds (hamk_quad.hpp): the dependency set of
+// every tape value is known here, and an operation computes only the gradient entries its operands make non-zero -- a product
+// with a constant or a function of one value costs |support| operations, a sum costs the OVERLAP of its operands' supports (an
+// entry only one operand has is passed through), a product of two values their union.  x = 2 q + A sin q + B cos q: 2 n per
+// output although the Jacobian is dense; a map whose every operation depends on every input: (tape length) x n.
+long long forward_gradient_work(const SystemDesc& d) {
+  const int n = d.n, nops = (int)d.f_ops.size();
+  std::vector<std::vector<char>> sup(nops, std::vector<char>(n, 0));
+  auto count = [&](const std::vector<char>& v) { long long c = 0; for (char x : v) c += x; return c; };
+  long long work = 0;
+  for (int i = 0; i < nops; ++i) {
+    const hamk_op& p = d.f_ops[i];
+    if (p.op == HAMK_OP_CONST) continue;
+    if (p.op == HAMK_OP_INPUT) { sup[i][p.a] = 1; continue; }
+    if (is_binary(p.op)) {
+      long long both = 0, any = 0;
+      for (int j = 0; j < n; ++j) { const char a = sup[p.a][j], b = sup[p.b][j]; sup[i][j] = a | b; both += a & b; any += a | b; }
+      const bool ca = d.f_ops[p.a].op == HAMK_OP_CONST, cb = d.f_ops[p.b].op == HAMK_OP_CONST;
+      if (p.op == HAMK_OP_ADD || p.op == HAMK_OP_SUB) work += both;
+      else if (ca || cb) work += any;                       // scaling
+      else work += count(sup[p.a]) + count(sup[p.b]);       // value(a) db + da value(b)
+    } else {
+      sup[i] = sup[p.a];
+      work += (p.op == HAMK_OP_NEG) ? 0 : count(sup[i]) + 2;
+    }
+  }
+  return work;
+}
+
 std::string generate_source(const SystemDesc& d) {
   std::ostringstream o;
   o << "// generated by libhamk (hamk_codegen.cpp) from the expression tape of one System " << d.m << " " << d.n << "\n";
@@ -516,6 +572,7 @@ std::string generate_source(const SystemDesc& d) {
   bool inertia_pos = true;
   for (double w : d.inertia) inertia_pos = inertia_pos && (w > 0.0);
   o << "  static constexpr bool INERTIA_POS = " << (inertia_pos ? "true" : "false") << ";\n";
+  o << "  static constexpr bool QUAD_DENSE = " << ((quad && d.quad_dense) ? "true" : "false") << ";\n";
   o << "  __device__ __forceinline__ static constexpr double inertia(int k) {\n";
   o << "    constexpr double w[M] = {";
   for (int k = 0; k < d.m; ++k) o << (k ? ", " : "") << lit(d.inertia[k]);
@@ -523,12 +580,16 @@ std::string generate_source(const SystemDesc& d) {
   // coordinate map f: generalized -> cartesian                       (_sysCoords, Hamilton.hs:220)
   o << "  template <class A, int TRIG, class TC> __device__ __forceinline__ static void coords(const A (&in)[N], A (&x)[M], TC& tc) {\n";
   std::vector<int> slot_operand;
+  auto mark_f = [&] { mark_outputs(d.f_ops.size(), d.f_outs.data(), d.m); };
+  auto mark_u = [&] { mark_outputs(d.u_ops.size(), &d.u_out, 1); };
+  mark_f();
   const int ntrig_f = emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f", nullptr, nullptr, "tc", &slot_operand);
   for (int k = 0; k < d.m; ++k) o << "    x[" << k << "] = hamk::lift<A>(" << value_name(d.f_ops, "f", d.f_outs[k]) << ");\n";
   o << "  }\n";
   // potential                                                         (_sysPotential, Hamilton.hs:223 / :254)
   const int nu = d.u_space == HAMK_U_CARTESIAN ? d.m : d.n;
   o << "  template <class A, int TRIG, class TC> __device__ __forceinline__ static A potential(const A (&in)[" << nu << "], TC& tc) {\n";
+  mark_u();
   const int ntrig_u = emit_body(o, d.u_ops.data(), (int)d.u_ops.size(), "u");
   o << "    return hamk::lift<A>(" << value_name(d.u_ops, "u", d.u_out) << ");\n";
   o << "  }\n";
@@ -549,6 +610,7 @@ std::string generate_source(const SystemDesc& d) {
     o << "  template <class A, int TRIG, class TC, class TCF> __device__ __forceinline__ static A potential_after_f(const A (&in)[" << nu
       << "], TC& tc, TCF& tcf) {\n";
     if (any) {
+      mark_u();
       emit_body(o, d.u_ops.data(), (int)d.u_ops.size(), "u", nullptr, nullptr, "tc", nullptr, "TRIG", &f_slot_of_input);
       o << "    return hamk::lift<A>(" << value_name(d.u_ops, "u", d.u_out) << ");\n";
     } else {
@@ -561,16 +623,19 @@ std::string generate_source(const SystemDesc& d) {
   std::vector<std::vector<int>> sink_outs(d.f_ops.size());
   for (int k = 0; k < d.m; ++k) sink_outs[d.f_outs[k]].push_back(k);
   std::vector<int> put_order;                               // output index of the SEQ-th put
+  mark_f();
   emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f", &sink_outs, nullptr, "tc", nullptr, "TRIG", nullptr, &put_order);
   o << "  }\n";
   // f with a sink, followed by the potential on the same SSA values (u . f when U is cartesian):
   // no array of M outputs is ever materialised
   o << "  template <class A, int TRIG, class IN, class TC, class TCU, class Sink> __device__ __forceinline__ static A coords_sink_u(const IN& in, TC& tc, TCU& tcu, Sink& sink) {\n";
+  mark_f();
   emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f", &sink_outs);
   {
     std::vector<std::string> u_in;
     if (d.u_space == HAMK_U_CARTESIAN) for (int k = 0; k < d.m; ++k) u_in.push_back(value_name(d.f_ops, "f", d.f_outs[k]));
     else for (int j = 0; j < d.n; ++j) u_in.push_back("in[" + std::to_string(j) + "]");
+    mark_u();
     emit_body(o, d.u_ops.data(), (int)d.u_ops.size(), "u", nullptr, &u_in, "tcu", nullptr, "hamk::TRIG_FULL");
     o << "    return hamk::lift<A>(" << value_name(d.u_ops, "u", d.u_out, &u_in) << ");\n";
   }

@@ -412,11 +412,34 @@ HAMK_DEV void sincos_f64(double x, double& s, double& c) {
 // 1/d for normal-range d: hardware estimate + two Newton steps (5 instructions instead
 // of the ~11 of an IEEE divide with scaling/fix-up); <= 1 ulp.  Used for pivots and
 // derivative factors, never where the reference's semantics hinge on exact division.
+// Domain edges: d = 0 or +-inf makes the Newton step inf * 0 = NaN where a division gives +-inf / 0 -- the derivative rules of sqrt,
+// log, asin ... (d2_* below) therefore return NaN, not `ad`'s Infinity, AT the edge of their domain (sqrt 0, log 0, asin 1); both are
+// non-finite, the trajectory is flagged HAMK_ST_NONFINITE either way, and the three instructions a guard costs are paid by every
+// evaluation of threeBodyPolar's 1/|x_i - x_j| (measured round 5: frcp there is 1 546 -> 1 398 instructions per step).  Denormal d
+// flushes to the same result.  tests/test_gpu_parity.py::test_derivative_rules_at_the_edge_of_their_domain states it.
 HAMK_DEV double frcp(double d) {
   double r = __builtin_amdgcn_rcp(d);
   r = fma(fma(-d, r, 1.0), r, r);
   r = fma(fma(-d, r, 1.0), r, r);
   return r;
+}
+
+// |yerr| / |D| of the step-size controller (cstd.c: r = max |yerr / D|): 2n IEEE divisions per attempt, 11 instructions each.  Round 6
+// built the cheaper quotient the round-5 review asked for -- frcp + one multiplication (6 instructions) -- in two forms and measured
+// both against the division on one box (profiles/r06_rkf_fold_ab.jsonl; identical accept / reject sequences on every lane):
+//   behind a range branch (the division where D is zero, denormal or non-finite)   chain8 -3 ... -4 %, chain10 -13 %, chain12 -10 %,
+//                                                                                 chain13..16 -1 ... -6 % stepHam/s;
+//   branch-free (a select supplies what the division would overflow to)             chain8 +1 / 0 %, chain10 -3 / +1 %, chain12 -4 / -5 %,
+//                                                                                 chain13..16 0 ... -4 %, threeBodyPolar +2 %.
+// Neither pays: the division stays, and the variants are gone (git history: the commit that adds this comment).
+HAMK_DEV double err_ratio(double e, double d) { return e / d; }
+#define HAMK_RKF_ERR_RATIO(e, d) hamk::err_ratio((e), (d))
+
+// 1 / sqrt(d) for normal-range d > 0: hardware estimate + one third-order step (6 instructions, <= 1 ulp); d = 0 and d < 0 give NaN
+HAMK_DEV double frsqrt(double d) {
+  const double y = __builtin_amdgcn_rsq(d);
+  const double e = fma(-(d * y), y, 1.0);
+  return fma(y * e, fma(0.375, e, 0.5), y);
 }
 
 template <class A> HAMK_DEV A recip(const A& x) {
@@ -760,6 +783,14 @@ HAMK_DEV void d2_atan2(double y, double x, double& f0, double& fa, double& fb, d
   const double i2 = frcp(fma(y, y, x * x));
   f0 = ::atan2(y, x); fa = x * i2; fb = -y * i2; faa = -2.0 * y * x * i2 * i2; fab = (y * y - x * x) * i2 * i2; fbb = -faa;
 }
+
+// 1 / sqrt(x) in one chain (the code generator fuses RECIP(SQRT(x)) where the square root has no other reader): r = x^(-1/2),
+// r' = -r^3 / 2, r'' = 3 r^5 / 4
+HAMK_DEV void d2_rsqrt(double x, double& g0, double& g1, double& g2) { const double r = frsqrt(x), r2 = r * r, r3 = r * r2; g0 = r; g1 = -0.5 * r3; g2 = 0.75 * r3 * r2; }
+template <class A> HAMK_DEV A rsqrt_of(const A& x) {
+  double g0, g1, g2; d2_rsqrt(val(x), g0, g1, g2); return chain(x, g0, g1, g2);
+}
+HAMK_DEV double rsqrt_of(double x) { return frsqrt(x); }
 
 #define HAMK_UNARY(name)                                                                    \
   template <class A> HAMK_DEV A name(const A& x) {                                          \
@@ -1577,6 +1608,17 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
 #else
   constexpr bool SWAP_LAST = HAMK_RKF_SWAP_LAST && NL == 2;
 #endif
+  // NL == 2, round 6: stage 6's two combinations are FOLDED in stage 5, which has f0, k3, k4 loaded anyway and k5 in registers:
+  //   Qc = c1 f0 + c3 k3 + c4 k4 + c5 k5,   Qe = ec1 f0 + ec3 k3 + ec4 k4 + ec5 k5
+  // Qe waits in dydt's LDS row (f0 -- read again only by a REJECTED attempt -- goes to its scratch row one stage earlier), Qc in
+  // the scratch row that held k5, which is then never stored; stage 6 reads y, Qc, Qe and adds the k6 terms.  Per attempt 13
+  // scratch rows cross the vector-memory pipe instead of 15 (k5's store and the reads of k3, k4, k5 in stage 6 become the
+  // store and the read of Qc).  The sums of stage 6 are associated differently -- (f0, k3, k4, k5 terms) + k6 term -- so states
+  // agree with the unfolded order to roundoff, not bitwise.  HAMK_RKF_FOLD=0 restores the round-5 order (A/B).
+#ifndef HAMK_RKF_FOLD
+#define HAMK_RKF_FOLD 1
+#endif
+  constexpr bool FOLD = HAMK_RKF_FOLD && SWAP_LAST;
 #ifdef HAMK_PROBE_ALIAS_ROWS
 #define HAMK_RKF_YN(j) ((NL >= 3) ? HAMK_RKF_LROW(2)[HAMK_ROW_AT(j)] : py[HAMK_ROW_AT(j)])
 #define HAMK_RKF_E(j) ((NL >= 4) ? HAMK_RKF_LROW(3)[HAMK_ROW_AT(j)] : pf[HAMK_ROW_AT(j)])
@@ -1705,14 +1747,35 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
                                           (29440.0 / 4104.0) * HAMK_RKF_K(1, j) + (-845.0 / 4104.0) * HAMK_RKF_RECENT(2, j));
             break;
           case 4:
+            if constexpr (FOLD) {
 #pragma unroll
-            for (int j = 0; j < D; ++j)
-              yt[j] = py[HAMK_ROW_AT(j)] + hh * ((-6080.0 / 20520.0) * pf[HAMK_ROW_AT(j)] + (41040.0 / 20520.0) * HAMK_RKF_K(0, j) +
-                                          (-28352.0 / 20520.0) * HAMK_RKF_K(1, j) + (9295.0 / 20520.0) * HAMK_RKF_K(2, j) +
-                                          (-5643.0 / 20520.0) * HAMK_RKF_RECENT(3, j));
+              for (int j = 0; j < D; ++j) {
+                const double f0 = pf[HAMK_ROW_AT(j)], k2 = HAMK_RKF_K(0, j), k3 = HAMK_RKF_K(1, j), k4 = HAMK_RKF_K(2, j), k5 = HAMK_RKF_RECENT(3, j);
+                yt[j] = py[HAMK_ROW_AT(j)] + hh * ((-6080.0 / 20520.0) * f0 + (41040.0 / 20520.0) * k2 + (-28352.0 / 20520.0) * k3 +
+                                            (9295.0 / 20520.0) * k4 + (-5643.0 / 20520.0) * k5);
+                v[3][j] = (902880.0 / 7618050.0) * f0 + (3953664.0 / 7618050.0) * k3 + (3855735.0 / 7618050.0) * k4 + (-1371249.0 / 7618050.0) * k5;      // Qc
+                v[6][j] = f0;                                // what a rejected attempt restarts from
+                pf[HAMK_ROW_AT(j)] = (1.0 / 360.0) * f0 + (-128.0 / 4275.0) * k3 + (-2197.0 / 75240.0) * k4 + (1.0 / 50.0) * k5;                          // Qe
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < D; ++j)
+                yt[j] = py[HAMK_ROW_AT(j)] + hh * ((-6080.0 / 20520.0) * pf[HAMK_ROW_AT(j)] + (41040.0 / 20520.0) * HAMK_RKF_K(0, j) +
+                                            (-28352.0 / 20520.0) * HAMK_RKF_K(1, j) + (9295.0 / 20520.0) * HAMK_RKF_K(2, j) +
+                                            (-5643.0 / 20520.0) * HAMK_RKF_RECENT(3, j));
+            }
             break;
           default: {
             double ye[D];
+            if constexpr (FOLD) {
+#pragma unroll
+              for (int j = 0; j < D; ++j) {
+                const double k6 = HAMK_RKF_RECENT(4, j), y_old = py[HAMK_ROW_AT(j)];
+                yt[j] = y_old + hh * (v[3][j] + (277020.0 / 7618050.0) * k6);
+                ye[j] = hh * (pf[HAMK_ROW_AT(j)] + (2.0 / 55.0) * k6);
+                v[5][j] = y_old;
+              }
+            } else {
 #pragma unroll
             for (int j = 0; j < D; ++j) {
               const double f0 = pf[HAMK_ROW_AT(j)], k3 = HAMK_RKF_K(1, j), k4 = HAMK_RKF_K(2, j), k5 = HAMK_RKF_K(3, j), k6 = HAMK_RKF_RECENT(4, j);
@@ -1723,6 +1786,7 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
               yt[j] = y_old + hh * di;
               ye[j] = hh * ((1.0 / 360.0) * f0 + (-128.0 / 4275.0) * k3 + (-2197.0 / 75240.0) * k4 + (1.0 / 50.0) * k5 + (2.0 / 55.0) * k6);
               if constexpr (SWAP_LAST) { v[5][j] = y_old; v[6][j] = f0; }        // what a rejected attempt restarts from
+            }
             }
 #ifdef HAMK_PROBE_ALIAS_ROWS
             if constexpr (NL >= 3) {
@@ -1760,7 +1824,7 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
         HAMK_MARK(0);
         HAMK_CYC_PIN(out);
         HAMK_CYC(1);
-        if (sg < 4) put_k(sg, out);                         // k2..k5; k6 and dydt_out are used from the registers and never stored
+        if (sg < (FOLD ? 3 : 4)) put_k(sg, out);            // k2..k5 (folded: k2..k4); k6 and dydt_out are used from the registers and never stored
         HAMK_CYC(2);
       }
       // --- cstd.c: std_control_hadjust, ord = 5 ------------------------------
@@ -1770,7 +1834,7 @@ HAMK_DEV void rkf45_body_parked(const double* q0, const double* p0, double* qout
       for (int j = 0; j < D; ++j) {
         yn[j] = HAMK_RKF_YN(j);
         const double D0 = eps_rel * (fabs(yn[j]) + fabs(hh * out[j])) + eps_abs;
-        const double rr = fabs(HAMK_RKF_E(j)) / fabs(D0);
+        const double rr = HAMK_RKF_ERR_RATIO(fabs(HAMK_RKF_E(j)), fabs(D0));
         rmax = (rr > rmax) ? rr : rmax;
       }
       const double tnew = final_step ? ti : t + hh;
@@ -1950,7 +2014,7 @@ HAMK_DEV void rkf45_body(const double* q0, const double* p0, double* qout, doubl
         const double yerr = hh * ((1.0 / 360.0) * f0[j] + (-128.0 / 4275.0) * k3[j] + (-2197.0 / 75240.0) * k4[j] +
                                   (1.0 / 50.0) * k5[j] + (2.0 / 55.0) * k6[j]);
         const double D0 = eps_rel * (fabs(yn[j]) + fabs(hh * fn[j])) + eps_abs;
-        const double rr = fabs(yerr) / fabs(D0);
+        const double rr = HAMK_RKF_ERR_RATIO(fabs(yerr), fabs(D0));
         rmax = (rr > rmax) ? rr : rmax;
       }
       const double tnew = final_step ? ti : t + hh;

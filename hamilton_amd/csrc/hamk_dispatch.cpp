@@ -429,6 +429,21 @@ static bool quad_eligible(hamk_system* s) {
   if (s->quad_eligible < 0) s->quad_eligible = distinct_jacobian_entries(s->base) <= 8 * s->base.n ? 1 : 0;
   return s->quad_eligible == 1;
 }
+// Round 6: a DENSE Jacobian whose entries are cheap.  With compile-time seeds a lane evaluates J at forward_gradient_work
+// operations per sweep whatever the number of distinct entries; hamk_quad.hpp's dense path (K accumulated in passes over groups of
+// row slots, one re-evaluation of J per pass) then needs ~3 x that + n^2 m / 8 per lane for SIXTEEN trajectories per wavefront,
+// where the wave-cooperative kernels evaluate the whole tape in every lane for two.  Taken where a sweep costs at most 4 m n
+// (x = 2 q + A sin q + B cos q: 2 m n); a map whose operations all depend on all inputs (tape x n) stays on the wave kernels.
+// Measured on MI355X (profiles/r06_dense_quad_ab.jsonl): dense32 / dense24 RK4 steps/s on this mapping against the wave kernels'.
+static bool quad_dense_eligible(hamk_system* s) {
+  if (s->quad_dense_eligible < 0) {
+    const long long mn = (long long)s->base.m * s->base.n;
+    s->quad_dense_eligible = (s->base.n > 16 && s->base.n <= 32 && forward_gradient_work(s->base) <= 4 * mn) ? 1 : 0;
+  }
+  bool b = false;
+  if (env_flag("HAMK_QUAD_DENSE", &b)) return b && s->base.n > 16 && s->base.n <= 32;      // test override (A/B against the wave kernels)
+  return s->quad_dense_eligible == 1;
+}
 
 // Is K = J^T M J semi-definite by construction?  Only then may a kernel factorise it without pivoting.  The reference
 // inverts EVERY K by LU with partial pivoting (hmatrix `inv`, Hamilton.hs:321, :381), so a system with a non-positive
@@ -451,7 +466,7 @@ static int choose_mapping(hamk_system* s, int64_t B, int kernel) {
   const bool no_quad = !pos || (env_flag("HAMK_QUAD", &w) && !w);
   if (env_flag("HAMK_WAVE", &w)) return (w || n > 16) ? HAMK_MAP_WAVE : HAMK_MAP_LANE;
   if (n > 32) return HAMK_MAP_WAVE;
-  if (n > 16) return (!no_quad && quad_has(kernel) && quad_eligible(s)) ? HAMK_MAP_QUAD : HAMK_MAP_WAVE;
+  if (n > 16) return (!no_quad && quad_has(kernel) && (quad_eligible(s) || quad_dense_eligible(s))) ? HAMK_MAP_QUAD : HAMK_MAP_WAVE;
   const int64_t below = quad_below(n);                      // ensembles smaller than this leave the lane kernels
   if (B < below && !no_quad && quad_eligible(s)) return quad_has(kernel) ? HAMK_MAP_QUAD : HAMK_MAP_LANE;
   return HAMK_MAP_LANE;
@@ -517,6 +532,8 @@ static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4,
   bool b = false;
   d.mapping = mapping;
   d.wave = mapping == HAMK_MAP_WAVE;
+  // four lanes per trajectory, dense Jacobian (chosen by quad_dense_eligible, or the mapping forced): K in passes (hamk_quad.hpp assemble_dense)
+  d.quad_dense = mapping == HAMK_MAP_QUAD && distinct_jacobian_entries(s->base) > 8 * n;
   // second-order AD: measured on MI355X (scripts/sweep.py): H >= D up to n = 3, D ahead from n = 4; the reverse sweep
   // pays from n = 8 (chain8 +4 %, chain16 +12 %); below, the compiler already strips the structural zeros of the
   // directional jets and Jet2 is as cheap
@@ -591,7 +608,10 @@ int variant_for(hamk_system* s, int64_t B, int kernel, Variant** out) {
   v->desc = make_desc(s, mapping, &v->forced_rk4_body, &v->forced_rkf_body);
   // an explicitly set option that this specialisation cannot honour is refused, not silently replaced (the lane mapping's
   // stage-loop stepper IS the parked one, its unrolled stepper keeps everything in registers: rkf_park follows rkf_body there)
-  if (mapping == HAMK_MAP_LANE && s->opt.rkf_park != HAMK_AUTO && (s->opt.rkf_park == HAMK_ON) != v->desc.rkf_stage_loop) {
+  // (only where no four-lane variant of this handle could honour it: the mapping pinned to LANE, or n <= 10 -- with the mapping left to
+  // the library a system of 11 <= n <= 16 also serves small ensembles on the quad kernels, where rkf_park = OFF means something)
+  if (mapping == HAMK_MAP_LANE && (s->opt.mapping == HAMK_MAP_LANE || s->base.n <= 10) &&
+      s->opt.rkf_park != HAMK_AUTO && (s->opt.rkf_park == HAMK_ON) != v->desc.rkf_stage_loop) {
     const bool on = s->opt.rkf_park == HAMK_ON;
     delete v;
     return fail(HAMK_ERR_UNSUPPORTED, std::string("hamk_options: rkf_park = ") + (on ? "ON" : "OFF") + " cannot be honoured on the lane mapping: its " +
@@ -636,6 +656,23 @@ int variant_for(hamk_system* s, int64_t B, int kernel, Variant** out) {
     v->source = generate_source(v->desc);
     rc = build_code(v, s->cache_on, build_force(s));
     if (rc != HAMK_OK) { delete v; return rc; }
+  }
+  // dense map on the four-lane kernels (quad_dense_eligible): the premise is that a tile's accumulators, the entries of J it needs
+  // and their sincos pairs fit the registers.  A tape that SHARES sub-expressions between outputs (the benchmark maps dense24 / 32
+  // draw their n^2 coefficients from 11 x 7 values: every product a sin q_j is one tape value used by several outputs) keeps
+  // hundreds of them alive across a sweep; what does not fit goes to scratch, and at one wavefront per SIMD the kernel then waits
+  // for memory (dense24: 1 499 spilled registers, 1.98e7 RK4 steps/s against the wave kernels' 3.05e7 although it issues a quarter
+  // of their instructions per trajectory).  Such a system goes back to the wave-cooperative kernels; a map with distinct
+  // coefficients spills nothing (denseD24: 4 registers).  Not where the mapping was stated (options, HAMK_QUAD, HAMK_QUAD_DENSE).
+  {
+    bool forced = false;
+    const bool stated = s->opt.mapping != HAMK_AUTO || env_flag("HAMK_QUAD", &forced) || env_flag("HAMK_QUAD_DENSE", &forced);
+    if (mapping == HAMK_MAP_QUAD && v->desc.quad_dense && !stated &&
+        vgpr_spill_count(v->use2[K_RK4] ? v->code2 : v->code, kKernelNames[K_RK4]) > 256) {
+      s->quad_dense_eligible = 0;
+      delete v;
+      return variant_for(s, B, kernel, out);
+    }
   }
   for (int k = 0; k < K__COUNT; ++k) v->has[k] = mapping != HAMK_MAP_QUAD || quad_has(k);
   s->var[mapping] = v;

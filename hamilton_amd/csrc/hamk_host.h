@@ -187,6 +187,7 @@ struct hamk_system {
   int max_substeps = 1 << 24;
   bool self_check_on = true, cache_on = true;
   int quad_eligible = -1;      // -1: not analysed yet
+  int quad_dense_eligible = -1;  // -1: not analysed yet (hamk_dispatch.cpp quad_dense_eligible)
   int64_t ensemble_size = 0;   // hamk_options::ensemble_size: AUTO picks the mapping for THIS size instead of a launch's own B
   DevModule& mod() { return cur->mod[curv->mapping]; }
 };

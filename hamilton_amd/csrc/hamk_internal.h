@@ -28,6 +28,7 @@ struct SystemDesc {
   bool trig_const_vgpr = false; // lane mapping, 8 <= n <= 14: sincos_lut's fp64 literals live in vector registers (hamk_device.hpp LutK)
   bool rkf_two_waves = false;   // lane mapping, n <= 7: the parked RKF45 stepper at two wavefronts per SIMD (rows beyond a halved LDS share in registers)
   bool pair_rows = false;       // lane mapping, n = 8, 9: the parked stepper's LDS rows hold components in pairs (16-byte accesses; hamk_device.hpp HAMK_PAIR_ROWS)
+  bool quad_dense = false;      // quad mapping, a coordinate map with a dense Jacobian: K accumulated in passes (hamk_quad.hpp assemble_dense)
   bool rkf_two_waves_off = false;  // ... built that way, its 256-register cap made THIS system's stepper spill: one wavefront (hamk_dispatch.cpp variant_for)
   std::vector<double> inertia;
   std::vector<hamk_op> f_ops;
@@ -41,5 +42,8 @@ std::string validate_tape(const hamk_op* ops, int nops, int n_in, const int32_t*
 std::string generate_source(const SystemDesc& d);
 // distinct non-zero entries of the coordinate map's Jacobian, as expressions (hamk_codegen.cpp)
 int distinct_jacobian_entries(const SystemDesc& d);
+// fp64 operations of ONE first-order forward sweep of the coordinate map with compile-time seeds: per tape operation the number of
+// gradient entries it has to COMPUTE (structural zeros and pass-through copies are free) -- what a lane of the quad mapping pays per pass
+long long forward_gradient_work(const SystemDesc& d);
 
 }  // namespace hamk_host

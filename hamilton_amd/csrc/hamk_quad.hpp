@@ -176,6 +176,23 @@ template <class S> struct TrigLdsQ {
   TrigSite<S> s, c;
   double* ax; double* as; double* ac;       // unused (TRIG_REUSE never touches them)
 };
+// ... every read an opaque copy (dense maps, the sweep that evaluates all m outputs' VALUES in one piece: with shared values the
+// compiler hoists every product a term shares with another output's -- 11 x 2 n of them for the benchmark maps -- to its first use
+// and parks them in scratch until the last; distinct copies leave nothing to share)
+template <class S> struct TrigSiteOpaque {
+  const double* base;
+  HAMK_DEV double operator[](int k) const {
+    double x = base[S::trig_input(k) * 64];
+#ifndef HAMK_HOST_EMULATION
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+  }
+};
+template <class S> struct TrigLdsOpaqueQ {
+  TrigSiteOpaque<S> s, c;
+  double* ax; double* as; double* ac;
+};
 // The same rows read in ONE BURST into registers.  A wavefront alone on its SIMD pays every LDS round trip it waits for, and
 // left to itself the compiler issues each ds_read a few instructions before its first use (it schedules for register
 // pressure): the sweeps then stop ~50 (first sweep) + ~100 (reverse sweep) times per right-hand side for ~100 cycles -- a
@@ -279,12 +296,7 @@ template <class S> struct SinkK {
   }
 };
 
-// 1 / sqrt(d) for normal-range d > 0: hardware estimate + one third-order step (6 instructions, <= 1 ulp)
-HAMK_DEV double frsqrt(double d) {
-  const double y = __builtin_amdgcn_rsq(d);
-  const double e = fma(-(d * y), y, 1.0);
-  return fma(y * e, fma(0.375, e, 0.5), y);
-}
+// (frsqrt: hamk_device.hpp)
 
 // CHOLESKY K = G G^T of the quad's K in registers, IN PLACE, the forward substitution of one right-hand side riding along.
 // On return: Kp[i][j], j < 4 i + r: G; Kp[i][4 i + r] = 1 / G_aa (a = 4 i + r); z[i] = w_a = p_a - sum_(k < a) G[a][k] y_k with
@@ -448,6 +460,206 @@ HAMK_DEV void stage_inputs(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR]) {
   HAMK_QUAD_SYNC();
 }
 
+// ---- DENSE coordinate maps on this mapping (S::QUAD_DENSE, round 6) ---------------------------------------------------------
+// A map whose Jacobian has ~m n distinct entries (x = 2 q + A sin q + B cos q) used to leave this mapping for the wave-cooperative
+// kernels, where every lane evaluates the WHOLE tape at one-direction jets with a run-time seed: dense32 63.9 k VALU instructions
+// per wavefront-step for TWO trajectories.  Compile-time seeds delete every structural zero of such a map too (a term that depends
+// on one input has one derivative), so a lane here evaluates J at ~2 FMAs per entry -- what stops the one-sweep SinkK above is
+// REGISTERS: its 144 accumulators (n = 32) are updated by every output, and beyond 256 VGPRs each update is a round trip through
+// AGPRs (first build, forced: 8 759 v_accvgpr moves around 5 640 FMAs, and the whole Jacobian parked in scratch ahead of them).
+// Here K is accumulated in TILES -- a group of row slots x a block of 16 columns -- whose accumulators fit the VGPRs NEXT TO the
+// entries of J the tile needs and their sincos pairs (a lane has 128 doubles of VGPRs; n = 32: rows 0..15 x columns 0..15, rows 16..23
+// and 24..31 x columns 0..15, rows 16..31 x columns 16..31 -- 40 / 32 / 32 / 40 accumulators with 16 / 24 / 24 / 16 entries of J per
+// output).  Every tile is a sweep of its own over the outputs: the generated code computes a whole row of J per output, the tile's
+// sink reads only its columns and its rows' entries, and everything else of the row is dead code -- 80 entries of J per output over
+// the four tiles instead of 4 x 32.  Each sweep runs behind a freshly laundered context (so that the compiler cannot keep one tile's
+// entries for the next), and every output ends with its accumulators passing through an opaque statement and a scheduling fence
+// (a fence alone orders only what has side effects: instruction selection emitted all m fences first and the arithmetic after them
+// in one block).  No re-association licence: the sum over the outputs must stay the chain of FMAs it is written as.
+// dU/dq of a potential over the cartesian coordinates is J^T (dU/dx), tiled the same way (SinkG: the chain rule by hand -- handing
+// the jets of all m outputs to the potential keeps m x n derivatives alive across the whole sweep).
+template <class T> HAMK_DEV void opaque_copy(T& x) {
+#ifndef HAMK_HOST_EMULATION
+  asm volatile("" : "+v"(x));
+#endif
+}
+// accumulators acc[i - I0][b - B0] = K[4 i + r][b] for slots [I0, I1) and columns [B0, min(B1, 4 i + 4))
+template <class S, int I0, int I1, int B0, int B1> struct SinkKTile {
+  static constexpr int N = S::N;
+  double acc[I1 - I0][B1 - B0];
+  LaneMask lm{0};
+  HAMK_DEV void init(int r_) {
+    lm = LaneMask(r_);
+#pragma unroll
+    for (int i = 0; i < I1 - I0; ++i)
+#pragma unroll
+      for (int b = 0; b < B1 - B0; ++b) acc[i][b] = 0.0;
+  }
+  static constexpr bool has(int i, int b) { return b >= B0 && b < B1 && b < 4 * i + 4 && b < N; }
+  template <int K, int SEQ> HAMK_DEV void put(const Jet1<N>& x) {
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+      const double xs = S::inertia(K) * msel4(lm, dget<N>(x.d, 4 * i), dget<N>(x.d, 4 * i + 1), dget<N>(x.d, 4 * i + 2), dget<N>(x.d, 4 * i + 3));
+#pragma unroll
+      for (int b = B0; b < B1; ++b)
+        if (has(i, b)) acc[i - I0][b - B0] = fma(xs, x.d[(b < N) ? b : 0], acc[i - I0][b - B0]);
+    }
+#pragma unroll
+    for (int i = I0; i < I1; ++i)
+#pragma unroll
+      for (int b = B0; b < B1; ++b)
+        if (has(i, b)) opaque_copy(acc[i - I0][b - B0]);
+    HAMK_PHASE();
+  }
+  template <int NR, int NP4> HAMK_DEV void store(double (&Kp)[NR][NP4]) const {
+#pragma unroll
+    for (int i = I0; i < I1; ++i)
+#pragma unroll
+      for (int b = B0; b < B1; ++b)
+        if (b < NP4 && b < 4 * i + 4) Kp[i][b] = (b < N) ? acc[i - I0][b - B0] : 0.0;
+  }
+};
+// the lane's rows [I0, I1) of J^T w, w = dU/dx (a potential over the cartesian coordinates)
+template <class S, int I0, int I1> struct SinkG {
+  static constexpr int N = S::N;
+  double g[I1 - I0];
+  const double* w;                                          // dU/dx_k of the trajectory in LDS (stride 64): k < NP4 in the rows of the velocities,
+  const double* w2;                                         // the others in the rows of dU/dq (both free while K is assembled)
+  LaneMask lm{0};
+  template <int K, int SEQ> HAMK_DEV void put(const Jet1<N>& x) {
+    const double wk = (K < Geo<N>::NP4) ? w[(K < Geo<N>::NP4 ? K : 0) * 64] : w2[(K >= Geo<N>::NP4 ? K - Geo<N>::NP4 : 0) * 64];
+#pragma unroll
+    for (int i = I0; i < I1; ++i)
+      g[i - I0] = fma(wk, msel4(lm, dget<N>(x.d, 4 * i), dget<N>(x.d, 4 * i + 1), dget<N>(x.d, 4 * i + 2), dget<N>(x.d, 4 * i + 3)), g[i - I0]);
+#pragma unroll
+    for (int i = I0; i < I1; ++i) opaque_copy(g[i - I0]);
+    HAMK_PHASE();
+  }
+};
+template <int NS> HAMK_DEV void launder_trig(TrigCache<NS>& t) {
+  if constexpr (NS > 0) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) { opaque_copy(t.s[k]); opaque_copy(t.c[k]); }
+  }
+}
+// one pass of the first-order sweep with `sink`, behind a freshly laundered context
+template <class S, class TC, class Sink>
+HAMK_DEV void dense_sweep(const Ctx<S>& c0, const TC& tc, Sink& sink) {
+  constexpr int N = S::N;
+  const Ctx<S> c = c0.launder();
+  InJet1<N> in{c.q()};
+  if constexpr (S::TRIG_ALL_INPUTS && S::NTRIG_F > 0) {
+    TrigLdsQ<S> tl = c.trig();
+    S::template coords_sink<Jet1<N>, TRIG_REUSE>(in, tl, sink);
+  } else {
+    TC t2 = tc;
+    launder_trig(t2);
+    S::template coords_sink<Jet1<N>, TRIG_REUSE>(in, t2, sink);
+  }
+  HAMK_PHASE();
+}
+// one tile of K: a sweep with SinkKTile, stored into Kp
+template <class S, int I0, int I1, int B0, int B1, class TC>
+HAMK_DEV void dense_tile(const Ctx<S>& c0, const TC& tc, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4]) {
+  if constexpr (I0 < I1 && B0 < B1) {
+    SinkKTile<S, I0, I1, B0, B1> sink;
+    sink.init(c0.r);
+    dense_sweep<S>(c0, tc, sink);
+    sink.store(Kp);
+  }
+}
+// the slots from H0 on, two at a time, against the first sixteen columns
+template <class S, int H0, class TC>
+HAMK_DEV void dense_tiles_low(const Ctx<S>& c0, const TC& tc, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4]) {
+  constexpr int NR = Geo<S::N>::NR;
+  if constexpr (H0 < NR) {
+    constexpr int H1 = (H0 + 2 < NR) ? H0 + 2 : NR;
+    dense_tile<S, H0, H1, 0, 16>(c0, tc, Kp);
+    dense_tiles_low<S, H1>(c0, tc, Kp);
+  }
+}
+template <class S, int I0, int I1, class TC>
+HAMK_DEV void dense_grad_rows(const Ctx<S>& c0, const TC& tc, double (&gUi)[Geo<S::N>::NR]) {
+  if constexpr (I0 < I1) {
+    SinkG<S, I0, I1> sg;
+    sg.w = c0.v(); sg.w2 = c0.gu();
+    sg.lm = LaneMask(c0.r);
+#pragma unroll
+    for (int i = 0; i < I1 - I0; ++i) sg.g[i] = 0.0;
+    dense_sweep<S>(c0, tc, sg);
+#pragma unroll
+    for (int i = I0; i < I1; ++i) gUi[i] = sg.g[i - I0];
+  }
+}
+// K, U and the lane's rows of dU/dq for a dense map; tc: the sincos pairs of f's sites when they are not inputs (filled here)
+template <class S, bool LUT, class TC>
+HAMK_DEV void assemble_dense(const Ctx<S>& c, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&gUi)[Geo<S::N>::NR], double& U, TC& tc) {
+  constexpr int N = S::N, M = S::M, NR = Geo<N>::NR, NP4 = Geo<N>::NP4;
+  constexpr bool shared = S::TRIG_ALL_INPUTS && S::NTRIG_F > 0;
+  constexpr int LO = NR < 4 ? NR : 4;                      // slots whose rows lie in the first sixteen
+  static_assert(!S::U_CART || M <= 2 * NP4, "dU/dx waits in the LDS rows of the velocities and of dU/dq");
+  const int r = c.r;
+  TrigCache<S::NTRIG_U> tu;
+  if constexpr (S::U_CART) {
+    // values of the outputs (this sweep also fills tc where the sites are not inputs), dU/dx by first-order jets over x; every lane
+    // computes all of it, lane 0 leaves dU/dx in LDS for the quad's sweeps below
+    {
+      double qv[N], xv[M];
+#pragma unroll
+      for (int j = 0; j < N; ++j) qv[j] = c.q()[j * 64];
+      if constexpr (shared) {
+        TrigLdsOpaqueQ<S> tl; tl.s.base = c.sq(); tl.c.base = c.cq(); tl.ax = tl.as = tl.ac = nullptr;
+        S::template coords<double, TRIG_REUSE>(qv, xv, tl);
+      } else S::template coords<double, LUT ? TRIG_LUT : TRIG_FULL>(qv, xv, tc);
+      Jet1<M> xj[M];
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        xj[k].v = xv[k];
+#pragma unroll
+        for (int i = 0; i < M; ++i) xj[k].d[i] = (i == k) ? 1.0 : 0.0;
+      }
+      const Jet1<M> ux = S::template potential<Jet1<M>, TRIG_FULL>(xj, tu);
+      U = ux.v;
+      // (M <= NP4 rows in V; the rest, if any, in GU -- which receives dU/dq only after the sweeps that read dU/dx)
+#pragma unroll
+      for (int k = 0; k < M; ++k)
+        if (r == (k & 3)) { if (k < NP4) c.v()[(k < NP4 ? k : 0) * 64] = ux.d[k]; else c.gu()[(k >= NP4 ? k - NP4 : 0) * 64] = ux.d[k]; }
+    }
+    HAMK_QUAD_SYNC();
+    dense_grad_rows<S, 0, LO>(c, tc, gUi);
+    dense_grad_rows<S, LO, NR>(c, tc, gUi);
+  } else {
+    double qv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) qv[j] = c.q()[j * 64];
+    if constexpr (!shared && S::NTRIG_F > 0) { double xv[M]; S::template coords<double, LUT ? TRIG_LUT : TRIG_FULL>(qv, xv, tc); }      // (fills tc; the values are dead code)
+    Jet1<N> qj[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      qj[j].v = qv[j];
+#pragma unroll
+      for (int i = 0; i < N; ++i) qj[j].d[i] = (i == j) ? 1.0 : 0.0;
+    }
+    const Jet1<N> u = S::template potential<Jet1<N>, TRIG_FULL>(qj, tu);
+    U = u.v;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) gUi[i] = sel4(r, dget<N>(u.d, 4 * i), dget<N>(u.d, 4 * i + 1), dget<N>(u.d, 4 * i + 2), dget<N>(u.d, 4 * i + 3));
+  }
+  HAMK_PHASE();
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+#pragma unroll
+    for (int b = 0; b < NP4; ++b) Kp[i][b] = 0.0;
+  dense_tile<S, 0, LO, 0, 16>(c, tc, Kp);
+  dense_tiles_low<S, LO>(c, tc, Kp);
+  dense_tile<S, LO, NR, 16, NP4>(c, tc, Kp);
+  if constexpr (NP4 != N) {                                // rows >= N: identity (SinkK::pad)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      if (4 * (NR - 1) + rr >= N && r == rr) Kp[NR - 1][4 * (NR - 1) + rr] = 1.0;
+  }
+}
+
 // Shared first half of every evaluation: q to LDS, sincos pairs, K and its factorisation with the forward substitution
 // of p, back substitution.  Returns the lane's velocities; gU (own rows), U.
 template <class S, bool LUT, class TC>
@@ -456,6 +668,18 @@ HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const
   constexpr int N = S::N, NR = Geo<N>::NR;
   const int r = c.r;
   stage_inputs<S, LUT>(c, qi);
+  if constexpr (S::QUAD_DENSE) {
+    double Kp[NR][Geo<N>::NP4];
+    assemble_dense<S, LUT>(c, Kp, gUi, U, tc);
+    double z[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { z[i] = pi[i]; c.gu()[(4 * i + r) * 64] = gUi[i]; gUi[i] = 0.0; }
+    HAMK_PHASE();
+    chol<S>(r, Kp, z, st);
+    HAMK_PHASE();
+    solve_back<S>(r, Kp, z, vi);
+    HAMK_PHASE();
+  } else {
   trig_fill<S>(tc, c.sq(), c.cq());
   SinkK<S> sink;
   sink.init(r);
@@ -475,6 +699,7 @@ HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const
   HAMK_PHASE();
   solve_back<S>(r, sink.acc, z, vi);
   HAMK_PHASE();
+  }
 }
 
 // hamEqs for the quad's trajectory: the lane returns (dq, dp) of its coordinates.         Hamilton.hs:370-387

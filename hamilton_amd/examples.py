@@ -347,6 +347,72 @@ def dense(N: int) -> SystemSpec:
         cite="build-defined (dense-Jacobian benchmark system; no reference counterpart)")
 
 
+def dense_distinct(N: int) -> SystemSpec:
+    """`denseDN`: `denseN` with every coefficient DISTINCT (a_kj, b_kj from a fixed irrational sequence instead of the 11 x 7 repeating
+    values of `dense`): no product a_kj sin q_j is shared between two outputs, which is what a dense map that was not built from a
+    small table looks like to the code generator (build-defined benchmark / test workload)."""
+    s = 1.0 / N
+    frac = lambda x: x - math.floor(x)
+
+    def f(q, o):
+        sn = [o.sin(q[j]) for j in range(N)]
+        cs = [o.cos(q[j]) for j in range(N)]
+        out = []
+        for k in range(N):
+            acc = 2.0 * q[k]
+            for j in range(N):
+                a = s * (0.2 + frac(0.6180339887498949 * (1 + k * N + j)))
+                b = s * (0.15 + 0.7 * frac(0.4142135623730951 * (3 + j * N + k)))
+                acc = acc + a * sn[j] + b * cs[j]
+            out.append(acc)
+        return out
+
+    def u(x, o):
+        acc = 0.0
+        for k in range(N):
+            acc = acc + x[k] * x[k]
+        return 0.5 * acc
+
+    return SystemSpec(
+        name=f"denseD{N}", m=N, n=N, inertia=(1.0,) * N, f=f, u=u, u_space=U_CARTESIAN,
+        q0=tuple(0.1 for _ in range(N)), qd0=(0.0,) * N,
+        q_box=tuple((-1.0, 1.0) for _ in range(N)), qd_box=tuple((-0.5, 0.5) for _ in range(N)), dt=0.01,
+        cite="build-defined (dense-Jacobian benchmark system, distinct coefficients; no reference counterpart)")
+
+
+def dense_mixed(N: int) -> SystemSpec:
+    """`denseMixedN`: a System (N+1) N with a dense Jacobian whose sincos sites are NOT inputs (sin(q_j + 0.3 q_(j+1))) and a
+    potential over the GENERALIZED coordinates (build-defined test workload: the branches of the four-lane kernels' dense path that
+    `denseN` -- sites = inputs, cartesian potential -- does not reach)."""
+    s = 1.0 / N
+
+    def f(q, o):
+        sn = [o.sin(q[j] + 0.3 * q[(j + 1) % N]) for j in range(N)]
+        out = []
+        for k in range(N):
+            acc = 1.5 * q[k]
+            for j in range(N):
+                acc = acc + (s * (0.2 + 0.1 * ((3 * k + 7 * j) % 11))) * sn[j]
+            out.append(acc)
+        acc = 0.0
+        for j in range(N):
+            acc = acc + (0.1 * s) * o.cos(q[j])
+        out.append(acc)
+        return out
+
+    def u(q, o):
+        acc = 0.0
+        for j in range(N):
+            acc = acc + 0.5 * q[j] * q[j] + 0.1 * o.cos(q[j] - q[(j + 1) % N])
+        return acc
+
+    return SystemSpec(
+        name=f"denseMixed{N}", m=N + 1, n=N, inertia=tuple(1.0 + 0.5 * (k % 2) for k in range(N + 1)), f=f, u=u, u_space=U_GENERALIZED,
+        q0=tuple(0.1 for _ in range(N)), qd0=(0.0,) * N,
+        q_box=tuple((-1.0, 1.0) for _ in range(N)), qd_box=tuple((-0.5, 0.5) for _ in range(N)), dt=0.01,
+        cite="build-defined (dense-Jacobian test system, sites not inputs, generalized potential; no reference counterpart)")
+
+
 def pendulums(N: int) -> SystemSpec:
     """`pendulumsN`: N UNCOUPLED unit pendulums as one System (2N) N (build-defined test workload): x_k = sin q_k, y_k = -cos q_k,
     U = 5 sum y_k.  Every output depends on exactly one input, K is diagonal: the wave kernels' accumulation of K issues one
@@ -404,6 +470,10 @@ def get(name: str) -> SystemSpec:
         return mixed_inertia(name[:-6])
     if name.startswith("chain"):
         return chain(int(name[5:]))
+    if name.startswith("denseD"):
+        return dense_distinct(int(name[6:]))
+    if name.startswith("denseMixed"):
+        return dense_mixed(int(name[10:]))
     if name.startswith("dense"):
         return dense(int(name[5:]))
     if name.startswith("pendulums"):

@@ -149,8 +149,9 @@ typedef struct hamk_system hamk_system;   /* opaque */
 
 /* ---- options of a system (hamk_system_create_ex) -----------------------------------------------------
  * Everything the library decides for itself when it specialises its kernels for a system can be fixed by the host
- * instead.  HAMK_AUTO (0) in a field leaves that decision to the library; a zero-filled struct with `size` set is
- * "all defaults" -- hamk_options_init also sets `version`.  The environment variables of DESIGN.md section 7 are TEST
+ * instead.  HAMK_AUTO (0) in a field leaves that decision to the library.  `size` AND `version` are mandatory: start from
+ * hamk_options_init, which sets both and leaves every choice AUTO -- a zero-filled struct with only `size` set (or one built
+ * against a header of another layout revision) is refused with HAMK_ERR_INVALID.  The environment variables of DESIGN.md section 7 are TEST
  * overrides: they are read only in a process that sets HAMK_TEST_OVERRIDES=1, and apply only where the field is
  * HAMK_AUTO.  hamk_system_get_options reports what was actually chosen.                                           */
 #define HAMK_AUTO 0
@@ -162,7 +163,8 @@ typedef struct hamk_system hamk_system;   /* opaque */
                              factorisation on the matrix cores and in LDS (any n <= 64; the only mapping for n > 32)   */
 #define HAMK_MAP_QUAD 3   /* four lanes per trajectory: every lane runs the sparse per-trajectory AD sweeps, the rows of
                              K are dealt out over the four lanes and factorised in registers with DPP exchanges
-                             (17 <= n <= 32 when the coordinate map's Jacobian is sparse enough; also usable for n <= 16) */
+                             (17 <= n <= 32 when the coordinate map's Jacobian is sparse, or dense but cheap to evaluate with
+                             compile-time seeds -- K is then accumulated in tiles; also usable for n <= 16)              */
 /* second-order AD strategy */
 #define HAMK_AD_H 1       /* one sweep of full second-order jets                        */
 #define HAMK_AD_D 2       /* first-order sweep, then a directional second-order sweep   */

@@ -2,6 +2,7 @@
 trajectory-steps/s (the metric), the SURVEY-8d HBM fraction, the code path taken, and the reference's
 own stepper (stepHam dt) over the same ensemble.  profiles/r01_configs.jsonl is this script's output."""
 import os, sys, json
+os.environ["HAMK_TEST_OVERRIDES"] = "1"               # HAMK_MAX_SUBSTEPS below is a test override: read only when asked for
 os.environ.setdefault("HAMK_MAX_SUBSTEPS", "100000")
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

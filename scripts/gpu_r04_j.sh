@@ -1,4 +1,5 @@
 #!/bin/bash
+export HAMK_TEST_OVERRIDES=1   # the HAMK_* variables below are test overrides: read only when asked for
 # GPU box, round 4, pass J (the final tree of the round: pass I without the table-gather bursts, which did not pay), most important first:
 # the whole GPU suite, smoke(), one bench line per BASELINE config on ONE box, the reference's own stepper, bench.py's RCCL path,
 # rocprofv3 stats + PMC for the headline kernel, chain32 and the adaptive stepper.

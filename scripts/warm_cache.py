@@ -23,6 +23,14 @@ def jobs():
         out.append((n, {"HAMK_GSL_API": "1"}, False))
     for n in ("dense18", "pendulums40", "dense24", "dense32", "chain13", "chain14"):  # round 5: the dense-Jacobian benchmark systems (wave kernels), bench lines with instruction counts
         out.append((n, {}, True))
+    # round 6: dense maps on the four-lane kernels (auto: dense18, denseD24; dense24 / dense32 build the quad module, find it spilling and go
+    # back to the wave kernels -- both builds are cached), the forced modules of the tests, the wave modules the A/B compares with
+    for n in ("denseD24", "denseD32"):
+        out.append((n, {}, False))
+    for n in ("dense18", "dense24", "dense32", "denseD24", "denseD32"):
+        out.append((n, {"HAMK_WAVE": "1"}, False))
+    for n in ("dense24", "denseMixed17"):
+        out.append((n, {"HAMK_QUAD": "1"}, False))
     for n in ("spring", "threeBodyPolar", "chain4", "opcodeZoo", "chain8", "chain16"):
         out.append((n, {"HAMK_WAVE": "1"}, False))
     for n in ("chain8", "chain16"):

@@ -26,6 +26,17 @@ def test_every_declared_symbol_is_exported(hamk_lib):
         assert hasattr(hamk_lib, name), f"{name} declared in include/hamk.h but not exported by libhamk.so"
 
 
+def test_nothing_but_the_c_abi_is_exported(hamk_lib):
+    """`nm -D --defined-only libhamk.so` = the prototypes of include/hamk.h, nothing else: -fvisibility=hidden and
+    -fvisibility-inlines-hidden for the library's own code, the linker's version script (csrc/hamk.map) for what libstdc++'s headers
+    instantiate into it (round 5's library also exported a handful of weak std::vector members)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "hamilton_amd", "libhamk.so")], capture_output=True, text=True, check=True).stdout
+    rows = [ln.split() for ln in out.splitlines() if ln.strip()]
+    assert sorted(r[-1] for r in rows) == declared_symbols()
+    assert all(r[-2] == "T" for r in rows)
+
+
 def test_binding_table_matches_header(hamk_lib):
     from hamilton_amd import _abi
     assert sorted(_abi.SIGNATURES) == declared_symbols()

@@ -755,3 +755,46 @@ def test_cold_path_compiles_on_the_gpu_box(api, oracle_lib):
     sq, sp, sns = o.step_ham_batch(q, p, spec.dt)
     assert np.array_equal(np.asarray(s.last_nsub), sns) and relerr(st.positions, sq) < 1e-9
     assert t_compile > 0.2, "served from a cache after all?"
+
+
+@pytest.mark.parametrize("name,mapping", [("chain19", "quad"), ("chain34", "wave")])
+def test_cold_path_of_the_cooperative_mappings(api, oracle_lib, name, mapping):
+    """The same on the two cooperative mappings (round 6): a four-lane module (chain19) and a wave-cooperative one (chain34: one
+    trajectory per wavefront, matrix cores) that no other test builds, compiled on the box with the cache off -- 20-60 s of hiprtc
+    each -- then self-check, hamEqs and five RK4 steps against the oracle."""
+    import time
+    from hamilton_amd import _abi
+    spec = E.get(name)
+    t0 = time.time()
+    s = api.system_from_spec(spec, {"cache": _abi.OFF})
+    t_compile = time.time() - t0
+    want = {"quad": _abi.MAP_QUAD, "wave": _abi.MAP_WAVE}[mapping]
+    assert s.options()["cache"] == _abi.OFF and s.options()["mapping"] == want and t_compile > 2.0
+    o = oracle_lib.OracleSystem(spec)
+    q, _ = E.sample_config(spec, 3, 40)
+    qd = 0.3 * np.cos(np.arange(spec.n * 40).reshape(spec.n, 40) * 0.7)
+    p = o.to_phase_batch(q, qd)
+    dq, dp = api.hamEqs(s, api.Phase(q, p))
+    odq, odp, _ = o.hameqs_batch(q, p)
+    assert relerr(dq, odq) < 1e-10 and relerr(dp, odp) < 1e-10 and not np.any(s.last_status)
+    ph = api.rk4Steps(spec.dt, 5, s, api.Phase(q, p))
+    oq, op = o.rk4_steps_batch(q, p, spec.dt, 5)
+    assert relerr(ph.positions, oq) < 1e-10 and relerr(ph.momenta, op) < 1e-10
+
+
+def test_derivative_rules_at_the_edge_of_their_domain(api):
+    """sqrt at 0: the reference's `ad` yields Infinity for the derivative, the device rules take their reciprocals from frcp
+    (hamk_device.hpp) and yield NaN there -- both non-finite; the trajectory is flagged HAMK_ST_NONFINITE, its neighbours are not
+    touched.  (stated and tested instead of guarded: the guard would be paid by every evaluation.)"""
+    from hamilton_amd import tracer as T
+    spec = E.SystemSpec(name="sqrtEdge", m=2, n=1, inertia=(1.0, 1.0), f=lambda q, o: [q[0], o.sqrt(q[0])], u=lambda q, o: q[0] * q[0],
+                        u_space=E.U_GENERALIZED, q0=(1.0,), qd0=(0.0,), q_box=((0.5, 2.0),), qd_box=((-1.0, 1.0),), cite="build-defined (domain edge of sqrt)")
+    s = api.system_from_spec(spec)
+    q = np.array([[1.0, 0.0, 2.0, 0.25]])
+    p = np.array([[0.3, 0.3, 0.3, 0.3]])
+    dq, dp = api.hamEqs(s, api.Phase(q, p))
+    st = np.asarray(s.last_status)
+    assert st[1] != 0 and not st[[0, 2, 3]].any()
+    assert not np.isfinite(np.asarray(dp)[0, 1]) or not np.isfinite(np.asarray(dq)[0, 1])
+    # K = 1 + 1 / (4 q): dq = p / K at the regular points
+    assert np.allclose(np.asarray(dq)[0, [0, 2, 3]], 0.3 / (1.0 + 1.0 / (4.0 * q[0, [0, 2, 3]])), rtol=1e-13)

@@ -149,7 +149,10 @@ def test_lane_path_at_its_upper_size(api, oracle_lib):
 
 # ---- four lanes per trajectory (hamk_quad.hpp): the default for 17 <= n <= 32 with a sparse Jacobian ------------------
 QUAD_CASES = [("chain32", False), ("chain20", False), ("chain17", False), ("chain18", False),
-              ("chain16", True), ("chain8", True), ("threeBodyPolar", True), ("spring", True), ("opcodeZoo", True)]
+              ("chain16", True), ("chain8", True), ("threeBodyPolar", True), ("spring", True), ("opcodeZoo", True),
+              # round 6: DENSE Jacobians on this mapping (hamk_quad.hpp assemble_dense: K in tiles) -- chosen by the library for dense18 and
+              # denseD24 (distinct coefficients), forced for denseMixed17 (sincos sites that are not inputs, generalized potential)
+              ("dense18", False), ("denseD24", False), ("denseMixed17", True)]
 
 
 @pytest.mark.parametrize("name,force", QUAD_CASES)
@@ -259,12 +262,19 @@ def test_heavy_tapes_leave_the_two_wavefront_rk4_kernel(api):
     assert api.system_from_spec(E.get("dense32"), {"rk4_min_waves": 2}).options()["rk4_min_waves"] == 2      # the host's word stands
 
 
-def test_dense_jacobians_stay_on_the_wave_kernels(api):
-    """The quad mapping needs a sparse Jacobian (every lane keeps one register pair per DISTINCT entry): a dense random
-    coordinate map of the same size is left on the wave-cooperative kernels."""
+def test_dense_jacobians_choose_their_kernels(api):
+    """17 <= n <= 32 with a dense Jacobian (round 6).  Where a first-order sweep with compile-time seeds is cheap (<= 4 m n operations:
+    x = 2 q + A sin q + B cos q costs 2 m n) the four-lane kernels take the system -- K accumulated in tiles, 2.4 x (dense18) to 4 x
+    (denseD32) the wave-cooperative kernels' RK4 rate -- unless the built kernel spills (a tape that shares products between outputs:
+    dense24 draws its coefficients from 11 x 7 values), in which case the library goes back to the wave kernels by itself."""
     from hamilton_amd import _abi
     assert api.system_from_spec(E.get("chain24")).options()["mapping"] == _abi.MAP_QUAD
-    spec = E.get("dense18")                                   # x = 2 q + A sin q + B cos q: n^2 distinct Jacobian entries
-    assert api.system_from_spec(spec).options()["mapping"] == _abi.MAP_WAVE
-
-
+    for name in ("dense18", "denseD24"):
+        s = api.system_from_spec(E.get(name))
+        assert s.options()["mapping"] == _abi.MAP_QUAD and "QUAD_DENSE = true" in s.source, name
+    s = api.system_from_spec(E.get("dense24"))
+    assert s.options()["mapping"] == _abi.MAP_WAVE and "HAMK_INSTANTIATE_WAVE" in s.source
+    assert "QUAD_DENSE = false" in api.system_from_spec(E.get("chain24")).source
+    # stated mappings stand: the dense path where quad is asked for, the wave kernels where they are
+    assert "QUAD_DENSE = true" in api.system_from_spec(E.get("dense24"), {"mapping": _abi.MAP_QUAD}).source
+    assert api.system_from_spec(E.get("dense18"), {"mapping": _abi.MAP_WAVE}).options()["mapping"] == _abi.MAP_WAVE
