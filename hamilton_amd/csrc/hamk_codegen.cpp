@@ -93,6 +93,12 @@ std::string validate_tape(const hamk_op* ops, int nops, int n_in, const int32_t*
 // Values of the tape being emitted that somebody outside emit_body reads by name (the tape's outputs): set by generate_source
 // before every call.  A value in it is always materialised.
 static std::vector<char> g_emit_is_output;
+// Dense maps on the four-lane kernels (SystemDesc::quad_dense): products `constant x value` that SEVERAL outputs read are not
+// materialised once but written out at every use with the constant behind an opaque copy -- a tape whose n^2 coefficients come from
+// a small table (the benchmark maps dense24 / dense32: 11 x 7 values) shares each product a sin q_j between ~n / 11 outputs, and a
+// shared value lives from its first reader to its last: hundreds of them at once, i.e. scratch (dense32: 3 666 spilled registers, the
+// library went back to the wave kernels).  Unshared, such a tape compiles like one with distinct coefficients.
+static bool g_emit_unshare_scales = false;
 static void mark_outputs(size_t nops, const int32_t* outs, int n_out) {
   g_emit_is_output.assign(nops, 0);
   for (int k = 0; k < n_out; ++k) g_emit_is_output[(size_t)outs[k]] = 1;
@@ -143,14 +149,34 @@ static int emit_body(std::ostringstream& o, const hamk_op* ops, int nops, const 
   // INPUT values are not materialised: every use reads `in[j]` in place.  With array inputs
   // that is a reference; with the wave kernels' LDS-backed proxies it keeps 32 input jets from
   // all being live from the top of the function (the tape lists its inputs first).
-  auto v = [&](int i) {
+  std::vector<char> inline_scale(nops, 0);
+  if (g_emit_unshare_scales) {
+    std::vector<int> nuse(nops, 0);
+    for (int i = 0; i < nops; ++i) {
+      const hamk_op& p = ops[i];
+      if (p.op == HAMK_OP_CONST || p.op == HAMK_OP_INPUT) continue;
+      ++nuse[p.a];
+      if (is_binary(p.op)) ++nuse[p.b];
+    }
+    for (int i = 0; i < nops; ++i)
+      if (ops[i].op == HAMK_OP_MUL && nuse[i] > 1 && (ops[ops[i].a].op == HAMK_OP_CONST) != (ops[ops[i].b].op == HAMK_OP_CONST) &&
+          !((size_t)i < g_emit_is_output.size() && g_emit_is_output[(size_t)i]) && !(sink_outs && !(*sink_outs)[i].empty()))
+        inline_scale[i] = 1;
+  }
+  std::function<std::string(int)> v = [&](int i) -> std::string {
     if (ops[i].op == HAMK_OP_INPUT)
       return input_exprs ? (*input_exprs)[ops[i].a] : std::string("in[") + std::to_string(ops[i].a) + "]";
+    if (inline_scale[i]) {
+      const bool ca = ops[ops[i].a].op == HAMK_OP_CONST;
+      const int c = ca ? ops[i].a : ops[i].b, x = ca ? ops[i].b : ops[i].a;
+      return "(hamk::opaque_const(" + lit(ops[c].c) + ") * " + v(x) + ")";
+    }
     return std::string(pfx) + std::to_string(i);
   };
   for (int i = 0; i < nops; ++i) {
     if (done[i]) continue;
     const hamk_op& p = ops[i];
+    if (inline_scale[i]) { done[i] = 2; continue; }
     o << "    ";
     switch (p.op) {
       case HAMK_OP_CONST: o << "const double " << v(i) << " = " << lit(p.c) << ";\n"; break;
@@ -580,8 +606,8 @@ std::string generate_source(const SystemDesc& d) {
   // coordinate map f: generalized -> cartesian                       (_sysCoords, Hamilton.hs:220)
   o << "  template <class A, int TRIG, class TC> __device__ __forceinline__ static void coords(const A (&in)[N], A (&x)[M], TC& tc) {\n";
   std::vector<int> slot_operand;
-  auto mark_f = [&] { mark_outputs(d.f_ops.size(), d.f_outs.data(), d.m); };
-  auto mark_u = [&] { mark_outputs(d.u_ops.size(), &d.u_out, 1); };
+  auto mark_f = [&] { mark_outputs(d.f_ops.size(), d.f_outs.data(), d.m); g_emit_unshare_scales = d.mapping == HAMK_MAP_QUAD && d.quad_dense; };
+  auto mark_u = [&] { mark_outputs(d.u_ops.size(), &d.u_out, 1); g_emit_unshare_scales = false; };
   mark_f();
   const int ntrig_f = emit_body(o, d.f_ops.data(), (int)d.f_ops.size(), "f", nullptr, nullptr, "tc", &slot_operand);
   for (int k = 0; k < d.m; ++k) o << "    x[" << k << "] = hamk::lift<A>(" << value_name(d.f_ops, "f", d.f_outs[k]) << ");\n";

@@ -658,17 +658,15 @@ int variant_for(hamk_system* s, int64_t B, int kernel, Variant** out) {
     if (rc != HAMK_OK) { delete v; return rc; }
   }
   // dense map on the four-lane kernels (quad_dense_eligible): the premise is that a tile's accumulators, the entries of J it needs
-  // and their sincos pairs fit the registers.  A tape that SHARES sub-expressions between outputs (the benchmark maps dense24 / 32
-  // draw their n^2 coefficients from 11 x 7 values: every product a sin q_j is one tape value used by several outputs) keeps
-  // hundreds of them alive across a sweep; what does not fit goes to scratch, and at one wavefront per SIMD the kernel then waits
-  // for memory (dense24: 1 499 spilled registers, 1.98e7 RK4 steps/s against the wave kernels' 3.05e7 although it issues a quarter
-  // of their instructions per trajectory).  Such a system goes back to the wave-cooperative kernels; a map with distinct
-  // coefficients spills nothing (denseD24: 4 registers).  Not where the mapping was stated (options, HAMK_QUAD, HAMK_QUAD_DENSE).
+  // and their sincos pairs fit the registers.  Where the built kernel says otherwise -- it spills by the hundred, and at one wavefront
+  // per SIMD a kernel that waits for scratch loses whatever it saves in instructions (first build of dense24, its shared products
+  // still materialised once: 1 499 spilled registers, 1.98e7 RK4 steps/s against the wave kernels' 3.05e7; unshared: 20 registers,
+  // 6.27e7) -- the system goes back to the wave-cooperative kernels.  Not where the mapping was stated (options, HAMK_QUAD, HAMK_QUAD_DENSE).
   {
     bool forced = false;
     const bool stated = s->opt.mapping != HAMK_AUTO || env_flag("HAMK_QUAD", &forced) || env_flag("HAMK_QUAD_DENSE", &forced);
     if (mapping == HAMK_MAP_QUAD && v->desc.quad_dense && !stated &&
-        vgpr_spill_count(v->use2[K_RK4] ? v->code2 : v->code, kKernelNames[K_RK4]) > 256) {
+        vgpr_spill_count(v->use2[K_RK4] ? v->code2 : v->code, kKernelNames[K_RK4]) > 768) {
       s->quad_dense_eligible = 0;
       delete v;
       return variant_for(s, B, kernel, out);

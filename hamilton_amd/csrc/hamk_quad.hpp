@@ -32,6 +32,14 @@
 #include "hamk_device.hpp"
 
 namespace hamk {
+// a constant the compiler cannot recognise twice (the generated code of a dense map writes shared `constant x value` products out
+// at every use: hamk_codegen.cpp g_emit_unshare_scales)
+HAMK_DEV double opaque_const(double c) {
+#ifndef HAMK_HOST_EMULATION
+  asm volatile("" : "+s"(c));
+#endif
+  return c;
+}
 namespace quad {
 
 template <int N> struct Geo {

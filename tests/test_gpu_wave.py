@@ -152,7 +152,7 @@ QUAD_CASES = [("chain32", False), ("chain20", False), ("chain17", False), ("chai
               ("chain16", True), ("chain8", True), ("threeBodyPolar", True), ("spring", True), ("opcodeZoo", True),
               # round 6: DENSE Jacobians on this mapping (hamk_quad.hpp assemble_dense: K in tiles) -- chosen by the library for dense18 and
               # denseD24 (distinct coefficients), forced for denseMixed17 (sincos sites that are not inputs, generalized potential)
-              ("dense18", False), ("denseD24", False), ("denseMixed17", True)]
+              ("dense18", False), ("dense24", False), ("denseD24", False), ("denseMixed17", True)]
 
 
 @pytest.mark.parametrize("name,force", QUAD_CASES)
@@ -255,26 +255,26 @@ def test_parked_adaptive_stepper_takes_the_reference_steps(api, oracle_lib, name
 
 def test_heavy_tapes_leave_the_two_wavefront_rk4_kernel(api):
     """The wave mapping's RK4 kernel is capped for two wavefronts per SIMD; where a system's tape spills by the thousand under
-    that cap (dense32: 967 registers, 490 GB of HBM traffic per launch) the library rebuilds it for one -- a chain keeps two."""
-    assert api.system_from_spec(E.get("dense32")).options()["rk4_min_waves"] == 1
-    assert api.system_from_spec(E.get("chain48")).options()["rk4_min_waves"] == 2
+    that cap (dense32: 967 registers, 490 GB of HBM traffic per launch) the library rebuilds it for one -- a chain keeps two.
+    (dense32 is asked onto the wave kernels here: since round 6 the library's own choice for it is the four-lane mapping.)"""
     from hamilton_amd import _abi
-    assert api.system_from_spec(E.get("dense32"), {"rk4_min_waves": 2}).options()["rk4_min_waves"] == 2      # the host's word stands
+    assert api.system_from_spec(E.get("dense32"), {"mapping": _abi.MAP_WAVE}).options()["rk4_min_waves"] == 1
+    assert api.system_from_spec(E.get("chain48")).options()["rk4_min_waves"] == 2
+    assert api.system_from_spec(E.get("dense32"), {"mapping": _abi.MAP_WAVE, "rk4_min_waves": 2}).options()["rk4_min_waves"] == 2      # the host's word stands
 
 
 def test_dense_jacobians_choose_their_kernels(api):
     """17 <= n <= 32 with a dense Jacobian (round 6).  Where a first-order sweep with compile-time seeds is cheap (<= 4 m n operations:
-    x = 2 q + A sin q + B cos q costs 2 m n) the four-lane kernels take the system -- K accumulated in tiles, 2.4 x (dense18) to 4 x
-    (denseD32) the wave-cooperative kernels' RK4 rate -- unless the built kernel spills (a tape that shares products between outputs:
-    dense24 draws its coefficients from 11 x 7 values), in which case the library goes back to the wave kernels by itself."""
+    x = 2 q + A sin q + B cos q costs 2 m n) the four-lane kernels take the system -- K accumulated in tiles, 2.0 x (dense24) to 4 x
+    (denseD32) the wave-cooperative kernels' RK4 rate (profiles/r06_dense_quad_ab.jsonl); a built kernel that spills by the hundred
+    sends the system back to the wave kernels (hamk_dispatch.cpp variant_for)."""
     from hamilton_amd import _abi
     assert api.system_from_spec(E.get("chain24")).options()["mapping"] == _abi.MAP_QUAD
-    for name in ("dense18", "denseD24"):
+    for name in ("dense18", "dense24", "denseD24"):
         s = api.system_from_spec(E.get(name))
         assert s.options()["mapping"] == _abi.MAP_QUAD and "QUAD_DENSE = true" in s.source, name
-    s = api.system_from_spec(E.get("dense24"))
-    assert s.options()["mapping"] == _abi.MAP_WAVE and "HAMK_INSTANTIATE_WAVE" in s.source
     assert "QUAD_DENSE = false" in api.system_from_spec(E.get("chain24")).source
-    # stated mappings stand: the dense path where quad is asked for, the wave kernels where they are
-    assert "QUAD_DENSE = true" in api.system_from_spec(E.get("dense24"), {"mapping": _abi.MAP_QUAD}).source
+    # shared `constant x value` products are written out per use in such a module (a tape that draws its coefficients from a small table)
+    assert "hamk::opaque_const(" in api.system_from_spec(E.get("dense24")).source and "hamk::opaque_const(" not in api.system_from_spec(E.get("chain24")).source
+    # a stated mapping stands
     assert api.system_from_spec(E.get("dense18"), {"mapping": _abi.MAP_WAVE}).options()["mapping"] == _abi.MAP_WAVE
