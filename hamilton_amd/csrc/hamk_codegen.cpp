@@ -565,6 +565,282 @@ long long forward_gradient_work(const SystemDesc& d) {
   return work;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Symbolic mass matrix (round 6).  K = J^T M J of the reference (Hamilton.hs:380) is a sum of products of Jacobian entries, and for
+// the systems people write it simplifies: a point on a circle contributes m (cos^2 + sin^2) = m, polar coordinates make the
+// r-phi entries cancel, a double pendulum's K is [[m1 + m2, m2/2 cos(t1 - t2)], [., m2/4]].  The compiler sees only fp64
+// arithmetic and may not use sin^2 + cos^2 = 1; the generator can.  Where f is a polynomial in its inputs and in sincos of
+// polynomial arguments (ADD, SUB, MUL, NEG, POWI, division by constants, SIN, COS), the Jacobian is derived here as polynomials
+// over {q_j, s_k, c_k} (s_k, c_k: the sincos pair of trig-cache slot k), K[a][b] = sum_k m_k J[k][a] J[k][b] is expanded, even
+// powers of s_k are rewritten through 1 - c_k^2, like terms are collected (terms whose coefficient cancelled to rounding are
+// dropped) -- and if the result is cheaper than the numerical sum, the module gets `mass_matrix_sym` and the lane kernels use
+// it.  doublePendulum: K00 = 2, K11 = 1/4 (constants: the 2 x 2 solve folds around them); twoBody: diag(mu, mu r^2);
+// threeBodyPolar: diag(1, r1^2, 1, r2^2, 1, r3^2) -- the 6 x 6 LDL^T becomes six divisions.  Results differ from the numerical
+// K by the rounding of the terms that cancel analytically (~1e-16 relative).
+// ---------------------------------------------------------------------------------------------
+namespace {
+typedef std::vector<std::pair<int, int>> Mono;            // sorted (variable, power)
+typedef std::map<Mono, double> Poly;
+struct SymFail {};
+
+Mono mono_mul(const Mono& a, const Mono& b) {
+  Mono r; size_t i = 0, j = 0;
+  while (i < a.size() || j < b.size()) {
+    if (j >= b.size() || (i < a.size() && a[i].first < b[j].first)) r.push_back(a[i++]);
+    else if (i >= a.size() || b[j].first < a[i].first) r.push_back(b[j++]);
+    else { r.push_back({a[i].first, a[i].second + b[j].second}); ++i; ++j; }
+  }
+  return r;
+}
+void poly_add(Poly& a, const Poly& b, double f = 1.0) {
+  for (const auto& t : b) { a[t.first] += f * t.second; }
+  if (a.size() > 20000) throw SymFail{};
+}
+Poly poly_mul(const Poly& a, const Poly& b) {
+  Poly r;
+  if (a.size() * b.size() > 200000) throw SymFail{};
+  for (const auto& x : a) for (const auto& y : b) r[mono_mul(x.first, y.first)] += x.second * y.second;
+  return r;
+}
+Poly poly_const(double c) { Poly p; if (c != 0.0) p[Mono{}] = c; return p; }
+Poly poly_var(int v) { Poly p; p[Mono{{v, 1}}] = 1.0; return p; }
+// s^2 -> 1 - c^2 for every sincos pair (sin variable ids are n + 2k, cos ids n + 2k + 1), then drop what cancelled
+Poly poly_reduce(const Poly& a, int n, int hi = 1 << 30) {   // sincos variables: ids in [n, hi)
+  Poly cur = a;
+  for (bool again = true; again;) {
+    again = false;
+    Poly next;
+    for (const auto& t : cur) {
+      int at = -1;
+      for (size_t i = 0; i < t.first.size(); ++i)
+        if (t.first[i].first >= n && t.first[i].first < hi && ((t.first[i].first - n) & 1) == 0 && t.first[i].second >= 2) { at = (int)i; break; }
+      if (at < 0) { next[t.first] += t.second; continue; }
+      again = true;
+      Mono rest = t.first;
+      const int sv = rest[at].first;
+      rest[at].second -= 2;
+      if (rest[at].second == 0) rest.erase(rest.begin() + at);
+      next[rest] += t.second;                               // ... * 1
+      next[mono_mul(rest, Mono{{sv + 1, 2}})] -= t.second;  // ... * (-c^2)
+    }
+    cur.swap(next);
+    if (cur.size() > 20000) throw SymFail{};
+  }
+  return cur;
+}
+void poly_prune(Poly& p, double scale) {
+  for (auto it = p.begin(); it != p.end();) it = (std::fabs(it->second) <= 8.0 * 2.220446049250313e-16 * scale) ? p.erase(it) : std::next(it);
+}
+double poly_abs_sum(const Poly& p) { double s = 0.0; for (const auto& t : p) s += std::fabs(t.second); return s; }
+
+struct SymK {
+  bool ok = false;
+  int n = 0;
+  std::vector<Poly> k;          // upper triangle, row-major: (a, b), a <= b
+  std::vector<Poly> dT;         // dT/dq_i = -1/2 v^T (dK/dq_i) v as a polynomial over {q, s, c, v}; variable ids of v_a: vbase + a
+  int vbase = 0;
+  bool dt_ok = false;
+  long long sym_ops = 0, num_ops = 0, dt_ops = 0;
+};
+
+// slot_operand: trig-cache slot -> tape value that is the sincos operand (emit_body's numbering)
+SymK symbolic_mass_matrix(const SystemDesc& d, const std::vector<int>& slot_operand) {
+  SymK out;
+  const int n = d.n, m = d.m, nops = (int)d.f_ops.size();
+  out.n = n;
+  if (n > 7 || d.mapping != HAMK_MAP_LANE) return out;     // the small systems (configs 2-4, the reference's examples): K is a visible share of their right-hand side
+  std::vector<int> slot_of(nops, -1);
+  for (size_t k = 0; k < slot_operand.size(); ++k) if (slot_operand[k] >= 0) slot_of[(size_t)slot_operand[k]] = (int)k;
+  try {
+    std::vector<Poly> V(nops);
+    std::vector<std::vector<Poly>> G(nops, std::vector<Poly>(n));
+    for (int i = 0; i < nops; ++i) {
+      const hamk_op& p = d.f_ops[i];
+      switch (p.op) {
+        case HAMK_OP_CONST: V[i] = poly_const(p.c); break;
+        case HAMK_OP_INPUT: V[i] = poly_var(p.a); G[i][p.a] = poly_const(1.0); break;
+        case HAMK_OP_ADD: V[i] = V[p.a]; poly_add(V[i], V[p.b]); for (int j = 0; j < n; ++j) { G[i][j] = G[p.a][j]; poly_add(G[i][j], G[p.b][j]); } break;
+        case HAMK_OP_SUB: V[i] = V[p.a]; poly_add(V[i], V[p.b], -1.0); for (int j = 0; j < n; ++j) { G[i][j] = G[p.a][j]; poly_add(G[i][j], G[p.b][j], -1.0); } break;
+        case HAMK_OP_NEG: poly_add(V[i], V[p.a], -1.0); for (int j = 0; j < n; ++j) poly_add(G[i][j], G[p.a][j], -1.0); break;
+        case HAMK_OP_MUL:
+          V[i] = poly_reduce(poly_mul(V[p.a], V[p.b]), n);
+          for (int j = 0; j < n; ++j) {
+            if (!G[p.b][j].empty()) poly_add(G[i][j], poly_mul(V[p.a], G[p.b][j]));
+            if (!G[p.a][j].empty()) poly_add(G[i][j], poly_mul(G[p.a][j], V[p.b]));
+            G[i][j] = poly_reduce(G[i][j], n);
+          }
+          break;
+        case HAMK_OP_DIV: {
+          if (d.f_ops[p.b].op != HAMK_OP_CONST || d.f_ops[p.b].c == 0.0) throw SymFail{};
+          const double r = 1.0 / d.f_ops[p.b].c;            // (x / c: the numerical path divides; the difference is one rounding of a constant)
+          poly_add(V[i], V[p.a], r); for (int j = 0; j < n; ++j) poly_add(G[i][j], G[p.a][j], r);
+        } break;
+        case HAMK_OP_POWI: {
+          if (p.b < 0 || p.b > 6) throw SymFail{};
+          Poly acc = poly_const(1.0), dacc;                  // x^k and k x^(k-1)
+          for (int e = 0; e < p.b; ++e) { dacc = acc; acc = poly_reduce(poly_mul(acc, V[p.a]), n); }
+          V[i] = acc;
+          if (p.b >= 1) for (int j = 0; j < n; ++j) if (!G[p.a][j].empty()) { Poly t = poly_mul(dacc, G[p.a][j]); poly_add(G[i][j], t, (double)p.b); G[i][j] = poly_reduce(G[i][j], n); }
+        } break;
+        case HAMK_OP_SIN: case HAMK_OP_COS: {
+          const int k = slot_of[p.a];
+          if (k < 0) throw SymFail{};
+          const int sv = n + 2 * k, cv = sv + 1;
+          const bool is_sin = p.op == HAMK_OP_SIN;
+          V[i] = poly_var(is_sin ? sv : cv);
+          for (int j = 0; j < n; ++j)
+            if (!G[p.a][j].empty()) { Poly t = poly_mul(poly_var(is_sin ? cv : sv), G[p.a][j]); poly_add(G[i][j], t, is_sin ? 1.0 : -1.0); G[i][j] = poly_reduce(G[i][j], n); }
+        } break;
+        default: throw SymFail{};                            // sqrt, exp, recip ...: not a polynomial
+      }
+    }
+    out.k.resize((size_t)n * (n + 1) / 2);
+    size_t e = 0;
+    for (int a = 0; a < n; ++a)
+      for (int b = a; b < n; ++b, ++e) {
+        Poly acc;
+        double scale = 0.0;
+        int both = 0;
+        for (int k = 0; k < m; ++k) {
+          const Poly& ga = G[d.f_outs[k]][a];
+          const Poly& gb = G[d.f_outs[k]][b];
+          if (ga.empty() || gb.empty()) continue;
+          ++both;
+          Poly t = poly_mul(ga, gb);
+          scale += std::fabs(d.inertia[k]) * poly_abs_sum(t);
+          poly_add(acc, t, d.inertia[k]);
+        }
+        acc = poly_reduce(acc, n);
+        poly_prune(acc, scale);
+        out.num_ops += 2LL * both;
+        for (const auto& t : acc) {
+          int deg = 0; for (const auto& vp : t.first) deg += vp.second;
+          out.sym_ops += deg + ((std::fabs(t.second) != 1.0 && deg > 0) ? 1 : 0);
+        }
+        if (acc.size() > 1) out.sym_ops += (long long)acc.size() - 1;
+        if (acc.size() > 24) throw SymFail{};
+        out.k[e] = acc;
+      }
+    out.ok = out.sym_ops < out.num_ops;
+    // dT/dq_i = -(M J v) . ((dJ/dq_i) v) = -1/2 v^T (dK/dq_i) v at fixed v (Hamilton.hs:382-385 in the form DESIGN.md section 3 derives):
+    // with K a polynomial its derivative is one too -- d s_k = c_k d(arg_k), d c_k = -s_k d(arg_k) -- and the second-order sweep of f
+    // (full second-order jets for n <= 3, the directional sweep above) is not needed at all
+    if (out.ok) {
+      const int nslots = (int)slot_operand.size();
+      out.vbase = n + 2 * nslots;
+      auto dvar = [&](int var, int i) -> Poly {               // d(var)/dq_i
+        if (var < n) return (var == i) ? poly_const(1.0) : Poly();
+        const int k = (var - n) / 2;
+        const Poly& arg = G[slot_operand[(size_t)k]][i];
+        if (arg.empty()) return Poly();
+        Poly r = poly_mul(poly_var(((var - n) & 1) ? var - 1 : var + 1), arg);      // cos: -sin * d arg; sin: cos * d arg
+        if ((var - n) & 1) { Poly neg; poly_add(neg, r, -1.0); return neg; }
+        return r;
+      };
+      out.dT.assign((size_t)n, Poly());
+      bool fits = true;
+      for (int i = 0; i < n && fits; ++i) {
+        Poly acc;
+        double scale = 0.0;
+        size_t e2 = 0;
+        for (int a = 0; a < n; ++a)
+          for (int b = a; b < n; ++b, ++e2) {
+            const double w = (a == b) ? -0.5 : -1.0;
+            for (const auto& t : out.k[e2]) {
+              for (size_t f = 0; f < t.first.size(); ++f) {
+                const Poly dv = dvar(t.first[f].first, i);
+                if (dv.empty()) continue;
+                Mono rest = t.first;
+                const double pw = (double)rest[f].second;
+                rest[f].second -= 1;
+                if (rest[f].second == 0) rest.erase(rest.begin() + (long)f);
+                Mono vv = (a == b) ? Mono{{out.vbase + a, 2}} : Mono{{out.vbase + a, 1}, {out.vbase + b, 1}};
+                Poly term; term[mono_mul(rest, vv)] = w * pw * t.second;
+                Poly prod = poly_mul(term, dv);
+                scale += poly_abs_sum(prod);
+                poly_add(acc, prod);
+              }
+            }
+          }
+        acc = poly_reduce(acc, n, out.vbase);
+        poly_prune(acc, scale);
+        for (const auto& t : acc) { int deg = 0; for (const auto& vp : t.first) deg += vp.second; out.dt_ops += deg + 1; }
+        if (acc.size() > 64) fits = false;
+        out.dT[(size_t)i] = acc;
+      }
+      // taken where it is SHORT (<= 12 n operations: doublePendulum 20, twoBody 4, spring 31, threeBodyPolar 12).  A chain's dT/dq has
+      // n (n - 1) terms of degree four -- counted from the code objects, chain4 -3 % and chain6 +7 % instructions per step against the
+      // directional second sweep, whose structural zeros the compiler already strips: the chains keep that sweep (and the symbolic K)
+      out.dt_ok = fits && out.dt_ops <= 12LL * n;
+    }
+  } catch (const SymFail&) { out.ok = false; out.dt_ok = false; }
+  return out;
+}
+
+static std::string sym_poly_expr(const Poly& p, int n, int vbase) {
+  std::ostringstream x;
+  bool first = true;
+  for (const auto& t : p) {
+    std::ostringstream f;
+    bool unit = true;
+    for (const auto& vp : t.first)
+      for (int r = 0; r < vp.second; ++r) {
+        f << (unit ? "" : " * ");
+        unit = false;
+        if (vp.first < n) f << "q[" << vp.first << "]";
+        else if (vp.first >= vbase) f << "v[" << (vp.first - vbase) << "]";
+        else f << "tc." << (((vp.first - n) & 1) ? "c" : "s") << "[" << (vp.first - n) / 2 << "]";
+      }
+    if (!first) x << " + ";
+    first = false;
+    if (unit) x << lit(t.second);
+    else if (t.second == 1.0) x << f.str();
+    else x << lit(t.second) << " * " << f.str();
+  }
+  if (first) x << "0.0";
+  return x.str();
+}
+
+void emit_symbolic_dt(std::ostringstream& o, const SymK& sk) {
+  o << "  // dT/dq = -1/2 v^T (dK/dq) v from the symbolic K (" << sk.dt_ops << " operations): no second-order sweep of f\n";
+  o << "  template <class TC> __device__ __forceinline__ static void dT_sym(const double (&q)[N], const double (&v)[N], const TC& tc, double (&dT)[N]) {\n";
+  for (int i = 0; i < sk.n; ++i) o << "    dT[" << i << "] = " << sym_poly_expr(sk.dT[(size_t)i], sk.n, sk.vbase) << ";\n";
+  o << "  }\n";
+}
+
+void emit_symbolic_k(std::ostringstream& o, const SymK& sk) {
+  const int n = sk.n;
+  o << "  // K = J^T M J derived symbolically (sin^2 + cos^2 = 1 applied; " << sk.sym_ops << " operations against " << sk.num_ops << " for the numerical sum)\n";
+  o << "  template <class TC> __device__ __forceinline__ static void mass_matrix_sym(const double (&q)[N], const TC& tc, double (&K)[N][N]) {\n";
+  size_t e = 0;
+  for (int a = 0; a < n; ++a)
+    for (int b = a; b < n; ++b, ++e) {
+      std::ostringstream x;
+      bool first = true;
+      for (const auto& t : sk.k[e]) {
+        std::ostringstream f;
+        bool unit = true;
+        for (const auto& vp : t.first)
+          for (int r = 0; r < vp.second; ++r) {
+            f << (unit ? "" : " * ");
+            unit = false;
+            if (vp.first < n) f << "q[" << vp.first << "]";
+            else f << "tc." << (((vp.first - n) & 1) ? "c" : "s") << "[" << (vp.first - n) / 2 << "]";
+          }
+        if (!first) x << " + ";
+        first = false;
+        if (unit) x << lit(t.second);
+        else if (t.second == 1.0) x << f.str();
+        else x << lit(t.second) << " * " << f.str();
+      }
+      if (first) x << "0.0";
+      o << "    K[" << a << "][" << b << "] = " << x.str() << ";\n";
+      if (a != b) o << "    K[" << b << "][" << a << "] = K[" << a << "][" << b << "];\n";
+    }
+  o << "  }\n";
+}
+}  // namespace
+
 std::string generate_source(const SystemDesc& d) {
   std::ostringstream o;
   o << "// generated by libhamk (hamk_codegen.cpp) from the expression tape of one System " << d.m << " " << d.n << "\n";
@@ -705,6 +981,15 @@ std::string generate_source(const SystemDesc& d) {
     table("seq_out", put_order);                            // (recorded by emit_body as it numbered the puts)
   }
   emit_reverse(o, d);
+  {
+    const SymK sk = d.k_symbolic ? symbolic_mass_matrix(d, slot_operand) : SymK();
+    o << "  static constexpr bool HAS_SYM_K = " << (sk.ok ? "true" : "false") << ";\n";
+    if (sk.ok) emit_symbolic_k(o, sk);
+    else o << "  template <class TC> __device__ __forceinline__ static void mass_matrix_sym(const double (&)[N], const TC&, double (&)[N][N]) {}\n";
+    o << "  static constexpr bool HAS_SYM_DT = " << ((sk.ok && sk.dt_ok) ? "true" : "false") << ";\n";
+    if (sk.ok && sk.dt_ok) emit_symbolic_dt(o, sk);
+    else o << "  template <class TC> __device__ __forceinline__ static void dT_sym(const double (&)[N], const double (&)[N], const TC&, double (&)[N]) {}\n";
+  }
   o << "  static constexpr int NTRIG_F = " << ntrig_f << ";\n";
   o << "  static constexpr int NTRIG_U = " << ntrig_u << ";\n";
   o << "};\n\n";

@@ -1041,7 +1041,7 @@ template <class S> HAMK_DEV void velocities(const double (&q)[S::N], const doubl
   seed1<S>(q, qj);
   S::template coords<Jet1<N>, TRIG_FULL>(qj, xj, tc);
   double K[N][N];
-  mass_matrix<S>(xj, K);
+  if constexpr (S::HAS_SYM_K) S::mass_matrix_sym(q, tc, K); else mass_matrix<S>(xj, K);
   solve_spd<N, S::INERTIA_POS>(K, p, qd, st);
 }
 
@@ -1074,7 +1074,17 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
                       TrigCache<S::NTRIG_F>& tc) {
   constexpr int N = S::N, M = S::M;
   double K[N][N], gU[N], U, v[N], dT[N];
-  if constexpr (MODE_H) {
+  if constexpr (S::HAS_SYM_K && S::HAS_SYM_DT) {
+    // K and dT/dq = -1/2 v^T (dK/dq) v from the generator's symbolic mass matrix (hamk_codegen.cpp symbolic_mass_matrix): the
+    // first-order sweep remains for dU/dq (and fills the sincos pairs); its Jacobian is dead code where U is over q
+    Jet1<N> qj[N], xj[M];
+    seed1<S>(q, qj);
+    S::template coords<Jet1<N>, TRIG>(qj, xj, tc);
+    S::mass_matrix_sym(q, tc, K);
+    solve_spd<N, S::INERTIA_POS>(K, p, v, st);
+    grad_potential<S>(qj, xj, gU, U, tc);
+    S::dT_sym(q, v, tc, dT);
+  } else if constexpr (MODE_H) {
     JetH<N> qh[N], xh[M];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -1090,7 +1100,7 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
 #pragma unroll
       for (int i = 0; i < N; ++i) xj[k].d[i] = xh[k].d[i];
     }
-    mass_matrix<S>(xj, K);
+    if constexpr (S::HAS_SYM_K) S::mass_matrix_sym(q, tc, K); else mass_matrix<S>(xj, K);
     solve_spd<N, S::INERTIA_POS>(K, p, v, st);
     grad_potential<S>(qj, xj, gU, U, tc);
 #pragma unroll
@@ -1113,7 +1123,7 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
     Jet1<N> qj[N], xj[M];
     seed1<S>(q, qj);
     S::template coords<Jet1<N>, TRIG>(qj, xj, tc);
-    mass_matrix<S>(xj, K);
+    if constexpr (S::HAS_SYM_K) S::mass_matrix_sym(q, tc, K); else mass_matrix<S>(xj, K);
     solve_spd<N, S::INERTIA_POS>(K, p, v, st);
     grad_potential<S>(qj, xj, gU, U, tc);
     if constexpr (S::MODE_R) {

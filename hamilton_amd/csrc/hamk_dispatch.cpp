@@ -562,6 +562,8 @@ static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4,
   if (o.rk4_min_waves > 0) d.rk4_min_waves = o.rk4_min_waves;
   d.k_reassoc = true;
   if (o.k_reassoc != HAMK_AUTO) d.k_reassoc = o.k_reassoc == HAMK_ON;
+  d.k_symbolic = true;                                      // (where it applies and pays: hamk_codegen.cpp symbolic_mass_matrix)
+  if (env_flag("HAMK_K_SYMBOLIC", &b)) d.k_symbolic = b;    // test override (A/B)
   {
     // sincos in the stepping kernels (hamk_device.hpp StageTrig).  Every evaluation through the LDS table is
     // the fewest instructions, but each is a 16-byte gather at a lane-dependent address (~20-25 LDS cycles

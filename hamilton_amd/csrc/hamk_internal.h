@@ -23,6 +23,7 @@ struct SystemDesc {
   int mapping = 1;              // HAMK_MAP_* (hamk.h)
   bool wave = false;            // mapping == HAMK_MAP_WAVE: wave-cooperative kernels (hamk_wave.hpp) instead of one trajectory per lane
   bool k_reassoc = true;        // mass_matrix summed with re-association allowed (hamk_device.hpp)
+  bool k_symbolic = true;       // lane mapping, n <= 7: K derived symbolically where f is polynomial in sincos of polynomial arguments (hamk_codegen.cpp symbolic_mass_matrix)
   bool rkf_park = false;        // lane / quad mapping: the RKF45 stepper's vectors in a run-time-indexed private array
   bool rk4_park = false;        // lane mapping: RK4 stage loop parks y / acc in LDS across the right-hand side
   bool trig_const_vgpr = false; // lane mapping, 8 <= n <= 14: sincos_lut's fp64 literals live in vector registers (hamk_device.hpp LutK)
