@@ -152,7 +152,7 @@ QUAD_CASES = [("chain32", False), ("chain20", False), ("chain17", False), ("chai
               ("chain16", True), ("chain8", True), ("threeBodyPolar", True), ("spring", True), ("opcodeZoo", True),
               # round 6: DENSE Jacobians on this mapping (hamk_quad.hpp assemble_dense: K in tiles) -- chosen by the library for dense18 and
               # denseD24 (distinct coefficients), forced for denseMixed17 (sincos sites that are not inputs, generalized potential)
-              ("dense18", False), ("dense24", False), ("denseD24", False), ("denseMixed17", True)]
+              ("dense18", False), ("dense24", False), ("dense32", False), ("denseD24", False), ("denseMixed17", True)]
 
 
 @pytest.mark.parametrize("name,force", QUAD_CASES)

@@ -684,10 +684,10 @@ def test_quad_kernels_on_host_match_oracle(emulate_quad, oracle_lib, name, B):
         check_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=min(B, 6), steps=2, tol=1e-10)
 
 
-@pytest.mark.parametrize("name,B", [("dense18", 5), ("dense24", 3), ("denseMixed17", 4), ("dense32", 2)])
+@pytest.mark.parametrize("name,B", [("dense18", 5), ("dense24", 3), ("denseMixed17", 4)])       # (dense32 -- four tiles -- on the GPU: test_gpu_wave.py)
 def test_quad_dense_maps_on_host_match_oracle(emulate_quad, oracle_lib, name, B):
     """Round 6: coordinate maps with a DENSE Jacobian on the four-lane kernels (hamk_quad.hpp assemble_dense) -- K accumulated in
-    one (n <= 20), two (24) and three (32) passes over groups of row slots, dU/dq of a cartesian potential as J^T dU/dx in a pass
+    tiles (one slot group at n <= 20, low and high slot groups against two column blocks at 24), dU/dq of a cartesian potential as J^T dU/dx in a pass
     of its own, identity padding (18, 17), sincos sites that are inputs (denseN) and that are not, a potential over the generalized
     coordinates (denseMixed17) -- against the oracle, through every entry point of the module."""
     spec = E.get(name)
@@ -695,8 +695,7 @@ def test_quad_dense_maps_on_host_match_oracle(emulate_quad, oracle_lib, name, B)
     assert "QUAD_DENSE = true" in __import__("hamilton_amd.api", fromlist=["api"]).system_from_spec(spec, {"mapping": __import__("hamilton_amd._abi", fromlist=["_abi"]).MAP_QUAD}).source
     o = oracle_lib.OracleSystem(spec)
     check_quad_against_oracle(L, spec, o, B=B)
-    if name != "dense32":
-        check_against_oracle(L, spec, o, B=min(B, 3), steps=2, tol=1e-10)
+    check_against_oracle(L, spec, o, B=min(B, 3), steps=2, tol=1e-10)
 
 
 def test_quad_flags_a_singular_mass_matrix(emulate_quad, oracle_lib):
