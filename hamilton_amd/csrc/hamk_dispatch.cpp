@@ -272,6 +272,7 @@ static int self_check_once(hamk_system* s, bool* rk4_ok, bool* rkf_ok) {
 
 static void derive_body_fields(const hamk_system* s, SystemDesc& d);
 
+static int post_build_checks(hamk_system* s, Variant* v);
 static int self_check(hamk_system* s) {
   if (!s->self_check_on) return HAMK_OK;
   Variant* v = s->curv;
@@ -292,6 +293,8 @@ static int self_check(hamk_system* s) {
     derive_body_fields(s, v->desc);
     v->source = generate_source(v->desc);
     rc = build_code(v, s->cache_on, build_force(s));
+    if (rc != HAMK_OK) return rc;
+    rc = post_build_checks(s, v);                          // (the rebuilt module passes the same look-at-the-built-kernel rules as a first build)
     if (rc != HAMK_OK) return rc;
     v->generation++;                                       // other devices reload (and re-check) lazily
     for (DevState* d : s->devs) if (d != s->cur) d->mod[v->mapping].self_checked = false;
@@ -602,6 +605,56 @@ static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4,
   return d;
 }
 
+// What variant_for decides by LOOKING AT THE BUILT KERNELS: a kernel over 64 KiB goes to the stage-loop body, a two-wavefront
+// stepper that spills goes back to one wavefront, a wave RK4 kernel that spills by the hundred under its two-wavefront cap is rebuilt
+// for one.  One helper, applied until nothing changes any more, for a first build AND for the self-check's rebuild (which flips bodies
+// and re-derives fields: the rebuilt module must pass the same rules -- ADVICE r05).
+static int post_build_checks(hamk_system* s, Variant* v) {
+  const int mapping = v->mapping;
+  const size_t kLimit = 64 * 1024;
+  const bool lane = mapping == HAMK_MAP_LANE;
+  bool lane_flag_ = false;
+  int rc = HAMK_OK;
+  for (int pass = 0; pass < 4; ++pass) {
+    const std::string before = v->source;
+    // keep every kernel comfortably inside SOPP branch reach: fall back to the stage-loop bodies
+    const bool big_rkf = lane && !v->forced_rkf_body && !v->desc.rkf_stage_loop && chosen_kernel_bytes(v, K_RKF45) > kLimit;
+    const bool big_rk4 = lane && !v->forced_rk4_body && !v->desc.rk4_stage_loop && chosen_kernel_bytes(v, K_RK4) > kLimit;
+    if (big_rkf || big_rk4) {
+      if (big_rkf) v->desc.rkf_stage_loop = true;
+      if (big_rk4) v->desc.rk4_stage_loop = true;
+      derive_body_fields(s, v->desc);
+      v->source = generate_source(v->desc);
+      rc = build_code(v, s->cache_on, build_force(s));
+      if (rc != HAMK_OK) return rc;
+    }
+    // the two-wavefront stepper caps hamk_rkf45_k at 256 registers: where THIS system's right-hand side does not fit (a heavy
+    // tape at small n) the cap turns into spill code inside the attempt loop -- back to one wavefront with every row in LDS
+    if (lane && v->desc.rkf_two_waves && !env_flag("HAMK_RKF_TWO_WAVES", &lane_flag_) &&
+        vgpr_spill_count(v->use2[K_RKF45] ? v->code2 : v->code, kKernelNames[K_RKF45]) > 32) {
+      v->desc.rkf_two_waves_off = true;
+      derive_body_fields(s, v->desc);
+      v->source = generate_source(v->desc);
+      rc = build_code(v, s->cache_on, build_force(s));
+      if (rc != HAMK_OK) return rc;
+    }
+    // wave-cooperative RK4 kernel: two wavefronts per SIMD (256 registers) is the measured default -- the chains spill a few hundred
+    // registers under the cap and still gain (chain48 1.32e7 vs 1.06e7 steps/s, chain64 8.1e6 vs 7.6e6) -- but a system whose tape
+    // is heavy (a dense coordinate map: every lane carries one-direction jets of n^2 terms) spills by the thousand and waits on
+    // scratch for three quarters of its cycles: dense32 967 spilled registers, 490 GB of HBM traffic per launch, 4.4e6 steps/s at
+    // two wavefronts against 1.30e7 at one with 6 spilled (profiles/r05c_wave_probe.jsonl; dense24, 241 spilled: a tie).
+    if (mapping == HAMK_MAP_WAVE && s->opt.rk4_min_waves == 0 && v->desc.rk4_min_waves > 1 &&
+        vgpr_spill_count(v->use2[K_RK4] ? v->code2 : v->code, kKernelNames[K_RK4]) > 512) {
+      v->desc.rk4_min_waves = 1;
+      v->source = generate_source(v->desc);
+      rc = build_code(v, s->cache_on, build_force(s));
+      if (rc != HAMK_OK) return rc;
+    }
+    if (v->source == before) break;
+  }
+  return HAMK_OK;
+}
+
 int variant_for(hamk_system* s, int64_t B, int kernel, Variant** out) {
   const int mapping = choose_mapping(s, B, kernel);
   if (s->var[mapping]) { *out = s->var[mapping]; return HAMK_OK; }
@@ -623,42 +676,8 @@ int variant_for(hamk_system* s, int64_t B, int kernel, Variant** out) {
   v->source = generate_source(v->desc);
   int rc = build_code(v, s->cache_on, build_force(s));
   if (rc != HAMK_OK) { delete v; return rc; }
-  // keep every kernel comfortably inside SOPP branch reach: fall back to the stage-loop bodies
-  const size_t kLimit = 64 * 1024;
-  const bool lane = mapping == HAMK_MAP_LANE;
-  bool lane_flag_ = false;
-  const bool big_rkf = lane && !v->forced_rkf_body && !v->desc.rkf_stage_loop && chosen_kernel_bytes(v, K_RKF45) > kLimit;
-  const bool big_rk4 = lane && !v->forced_rk4_body && !v->desc.rk4_stage_loop && chosen_kernel_bytes(v, K_RK4) > kLimit;
-  if (big_rkf || big_rk4) {
-    if (big_rkf) v->desc.rkf_stage_loop = true;
-    if (big_rk4) v->desc.rk4_stage_loop = true;
-    derive_body_fields(s, v->desc);
-    v->source = generate_source(v->desc);
-    rc = build_code(v, s->cache_on, build_force(s));
-    if (rc != HAMK_OK) { delete v; return rc; }
-  }
-  // the two-wavefront stepper caps hamk_rkf45_k at 256 registers: where THIS system's right-hand side does not fit (a heavy
-  // tape at small n) the cap turns into spill code inside the attempt loop -- back to one wavefront with every row in LDS
-  if (lane && v->desc.rkf_two_waves && !env_flag("HAMK_RKF_TWO_WAVES", &lane_flag_) &&
-      vgpr_spill_count(v->use2[K_RKF45] ? v->code2 : v->code, kKernelNames[K_RKF45]) > 32) {
-    v->desc.rkf_two_waves_off = true;
-    derive_body_fields(s, v->desc);
-    v->source = generate_source(v->desc);
-    rc = build_code(v, s->cache_on, build_force(s));
-    if (rc != HAMK_OK) { delete v; return rc; }
-  }
-  // wave-cooperative RK4 kernel: two wavefronts per SIMD (256 registers) is the measured default -- the chains spill a few hundred
-  // registers under the cap and still gain (chain48 1.32e7 vs 1.06e7 steps/s, chain64 8.1e6 vs 7.6e6) -- but a system whose tape
-  // is heavy (a dense coordinate map: every lane carries one-direction jets of n^2 terms) spills by the thousand and waits on
-  // scratch for three quarters of its cycles: dense32 967 spilled registers, 490 GB of HBM traffic per launch, 4.4e6 steps/s at
-  // two wavefronts against 1.30e7 at one with 6 spilled (profiles/r05c_wave_probe.jsonl; dense24, 241 spilled: a tie).
-  if (mapping == HAMK_MAP_WAVE && s->opt.rk4_min_waves == 0 && v->desc.rk4_min_waves > 1 &&
-      vgpr_spill_count(v->use2[K_RK4] ? v->code2 : v->code, kKernelNames[K_RK4]) > 512) {
-    v->desc.rk4_min_waves = 1;
-    v->source = generate_source(v->desc);
-    rc = build_code(v, s->cache_on, build_force(s));
-    if (rc != HAMK_OK) { delete v; return rc; }
-  }
+  rc = post_build_checks(s, v);
+  if (rc != HAMK_OK) { delete v; return rc; }
   // dense map on the four-lane kernels (quad_dense_eligible): the premise is that a tile's accumulators, the entries of J it needs
   // and their sincos pairs fit the registers.  Where the built kernel says otherwise -- it spills by the hundred, and at one wavefront
   // per SIMD a kernel that waits for scratch loses whatever it saves in instructions (first build of dense24, its shared products
