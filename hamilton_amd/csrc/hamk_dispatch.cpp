@@ -567,6 +567,7 @@ static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4,
   if (o.k_reassoc != HAMK_AUTO) d.k_reassoc = o.k_reassoc == HAMK_ON;
   d.k_symbolic = true;                                      // (where it applies and pays: hamk_codegen.cpp symbolic_mass_matrix)
   if (env_flag("HAMK_K_SYMBOLIC", &b)) d.k_symbolic = b;    // test override (A/B)
+
   {
     // sincos in the stepping kernels (hamk_device.hpp StageTrig).  Every evaluation through the LDS table is
     // the fewest instructions, but each is a 16-byte gather at a lane-dependent address (~20-25 LDS cycles
@@ -584,6 +585,10 @@ static SystemDesc make_desc(const hamk_system* s, int mapping, bool* forced_rk4,
     const double width = d.mode_h ? 1.0 + n + 0.5 * n * (n + 1) : 3.0 * n + 3.0;      // jet components carried per tape value
     const double est_rhs = (f_nops + u_nops) * width + 2.0 * m * n * n + n * n * n / 3.0;
     d.use_lut = (sites >= 1 && sites <= 4 && est_rhs / sites < 100.0) ? 2 : 1;
+    // round 6: where K and dT/dq come from the symbolic mass matrix the right-hand side is a fraction of that estimate, and rotations
+    // win for every system with 1-4 sites -- measured on one box (profiles/r06_trig_rule_ab.jsonl): threeBodyPolar 3.23e10 (table) /
+    // 3.39e10 (one table evaluation per step + rotations), spring 6.16e10 / 6.33e10; doublePendulum and pendulum had them already
+    if (mapping == HAMK_MAP_LANE && sites >= 1 && sites <= 4 && n <= 7 && d.k_symbolic && symbolic_rhs_applies(d)) d.use_lut = 2;
     // the four-lane kernels from n = 14: no table.  Their register file is K's, the table costs 8 KiB of an LDS that is nearly
     // full and a handful of registers: chain32 2.50e8 steps/s without it, 2.28e8 with (Scratch_Size 372 -> 488 B, HBM traffic
     // per launch 233 -> 788 MB; profiles/r03e_chain32_summary.json vs the first r04 pass, where this rule had been dropped

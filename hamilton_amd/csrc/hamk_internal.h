@@ -46,5 +46,7 @@ int distinct_jacobian_entries(const SystemDesc& d);
 // fp64 operations of ONE first-order forward sweep of the coordinate map with compile-time seeds: per tape operation the number of
 // gradient entries it has to COMPUTE (structural zeros and pass-through copies are free) -- what a lane of the quad mapping pays per pass
 long long forward_gradient_work(const SystemDesc& d);
+// a lane module of this system takes K and dT/dq from the symbolic mass matrix (hamk_codegen.cpp symbolic_mass_matrix)
+bool symbolic_rhs_applies(const SystemDesc& d);
 
 }  // namespace hamk_host
