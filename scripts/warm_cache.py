@@ -47,6 +47,8 @@ def jobs():
         out.append((n, {"HAMK_TRIG_LUT": "1"}, False))
     for seed in range(16):
         out.append((f"random{seed}", {}, False))
+    for seed in (0, 2, 3, 5, 6, 7, 8, 11, 13, 14, 15):     # round 6: random trigonometric-polynomial maps (the symbolic mass matrix; tests/test_gpu_random_systems.py)
+        out.append((f"polytrig{seed}", {}, False))
     # four lanes per trajectory (hamk_quad.hpp): the default RK4 / hamEqs module of 17 <= n <= 32 (built by the plain jobs
     # above); the wave module those systems keep for their other entry points; forced quad builds of small systems
     for n in ("chain17", "chain18", "chain20", "chain24", "chain32"):
@@ -89,6 +91,9 @@ def build(job):
         if name.startswith("random"):
             from test_gpu_random_systems import random_spec
             spec = random_spec(int(name[6:]))
+        elif name.startswith("polytrig"):
+            from test_gpu_random_systems import poly_trig_spec
+            spec = poly_trig_spec(int(name[8:]))
         else:
             spec = examples.get(name)
         s = api.system_from_spec(spec)

@@ -72,6 +72,85 @@ def random_spec(seed):
                         q0=(0.1,) * n, qd0=(0.2,) * n, q_box=box, qd_box=box, dt=0.005, cite="random")
 
 
+def poly_trig_spec(seed):
+    """Random TRIGONOMETRIC-POLYNOMIAL coordinate maps with the structure that makes a mass matrix simplify (round 6): planar bodies at
+    (base + rho cos phi, base + rho sin phi), rho in {constant, q_i, 1 + q_i / 2}, phi an integer-ish combination of inputs, each body
+    hanging from the origin or from the previous body -- random pendulums, polar particles and mixtures, optionally with a free
+    cartesian coordinate.  The class of maps for which the generator derives K and dT/dq SYMBOLICALLY (hamk_codegen.cpp
+    symbolic_mass_matrix: sin^2 + cos^2 = 1); the random expression DAGs above never are (exp, tanh, sqrt ...)."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 5))
+    bodies = int(rng.integers(1, 4))
+    extra = int(rng.integers(0, 2))
+    m = 2 * bodies + extra
+    prog_seed = int(rng.integers(1 << 30))
+    u_cart = bool(rng.integers(2))
+    inertia = tuple(float(np.round(rng.uniform(0.5, 2.0), 2)) for _ in range(m))
+
+    def f(q, o):
+        r = np.random.default_rng(prog_seed)
+        out, bx, by = [], 0.0, 0.0
+        used = set()
+        for b in range(bodies):
+            i = b % n                                              # every coordinate drives something (full-rank J)
+            used.add(i)
+            kind = int(r.integers(3))
+            j = int(r.integers(n))
+            phi = q[i] if kind == 0 else (q[i] + float(r.choice([1.0, -1.0, 2.0])) * q[j] if (kind == 1 and j != i) else float(r.choice([1.0, 2.0])) * q[i])
+            rk = int(r.integers(3))
+            l = int(r.integers(n))
+            rho = float(np.round(r.uniform(0.5, 1.5), 2)) if (rk == 0 or l == i) else (1.5 + q[l] if rk == 1 else 1.0 + 0.5 * q[l])
+            if not isinstance(rho, float):
+                used.add(l)
+            x, y = bx + rho * o.cos(phi), by + rho * o.sin(phi)
+            out += [x, y]
+            if r.random() < 0.5:
+                bx, by = x, y                                      # the next body hangs from this one
+        for _ in range(extra):
+            out.append(sum(q[k] for k in range(n)) * 0.7)
+        for k in range(n):                                         # coordinates nothing drives yet: a direct cartesian component
+            if k not in used and extra == 0:
+                out[-1] = out[-1] + 1.3 * q[k]
+        return out
+
+    def u(z, o):
+        acc = 0.0
+        for k, zk in enumerate(z):
+            acc = acc + (0.5 + 0.1 * k) * zk * zk
+        return acc + 0.2 * o.cos(z[0])
+
+    box = tuple((-1.0, 1.0) for _ in range(n))
+    return E.SystemSpec(name=f"polytrig{seed}", m=m, n=n, inertia=inertia, f=f, u=u,
+                        u_space=E.U_CARTESIAN if u_cart else E.U_GENERALIZED,
+                        q0=(0.1,) * n, qd0=(0.2,) * n, q_box=box, qd_box=box, dt=0.005, cite="random (trigonometric polynomial)")
+
+
+POLY_TRIG_SEEDS = [0, 2, 3, 5, 6, 7, 8, 11, 13, 14, 15]      # (the seeds whose random map has full rank: median cond K < 100)
+
+
+@pytest.mark.parametrize("seed", POLY_TRIG_SEEDS)
+def test_random_trigonometric_polynomial_systems_vs_oracle(api, oracle_lib, seed):
+    """The symbolic mass matrix on maps nobody hand-checked: hamEqs, velocities, energies, RK4 and stepHam of random
+    trigonometric-polynomial systems against the oracle (which differentiates the tape numerically-exactly and knows no algebra)."""
+    spec = poly_trig_spec(seed)
+    s = api.system_from_spec(spec)
+    o = oracle_lib.OracleSystem(spec)
+    B = 257
+    q, qd = E.sample_config(spec, 5, B)
+    p = o.to_phase_batch(q, qd)
+    dq, dp = api.hamEqs(s, api.Phase(q, p))
+    odq, odp, ost = o.hameqs_batch(q, p)
+    ok = (ost == 0) & (np.asarray(s.last_status) == 0)
+    assert ok.mean() > 0.9
+    cond = np.array([np.linalg.cond(o.jacobian(q[:, i]).T @ np.diag(spec.inertia) @ o.jacobian(q[:, i])) for i in range(B)])
+    ok &= cond < 1e6
+    assert relerr(np.asarray(dq)[:, ok], odq[:, ok]) < 1e-9 and relerr(np.asarray(dp)[:, ok], odp[:, ok]) < 1e-9, (seed, "HAS_SYM_K = true" in s.source)
+    assert relerr(np.asarray(api.hamiltonian(s, api.Phase(q, p)))[ok], o.observe_batch(q, p)[2][ok]) < 1e-9
+    ph = api.rk4Steps(spec.dt, 4, s, api.Phase(q, p))
+    oq, op = o.rk4_steps_batch(q, p, spec.dt, 4)
+    assert relerr(np.asarray(ph.positions)[:, ok], oq[:, ok]) < 1e-9 and relerr(np.asarray(ph.momenta)[:, ok], op[:, ok]) < 1e-9
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_random_system_vs_oracle(api, oracle_lib, seed):
     spec = random_spec(seed)

@@ -353,6 +353,23 @@ def test_random_systems_on_host(emulate, oracle_lib, seed):
         check_against_oracle(L, spec, o, B=32, start=99, dt_ham=0.02)
 
 
+POLY_TRIG_SEEDS = [0, 2, 3, 5, 6, 7, 8, 11, 13, 14, 15]      # (the seeds whose random map has full rank: median cond K < 100)
+
+
+@pytest.mark.parametrize("seed", POLY_TRIG_SEEDS)
+def test_random_trigonometric_polynomial_systems_on_host(emulate, oracle_lib, seed):
+    """Round 6: random trigonometric-polynomial maps -- the class whose mass matrix and dT/dq the generator derives symbolically -- through
+    the emulated lane kernels against the oracle; at least six of the eleven must actually take the symbolic path."""
+    from test_gpu_random_systems import poly_trig_spec
+    spec = poly_trig_spec(seed)
+    o = oracle_lib.OracleSystem(spec)
+    L, src = emulate(spec)
+    check_against_oracle(L, spec, o, B=32, start=99, dt_ham=0.02, tol=1e-10)
+    test_random_trigonometric_polynomial_systems_on_host.symbolic = getattr(test_random_trigonometric_polynomial_systems_on_host, "symbolic", 0) + ("HAS_SYM_K = true" in src)
+    if seed == POLY_TRIG_SEEDS[-1]:
+        assert test_random_trigonometric_polynomial_systems_on_host.symbolic >= 6
+
+
 def check_against_golden(L, name, tol0=1e-12):
     """Device code (any mapping) against the independently derived 50-digit fixtures (tests/golden): no oracle in the loop."""
     from conftest import fvec, load_golden
