@@ -1171,8 +1171,11 @@ HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (
 //     5 or more sites (the chains: anchors do not fit in registers) -> every evaluation through the table;
 //   HAMK_USE_LUT = 1: every evaluation through the table;  0: no table (round-1 arithmetic).
 // The adaptive stepper (RKF45) takes every evaluation through the table when there is one.
+#ifndef HAMK_TRIG_FEW_MAX
+#define HAMK_TRIG_FEW_MAX 4      /* rotations (one table evaluation per step + three rotations per site) up to this many sincos sites: anchors are 3 registers each */
+#endif
 template <class S> struct StageTrig {
-  static constexpr bool few = (S::NTRIG_F >= 1 && S::NTRIG_F <= 4);
+  static constexpr bool few = (S::NTRIG_F >= 1 && S::NTRIG_F <= HAMK_TRIG_FEW_MAX);
   static constexpr bool lut = (HAMK_USE_LUT != 0) && (S::NTRIG_F >= 1);          // the kernel loads the table
 #ifdef HAMK_NO_INCR
   static constexpr bool on = false;
