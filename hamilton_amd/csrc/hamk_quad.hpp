@@ -50,25 +50,11 @@ template <int N> struct Geo {
 
 // [row][64]: component `a` of the block's trajectory `tl` at a * 64 + tl (a wavefront reads 16 consecutive doubles, each
 // by the four lanes of a quad: conflict-free broadcasts)
-// HAMK_CHOL_LDS (round 6, A/B switch; 0 = the shipped DPP broadcasts): the factorisation's panel update takes the panel's rows of the
-// finished columns through LDS (chol below) from panel HAMK_CHOL_LDS on; costs one more region of NP4 x 64 doubles (BX: the rows of the
-// velocities are dead while the factorisation runs, but only for THIS wavefront -- the block's other wavefronts write theirs
-// whenever they get there, and the [row][64 trajectories] layout interleaves the wavefronts' doubles).
-#ifndef HAMK_CHOL_LDS
-#define HAMK_CHOL_LDS 0
-#endif
-#ifndef HAMK_CHOL_LDS_LAST
-#define HAMK_CHOL_LDS_LAST 99      /* last panel that takes the finished columns through LDS */
-#endif
-#ifndef HAMK_CHOL_LDS_PD
-#define HAMK_CHOL_LDS_PD 2         /* column pairs the loads run ahead of the arithmetic (at most a chunk) */
-#endif
 template <class S> struct Lds {
   static constexpr int NP4 = Geo<S::N>::NP4;
-  static constexpr bool CHOL_LDS = (HAMK_CHOL_LDS != 0) && !S::QUAD_DENSE && Geo<S::N>::NR >= 4;
-  static constexpr int Q = 0, V = NP4 * 64, SQ = 2 * NP4 * 64, CQ = 3 * NP4 * 64, GU = 4 * NP4 * 64, BX = 5 * NP4 * 64, TOTAL = (CHOL_LDS ? 6 : 5) * NP4 * 64;
+  static constexpr int Q = 0, V = NP4 * 64, SQ = 2 * NP4 * 64, CQ = 3 * NP4 * 64, GU = 4 * NP4 * 64, TOTAL = 5 * NP4 * 64;
 };
-#define HAMK_QUAD_SMEM(S) __shared__ __attribute__((aligned(16))) double smem[hamk::quad::Lds<S>::TOTAL]
+#define HAMK_QUAD_SMEM(S) __shared__ double smem[hamk::quad::Lds<S>::TOTAL]
 
 #ifdef HAMK_HOST_EMULATION
 // tests/host_emulation/wave_shim.hpp: one OS thread per lane; quad primitives through a per-quad barrier
@@ -339,77 +325,21 @@ template <class S> struct SinkK {
 // owns; the entries beyond the lane's diagonal are the symmetric ones and never read.
 // (Measured against this order on one box and not kept, profiles/r04g_ab.jsonl, r04h_ab.jsonl, r04i_ab.jsonl: the right-looking
 // order of the same in-place Cholesky, -1.7 ... -5 %; a look-ahead -- the next panel collecting the finished columns while
-// this panel's pivots are eliminated -- +3 % at n = 32, -1 % at n = 24 and 17.  git history: 4c91209.)
-// two doubles of LDS, 16-byte aligned: one ds_read_b128 / ds_write_b128
-HAMK_DEV void lds_put2(double* p, double a, double b) {
-#ifdef HAMK_HOST_EMULATION
-  p[0] = a; p[1] = b;
-#else
-  typedef double v2d __attribute__((ext_vector_type(2)));
-  v2d x; x.x = a; x.y = b;
-  *reinterpret_cast<v2d*>(p) = x;
-#endif
-}
-HAMK_DEV void lds_get2(const double* p, double& a, double& b) {
-#ifdef HAMK_HOST_EMULATION
-  a = p[0]; b = p[1];
-#else
-  typedef double v2d __attribute__((ext_vector_type(2)));
-  const v2d x = *reinterpret_cast<const v2d*>(p);
-  a = x.x; b = x.y;
-#endif
-}
-// (writes of one lane, reads of its three neighbours: the four are one wavefront's, whose DS operations execute in order -- the
-// fence is for the compiler)
-#ifdef HAMK_HOST_EMULATION
-#define HAMK_CHOL_SYNC() emu_quad_barrier()
-#define HAMK_CHOL_WAR() emu_quad_barrier()
-#else
-#define HAMK_CHOL_WAR() ((void)0)
-#define HAMK_CHOL_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#endif
-
+// this panel's pivots are eliminated -- +3 % at n = 32, -1 % at n = 24 and 17.  git history: 4c91209.
+// Round 6, profiles/r06g_chol_lds_ab.jsonl: the update's broadcasts through LDS -- every lane leaves its row of the finished columns, all
+// four read the panel's four rows, 2.5 LDS instructions per column instead of 8 moves, written a panel ahead and loaded two column pairs
+// ahead: 9 % fewer VALU instructions and -7.5 ... +0.6 % steps/s at n = 32 (a wavefront alone on its SIMD waits for what it does not
+// issue).  git history: bdf3ae2.)
 template <class S>
-HAMK_DEV void chol(const Ctx<S>& cx, int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], int& st) {
+HAMK_DEV void chol(int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N>::NP4], double (&z)[Geo<S::N>::NR], int& st) {
   constexpr int N = S::N, NR = Geo<N>::NR;
   bool ok = true;
 #pragma unroll
   for (int jb = 0; jb < NR; ++jb) {
     HAMK_PHASE();
     const int J0 = 4 * jb, J1 = (4 * jb + 4 < N) ? 4 * jb + 4 : N;        // this panel's pivots [J0, J1)
-    // Columns [0, JL) of the update THROUGH LDS (HAMK_CHOL_LDS: panels HAMK_CHOL_LDS .. HAMK_CHOL_LDS_LAST), the last finished panel's
-    // columns [JL, J0) by DPP.  Every lane leaves its row's entries of a chunk of CH columns (half a ds_write_b128 per column) and
-    // reads all four rows' (two ds_read_b128 per column): 2.5 issue slots per column instead of 8 moves.  Two regions (the halves of
-    // Lds::BX), each [row of the panel][column pair][trajectory][2]: a wavefront's sixteen trajectories read 256 consecutive bytes,
-    // the quad's four lanes the same sixteen.  Chunks alternate between the regions.  What a panel reads was final one panel earlier:
-    // chunks 0 and 1 are written while the PREVIOUS panel eliminates its pivots, chunk ch + 2 when chunk ch has been consumed, and the
-    // loads run PD column pairs ahead of the arithmetic (a wavefront alone on its SIMD waits for every round trip it does not cover).
-    constexpr bool LX = Lds<S>::CHOL_LDS;
-    constexpr int CH = LX ? 2 * (NR / 4) : 2, HP = CH / 2, PD = (HAMK_CHOL_LDS_PD < HP) ? HAMK_CHOL_LDS_PD : HP;
-    double* const reg[2] = {cx.smem + Lds<S>::BX + 2 * cx.tl, cx.smem + Lds<S>::BX + Lds<S>::NP4 * 32 + 2 * cx.tl};
-    const int ro = r * (HP * 128);
-    auto put = [&](int slot, int ch, int JLx) {          // chunk ch of row slot `slot`'s columns [0, JLx)
 #pragma unroll
-      for (int cp = 0; cp < HP; ++cp) {
-        const int j = ch * CH + 2 * cp;
-        if (j < JLx) lds_put2(reg[ch & 1] + ro + cp * 128, Kp[slot][j], Kp[slot][j + 1]);
-      }
-    };
-    auto through_lds = [](int b) { return LX && b >= 2 && b >= HAMK_CHOL_LDS && b <= HAMK_CHOL_LDS_LAST; };
-    const int JL = through_lds(jb) ? 4 * (jb - 1) : 0;
-    const int NPR = JL / 2, NCH = (JL + CH - 1) / CH;
-    double cb[PD + 1][4][2];
-    auto get = [&](int P) {
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) lds_get2(reg[(P / HP) & 1] + (rr * HP + (P % HP)) * 128, cb[P % (PD + 1)][rr][0], cb[P % (PD + 1)][rr][1]);
-    };
-    if (JL > 0) {
-      HAMK_CHOL_SYNC();
-#pragma unroll
-      for (int P = 0; P < PD && P < NPR; ++P) get(P);
-    }
-#pragma unroll
-    for (int j = JL; j < J0; ++j) {
+    for (int j = 0; j < J0; ++j) {
       const double c0 = qbcast<0>(Kp[jb][j]), c1 = qbcast<1>(Kp[jb][j]), c2 = qbcast<2>(Kp[jb][j]), c3 = qbcast<3>(Kp[jb][j]);
 #pragma unroll
       for (int i = jb; i < NR; ++i) {
@@ -419,28 +349,6 @@ HAMK_DEV void chol(const Ctx<S>& cx, int r, double (&Kp)[Geo<S::N>::NR][Geo<S::N
         if (J0 + 2 < J1) Kp[i][J0 + 2] = fma(-g, c2, Kp[i][J0 + 2]);
         if (J0 + 3 < J1) Kp[i][J0 + 3] = fma(-g, c3, Kp[i][J0 + 3]);
       }
-    }
-#pragma unroll
-    for (int P = 0; P < NPR; ++P) {
-      if (P + PD < NPR) get(P + PD);
-      HAMK_PHASE();
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-#pragma unroll
-        for (int i = jb; i < NR; ++i) {
-          const double g = Kp[i][2 * P + e];
-          Kp[i][J0] = fma(-g, cb[P % (PD + 1)][0][e], Kp[i][J0]);
-          if (J0 + 1 < J1) Kp[i][J0 + 1] = fma(-g, cb[P % (PD + 1)][1][e], Kp[i][J0 + 1]);
-          if (J0 + 2 < J1) Kp[i][J0 + 2] = fma(-g, cb[P % (PD + 1)][2][e], Kp[i][J0 + 2]);
-          if (J0 + 3 < J1) Kp[i][J0 + 3] = fma(-g, cb[P % (PD + 1)][3][e], Kp[i][J0 + 3]);
-        }
-      }
-      if ((P + 1) % HP == 0 && P / HP + 2 < NCH) { HAMK_CHOL_WAR(); put(jb, P / HP + 2, JL); HAMK_CHOL_SYNC(); }
-    }
-    if (jb + 1 < NR && through_lds(jb + 1)) {            // the next panel's first two chunks: final since the previous panel
-      HAMK_CHOL_WAR();
-      put(jb + 1, 0, 4 * jb);
-      if (4 * jb > CH) put(jb + 1, 1, 4 * jb);
     }
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -779,7 +687,7 @@ HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const
 #pragma unroll
     for (int i = 0; i < NR; ++i) { z[i] = pi[i]; c.gu()[(4 * i + r) * 64] = gUi[i]; gUi[i] = 0.0; }
     HAMK_PHASE();
-    chol<S>(c, r, Kp, z, st);
+    chol<S>(r, Kp, z, st);
     HAMK_PHASE();
     solve_back<S>(r, Kp, z, vi);
     HAMK_PHASE();
@@ -799,7 +707,7 @@ HAMK_DEV void velocity(const Ctx<S>& c, const double (&qi)[Geo<S::N>::NR], const
 #pragma unroll
   for (int i = 0; i < NR; ++i) { z[i] = pi[i]; c.gu()[(4 * i + r) * 64] = gUi[i]; gUi[i] = 0.0; }      // (dU/dq waits in LDS: Ctx::gu)
   HAMK_PHASE();
-  chol<S>(c, r, sink.acc, z, st);
+  chol<S>(r, sink.acc, z, st);
   HAMK_PHASE();
   solve_back<S>(r, sink.acc, z, vi);
   HAMK_PHASE();
@@ -1127,14 +1035,13 @@ template <class S> struct RkfPark {
   static constexpr int D = 2 * Geo<S::N>::NR;
   static constexpr int BUDGET = (160 * 1024 - 8 * 1024 - 2 * 1024 - Lds<S>::TOTAL * 8) / 2048;       // doubles per lane left in the CU's LDS
   static constexpr int NL = (BUDGET / D) > 5 ? 5 : (BUDGET / D);                                        // y, dydt, then k2, k3, k4
-  static constexpr bool FITS = NL >= 2;      // the quad exchange arrays leave room for y and dydt up to n = 32 (not next to HAMK_CHOL_LDS's region at n > 28: the register body then)
+  static_assert(NL >= 2, "the quad exchange arrays leave room for y and dydt up to n = 32");
 };
 template <class S>
 HAMK_DEV void rkf45_body_parked(double* smem, const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt,
                                 const double* ts, double ts0, double ts1, double h0, double eps_abs, double eps_rel,
                                 int flags, int max_sub, int* status, int* nsub, int ncalls, int it_every) {
   constexpr int N = S::N, NR = Geo<N>::NR, D = 2 * NR, NL = RkfPark<S>::NL;
-  static_assert(RkfPark<S>::FITS, "the quad exchange arrays leave room for y and dydt up to n = 32");
   constexpr bool LUT = StageTrig<S>::lut;
   if constexpr (LUT) lut_load();
   const int row0 = flags & 1, inplace = (flags >> 8) & 3, gsl_api = (flags >> 16) & 3;
@@ -1341,7 +1248,7 @@ template <class S>
 HAMK_DEV void rkf45_body(double* smem, const double* q0, const double* p0, double* qout, double* pout, i64 B, int nt,
                          const double* ts, double ts0, double ts1, double h0, double eps_abs, double eps_rel,
                          int flags, int max_sub, int* status, int* nsub, int ncalls, int it_every) {
-  if constexpr (HAMK_QUAD_RKF_PARK != 0 && RkfPark<S>::FITS) {
+  if constexpr (HAMK_QUAD_RKF_PARK != 0) {
     rkf45_body_parked<S>(smem, q0, p0, qout, pout, B, nt, ts, ts0, ts1, h0, eps_abs, eps_rel, flags, max_sub, status, nsub, ncalls, it_every);
     return;
   }

@@ -4,12 +4,12 @@ The left-looking panel update of hamk_quad.hpp chol needs, per finished column, 
 moves per column in the shipped kernel.  -DHAMK_CHOL_LDS=k takes them through LDS from panel k on (half a ds_write_b128 + two
 ds_read_b128 per column; chunks written a panel ahead, loads HAMK_CHOL_LDS_PD column pairs ahead): 6 377 -> ~5 800 VALU instructions per
 stage at n = 32, +210 LDS instructions.  RK4 steps/s of each variant, same box, same state; results against the default build.
-  python scripts/chol_lds_ab.py [--compile-only]"""
+  python scripts/archive/chol_lds_ab.py [--compile-only]      (needs the tree of commit bdf3ae2: the variant was deleted after the measurement)"""
 import json
 import os
 os.environ["HAMK_TEST_OVERRIDES"] = "1"
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 COMPILE_ONLY = "--compile-only" in sys.argv

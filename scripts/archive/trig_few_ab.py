@@ -2,12 +2,12 @@
 """Round 6: rotations (one table evaluation per step + three rotations per sincos site) for systems with MORE than four sites -- the chains
 of 5 ... 8 links, whose stepping kernels run one wavefront per SIMD and wait for their table gathers (chain8: SQ_WAIT_ANY 0.20) --
 against every evaluation through the LDS table.  -DHAMK_TRIG_FEW_MAX=8 with HAMK_TRIG_LUT=2 vs the default; RK4 steps/s, same box.
-  python scripts/trig_few_ab.py [--compile-only]"""
+  python scripts/archive/trig_few_ab.py [--compile-only]"""
 import json
 import os
 os.environ["HAMK_TEST_OVERRIDES"] = "1"
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 COMPILE_ONLY = "--compile-only" in sys.argv
 from hamilton_amd import api, examples

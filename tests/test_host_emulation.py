@@ -701,28 +701,6 @@ def test_quad_kernels_on_host_match_oracle(emulate_quad, oracle_lib, name, B):
         check_against_oracle(L, spec, oracle_lib.OracleSystem(spec), B=min(B, 6), steps=2, tol=1e-10)
 
 
-@pytest.mark.parametrize("name,B,first", [("chain32", 5, 1), ("chain24", 3, 1), ("chain20", 3, 1), ("chain17", 2, 1), ("chain32", 2, 5)])
-def test_quad_factorisation_with_panel_rows_through_lds(emulate_quad, oracle_lib, name, B, first):
-    """-DHAMK_CHOL_LDS=k (round 6's A/B build, not the default): from panel k on, the panel's rows of the finished columns reach the
-    four lanes through two LDS regions (chunks written one panel ahead, loads one column pair ahead) instead of DPP broadcasts --
-    the same products summed in another order (the last finished panel's columns first, while the first loads are in flight): against
-    the oracle, and to roundoff against the default build."""
-    spec = E.get(name)
-    o = oracle_lib.OracleSystem(spec)
-    L = emulate_quad(spec, defines=(f"HAMK_CHOL_LDS {first}",))
-    check_quad_against_oracle(L, spec, o, B=B)
-    L0 = emulate_quad(spec)
-    q, qd = E.sample_config(spec, 3, B)
-    p = o.to_phase_batch(q, qd + 0.2)
-    out = []
-    for lib in (L0, L):
-        q2, p2, st = q.copy(), p.copy(), np.zeros(B, np.int32)
-        lib.emu_rk4(P(q2), P(p2), LL(B), ctypes.c_double(spec.dt), 2, I(st))
-        assert not st.any()
-        out.append((q2, p2))
-    assert np.abs(out[0][0] - out[1][0]).max() < 1e-11 and np.abs(out[0][1] - out[1][1]).max() < 1e-11 * max(1.0, np.abs(out[0][1]).max())
-
-
 @pytest.mark.parametrize("name,B", [("dense18", 5), ("dense24", 3), ("denseMixed17", 4)])       # (dense32 -- four tiles -- on the GPU: test_gpu_wave.py)
 def test_quad_dense_maps_on_host_match_oracle(emulate_quad, oracle_lib, name, B):
     """Round 6: coordinate maps with a DENSE Jacobian on the four-lane kernels (hamk_quad.hpp assemble_dense) -- K accumulated in
