@@ -59,6 +59,13 @@ module Numeric.Hamilton.HIP
   , iterateStepHamDevice
   , synchronize
   , gatherEnsembles
+    -- * one process per GPU: the final all-gather over RCCL (hamk_comm_*)
+  , Comm
+  , CommId
+  , commUniqueId
+  , commCreate
+  , commDestroy
+  , allGatherEnsemble
     -- * which GSL binding of hmatrix-gsl 'stepHam' / 'evolveHam' reproduce (hamk.h)
   , GslApi (..)
   , setGslApi
@@ -95,6 +102,7 @@ import System.IO.Unsafe (unsafePerformIO)
 -- C ABI (include/hamk.h) -- one declaration per entry point used here
 -- ---------------------------------------------------------------------------
 data HamkSystem
+data HamkComm
 
 -- struct hamk_op { int32 op, a, b, _pad; double c; }  (24 bytes)
 data Op = Op !Int32 !Int32 !Int32 !Double
@@ -180,6 +188,14 @@ foreign import ccall safe "hamk_gather_batch"
   c_gather :: Int32 -> Int32 -> Ptr Int64 -> Ptr (Ptr Double) -> Ptr Double -> Int32 -> IO CInt
 foreign import ccall unsafe "hamk_system_set_ensemble_size"
   c_system_set_ensemble_size :: Ptr HamkSystem -> Int64 -> IO CInt
+foreign import ccall safe "hamk_comm_unique_id"
+  c_comm_unique_id :: Ptr Word8 -> IO CInt
+foreign import ccall safe "hamk_comm_create"
+  c_comm_create :: Ptr Word8 -> Int32 -> Int32 -> Ptr (Ptr HamkComm) -> IO CInt
+foreign import ccall safe "hamk_comm_allgather_batch"
+  c_comm_allgather :: Ptr HamkComm -> Int32 -> Ptr Int64 -> Ptr Double -> Ptr Double -> IO CInt
+foreign import ccall safe "hamk_comm_destroy"
+  c_comm_destroy :: Ptr HamkComm -> IO CInt
 foreign import ccall safe "hamk_sample_batch"
   c_sample_batch :: Ptr HamkSystem -> Int64 -> Int64 -> Word64 -> Ptr Double -> Ptr Double -> Ptr Double -> Ptr Double
                  -> Ptr Double -> Ptr Double -> Int32 -> IO CInt
@@ -590,6 +606,54 @@ gatherEnsembles parts = do
   q <- newOut (n * total); p <- newOut (n * total)
   one devPositions q; one devMomenta p
   Ensemble total <$> VS.unsafeFreeze q <*> VS.unsafeFreeze p
+
+-- ---------------------------------------------------------------------------
+-- one process per GPU (mpirun and the like): the same final gather over RCCL
+-- ---------------------------------------------------------------------------
+-- | An RCCL communicator bound to the device that was current at 'commCreate' (hamk.h:
+--   @hamk_comm_*@).  'gatherEnsembles' serves ONE process that drives every GPU; a process
+--   started once per GPU has no peer pointers to hand over.
+data Comm = Comm { commPtr :: Ptr HamkComm, commWorld :: Int, commRank :: Int }
+-- | The communicator's id: 128 opaque bytes.  Rank 0 draws it and ships it to the other
+--   processes by whatever channel the launcher offers (a file, a socket, @MPI_Bcast@).
+newtype CommId = CommId [Word8]
+
+commIdBytes :: Int
+commIdBytes = 128
+
+commUniqueId :: IO CommId
+commUniqueId = allocaArray commIdBytes $ \p -> do
+  c_comm_unique_id p >>= check "commUniqueId"
+  CommId <$> peekArray commIdBytes p
+
+-- | Collective: returns when all @world@ ranks have called it with the same id.  'setDevice' first.
+commCreate :: CommId -> Int -> Int -> IO Comm
+commCreate (CommId bytes) world rank = withArrayLen bytes $ \len p -> do
+  when (len /= commIdBytes) $ throwIO (ErrorCall "commCreate: the id is 128 bytes")
+  alloca $ \out -> do
+    c_comm_create p (fromIntegral world) (fromIntegral rank) out >>= check "commCreate"
+    c <- peek out
+    pure (Comm c world rank)
+
+commDestroy :: Comm -> IO ()
+commDestroy (Comm c _ _) = c_comm_destroy c >>= check "commDestroy"
+
+-- | Collective: every rank's shard, rank order, on this rank's device.  @sizes@ holds the
+--   members of every rank's shard (the same list on all ranks; ragged shards are fine).
+--   'synchronize' the system that advanced the shard first.
+allGatherEnsemble :: forall n. KnownNat n => Comm -> [Int] -> DeviceEnsemble n -> IO (DeviceEnsemble n)
+allGatherEnsemble (Comm c world rank) sizes mine@(DeviceEnsemble b dq dp) = do
+  when (length sizes /= world || sizes !! rank /= b) $
+    throwIO (ErrorCall "allGatherEnsemble: one size per rank, sizes !! rank = the shard's")
+  let n = fromIntegral (natVal (Proxy @n)) :: Int
+      total = sum sizes
+  oq <- deviceArray (n * total); op <- deviceArray (n * total)
+  withArray (map fromIntegral sizes) $ \bs -> do
+    withForeignPtr dq $ \src -> withForeignPtr oq $ \dst -> c_comm_allgather c (fromIntegral n) bs src dst >>= check "allGather q"
+    withForeignPtr dp $ \src -> withForeignPtr op $ \dst -> c_comm_allgather c (fromIntegral n) bs src dst >>= check "allGather p"
+  touchEnsemble mine
+  pure (DeviceEnsemble total oq op)
+  where touchEnsemble (DeviceEnsemble _ a b') = touchForeignPtr a >> touchForeignPtr b'
 
 -- ---------------------------------------------------------------------------
 -- which binding of hmatrix-gsl's gsl-ode.c the adaptive stepper reproduces

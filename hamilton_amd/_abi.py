@@ -37,6 +37,7 @@ _i32, _i64, _f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 
 AUTO, ON, OFF = 0, 1, 2
 MAP_LANE, MAP_WAVE, MAP_QUAD = 1, 2, 3
+HAMK_COMM_ID_BYTES = 128
 AD_H, AD_D, AD_R = 1, 2, 3
 BODY_UNROLLED, BODY_STAGE_LOOP = 1, 2
 TRIG_DIRECT, TRIG_TABLE, TRIG_TABLE_ROTATE = 1, 2, 3
@@ -118,6 +119,10 @@ SIGNATURES = {
     "hamk_memcpy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _i64, _i32]),
     "hamk_gather_batch": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_void_p),
                                          ctypes.c_void_p, _i32]),
+    "hamk_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "hamk_comm_create": (ctypes.c_int, [ctypes.c_void_p, _i32, _i32, ctypes.POINTER(ctypes.c_void_p)]),
+    "hamk_comm_allgather_batch": (ctypes.c_int, [ctypes.c_void_p, _i32, ctypes.POINTER(_i64), ctypes.c_void_p, ctypes.c_void_p]),
+    "hamk_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
 }
 
 _lib = None

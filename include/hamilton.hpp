@@ -30,6 +30,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <array>
 #include <vector>
 
 #include "hamk.h"
@@ -581,5 +582,43 @@ inline Phase gather(const std::vector<const DevicePhase*>& parts) {
   check(hamk_gather_batch((int32_t)parts.size(), out.n, Bs.data(), ps.data(), out.momenta.data(), HAMK_MEM_HOST));
   return out;
 }
+
+// The same final gather for a host that runs ONE PROCESS PER GPU: an RCCL communicator through the C ABI (hamk_comm_*).  Rank 0 draws the
+// id and ships its 128 bytes to the other processes by whatever channel the launcher offers; every process selects its device first.
+class Comm {
+ public:
+  using Id = std::array<char, HAMK_COMM_ID_BYTES>;
+  static Id uniqueId() { Id id; check(hamk_comm_unique_id(id.data())); return id; }
+  Comm(const Id& id, int world, int rank) : world_(world), rank_(rank) { check(hamk_comm_create(id.data(), world, rank, &c_)); }
+  Comm(const Comm&) = delete;
+  Comm& operator=(const Comm&) = delete;
+  ~Comm() { hamk_comm_destroy(c_); }
+  int world() const { return world_; }
+  int rank() const { return rank_; }
+  // every rank's shard, rank order, on this rank's device; Bs[g] = trajectories of rank g (the same vector on all ranks);
+  // synchronize() the System that advanced `mine` first
+  DevicePhase allGather(const DevicePhase& mine, const std::vector<int64_t>& Bs) const {
+    if ((int)Bs.size() != world_ || Bs[(size_t)rank_] != mine.B) throw HamkError(HAMK_ERR_INVALID, "Comm::allGather: Bs must hold one size per rank, Bs[rank] = mine.B");
+    int64_t total = 0;
+    for (int64_t b : Bs) total += b;
+    DevicePhase all(mine.n, total);
+    check(hamk_comm_allgather_batch(c_, mine.n, Bs.data(), mine.positions.as<double>(), all.positions.as<double>()));
+    check(hamk_comm_allgather_batch(c_, mine.n, Bs.data(), mine.momenta.as<double>(), all.momenta.as<double>()));
+    return all;
+  }
+  // one double per rank (timings, counts), rank order, on the host
+  std::vector<double> allGatherScalar(double x) const {
+    DeviceArray mine(8), all(8 * (int64_t)world_);
+    mine.upload(&x);
+    const std::vector<int64_t> ones((size_t)world_, 1);
+    check(hamk_comm_allgather_batch(c_, 1, ones.data(), mine.as<double>(), all.as<double>()));
+    std::vector<double> out((size_t)world_);
+    all.download(out.data());
+    return out;
+  }
+ private:
+  hamk_comm* c_ = nullptr;
+  int world_ = 0, rank_ = 0;
+};
 
 }  // namespace hamilton

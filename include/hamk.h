@@ -397,6 +397,27 @@ int hamk_memcpy(void* dst, const void* src, int64_t bytes, int32_t kind);   /* s
 int hamk_gather_batch(int32_t nparts, int32_t n, const int64_t* B_parts, const double* const* parts,
                       double* out, int32_t out_mem);
 
+/* The same final gather for hosts that run ONE PROCESS PER GPU ("RCCL over xGMI only for
+ * the final gather"; the reference has no counterpart): a process has no peer pointers to hand to
+ * hamk_gather_batch, it needs a communicator.  Rank 0 draws an id (HAMK_COMM_ID_BYTES opaque bytes) and ships
+ * it to the other processes by whatever host channel the launcher offers (a file, a socket, MPI_Bcast); every
+ * process selects its device (hamk_set_device) and calls hamk_comm_create with the same id and world and its
+ * own rank -- collectively: the call returns when all ranks have arrived.  hamk_comm_allgather_batch is
+ * collective too: part is this rank's structure-of-arrays block [n][B_parts[rank]] on the communicator's
+ * device, out [n][sum_g B_parts[g]] on the same device, trajectories in rank order on EVERY rank; B_parts
+ * (host array, world entries) must be the same on all ranks.  Equal shards take one ncclAllGather per row,
+ * ragged ones one ncclBroadcast per (rank, row), fused in one RCCL group either way.  One array per call (q,
+ * then p).  Runs on the NULL stream and returns when the data is there; hamk_synchronize the handle that
+ * produced part first.  RCCL is loaded on first use: a box without librccl gets HAMK_ERR_UNSUPPORTED from
+ * these four calls and loses nothing else.                                                                     */
+#define HAMK_COMM_ID_BYTES 128
+typedef struct hamk_comm hamk_comm;
+int hamk_comm_unique_id(void* id);                                        /* HAMK_COMM_ID_BYTES bytes out   */
+int hamk_comm_create(const void* id, int32_t world, int32_t rank, hamk_comm** out);
+int hamk_comm_allgather_batch(hamk_comm* comm, int32_t n, const int64_t* B_parts, const double* part,
+                              double* out);
+int hamk_comm_destroy(hamk_comm* comm);                                   /* NULL is fine                   */
+
 /* ---- ensemble checkpoint (no reference counterpart) -----------------------
  * One file = 64-byte header (magic "HAMKCKP1", n, B, steps_done, seed, t), q[n][B], p[n][B] as raw
  * little-endian fp64, SHA-256 of all of it.  q, p may be host or device arrays (mem); device state

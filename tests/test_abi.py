@@ -37,6 +37,26 @@ def test_nothing_but_the_c_abi_is_exported(hamk_lib):
     assert all(r[-2] == "T" for r in rows)
 
 
+def test_communicator_argument_checks(hamk_lib):
+    """hamk_comm_* (the RCCL all-gather for one-process-per-GPU hosts): what can be refused without a GPU is refused before RCCL is
+    touched; destroying nothing is fine."""
+    from hamilton_amd import _abi
+    L = hamk_lib
+    out = ctypes.c_void_p()
+    ident = (ctypes.c_char * _abi.HAMK_COMM_ID_BYTES)()
+    assert L.hamk_comm_unique_id(None) == _abi.HAMK_ERR_INVALID
+    assert L.hamk_comm_create(None, 1, 0, ctypes.byref(out)) == _abi.HAMK_ERR_INVALID and not out.value
+    assert L.hamk_comm_create(ident, 0, 0, ctypes.byref(out)) == _abi.HAMK_ERR_INVALID
+    assert L.hamk_comm_create(ident, 2, 2, ctypes.byref(out)) == _abi.HAMK_ERR_INVALID
+    assert L.hamk_comm_create(ident, 2, -1, ctypes.byref(out)) == _abi.HAMK_ERR_INVALID
+    assert L.hamk_comm_create(ident, 1, 0, None) == _abi.HAMK_ERR_INVALID
+    assert L.hamk_comm_allgather_batch(None, 2, None, None, None) == _abi.HAMK_ERR_INVALID
+    assert b"communicator" in L.hamk_last_error()
+    assert L.hamk_comm_destroy(None) == _abi.HAMK_OK
+    text = open(os.path.join(ROOT, "include", "hamk.h")).read()
+    assert int(re.search(r"#define HAMK_COMM_ID_BYTES (\d+)", text).group(1)) == _abi.HAMK_COMM_ID_BYTES == 128       # = NCCL_UNIQUE_ID_BYTES (rccl.h)
+
+
 def test_binding_table_matches_header(hamk_lib):
     from hamilton_amd import _abi
     assert sorted(_abi.SIGNATURES) == declared_symbols()

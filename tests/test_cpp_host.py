@@ -1,5 +1,6 @@
 """The C++ host mirror (include/hamilton.hpp) over the same C ABI: builds and specialises a
 System on CPU; on a GPU reproduces the reference's initial-state facts."""
+import ctypes
 import os
 import re
 import subprocess
@@ -89,6 +90,56 @@ def test_cpp_bench_matches_python_host(bench_binary):
         got = [float(x) for x in m.groups()]
         want = [ph.positions[0, i], ph.positions[1, i], ph.momenta[0, i], ph.momenta[1, i], h0[i]]
         assert got == [float(w) for w in want], (i, got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_bcast", [False, True])
+def test_rccl_allgather_through_the_c_abi(hamk_lib, monkeypatch, force_bcast):
+    """hamk_comm_* on the one GPU of the box: a one-rank RCCL communicator (the real library, loaded on first use) gathers a shard
+    [n][B] into [n][B] -- the equal-shard path (one ncclAllGather per row in one group) and the ragged path (one ncclBroadcast per
+    (rank, row)).  More than one rank needs more than one device: the driver's 8-GPU box."""
+    import numpy as np
+    import torch
+    from hamilton_amd import _abi
+    L = hamk_lib
+    if force_bcast:
+        monkeypatch.setenv("HAMK_COMM_FORCE_BCAST", "1")
+    ident = (ctypes.c_char * _abi.HAMK_COMM_ID_BYTES)()
+    assert L.hamk_comm_unique_id(ident) == _abi.HAMK_OK, L.hamk_last_error()
+    comm = ctypes.c_void_p()
+    assert L.hamk_comm_create(ident, 1, 0, ctypes.byref(comm)) == _abi.HAMK_OK, L.hamk_last_error()
+    try:
+        n, B = 5, 1237
+        src = torch.arange(n * B, dtype=torch.float64, device="cuda").reshape(n, B) * 0.5 - 3.0
+        dst = torch.full((n, B), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        Bs = (ctypes.c_int64 * 1)(B)
+        rc = L.hamk_comm_allgather_batch(comm, n, Bs, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()))
+        assert rc == _abi.HAMK_OK, L.hamk_last_error()
+        assert torch.equal(src, dst)
+        assert L.hamk_comm_allgather_batch(comm, n, Bs, None, ctypes.c_void_p(dst.data_ptr())) == _abi.HAMK_ERR_INVALID
+        Bs[0] = -1
+        assert L.hamk_comm_allgather_batch(comm, n, Bs, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr())) == _abi.HAMK_ERR_INVALID
+    finally:
+        assert L.hamk_comm_destroy(comm) == _abi.HAMK_OK
+
+
+@pytest.mark.gpu
+def test_cpp_bench_one_process_per_gpu_matches_the_single_process_form(bench_binary, tmp_path):
+    """tools/hamk_bench --world 1 --rank 0 (the process-per-GPU form of a native host: communicator id through a file, barrier and
+    max-over-ranks timing and the final all-gather over RCCL through hamk_comm_*) ends with the same bits as the single-process form."""
+    import json
+    args = ["--batch", "1000", "--nsteps", "7", "--launches", "3", "--warmup", "1", "--dump-first", "5"]
+    one = subprocess.check_output([bench_binary] + args, text=True).splitlines()
+    idf = str(tmp_path / "hamk.id")
+    per = subprocess.check_output([bench_binary, "--world", "1", "--rank", "0", "--id-file", idf] + args, text=True, timeout=300).splitlines()
+    line = json.loads(next(l for l in per if l.startswith("{")))         # (RCCL prints its version banner on stdout first)
+    assert line["n_gpus"] == 1 and line["status_flagged"] == 0 and line["value"] > 0 and "allgather_ms_rccl" in line
+    assert not os.path.exists(idf)
+    strip = lambda rows: [re.sub(r" H0 = \S+", "", l) for l in rows if l.startswith("traj ")]
+    assert len(strip(per)) == 5 and strip(per) == strip(one)
+    r = subprocess.run([bench_binary, "--world", "2", "--rank", "2", "--id-file", idf], capture_output=True, text=True)
+    assert r.returncode == 2
 
 
 @pytest.fixture(scope="module")
