@@ -148,6 +148,15 @@ def test_random_trigonometric_polynomial_systems_vs_oracle(api, oracle_lib, seed
     assert relerr(np.asarray(api.hamiltonian(s, api.Phase(q, p)))[ok], o.observe_batch(q, p)[2][ok]) < 1e-9
     ph = api.rk4Steps(spec.dt, 4, s, api.Phase(q, p))
     oq, op = o.rk4_steps_batch(q, p, spec.dt, 4)
+    # a trajectory that passes a near-singular K on its way amplifies roundoff without bound -- in the oracle as much as in the kernel
+    # (polytrig15, lane 58: cond K 1e4 -> 6e7 -> overflow within four steps): only lanes whose ORACLE path stays well-conditioned compare
+    wq, wp = q, p
+    for _ in range(4):
+        wq, wp = o.rk4_steps_batch(wq, wp, spec.dt, 1)
+        fin = np.isfinite(wq).all(0) & np.isfinite(wp).all(0)
+        c = np.array([np.linalg.cond(o.jacobian(wq[:, i]).T @ np.diag(spec.inertia) @ o.jacobian(wq[:, i])) if fin[i] else np.inf for i in range(B)])
+        ok &= fin & (c < 1e6)
+    assert ok.mean() > 0.8
     assert relerr(np.asarray(ph.positions)[:, ok], oq[:, ok]) < 1e-9 and relerr(np.asarray(ph.momenta)[:, ok], op[:, ok]) < 1e-9
 
 
