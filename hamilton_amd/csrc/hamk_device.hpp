@@ -1069,10 +1069,80 @@ template <class S> HAMK_DEV double potential_value(const double (&q)[S::N]) {
 // Both use dT/dq_i = -(M J qd) . ((dJ/dq_i) qd), which equals the reference's
 // -(p . K^-1 J^T M (dJ/dq_i) K^-1 p) because K^-1 is symmetric and qd = K^-1 p.
 // ---------------------------------------------------------------------------
-template <class S, bool MODE_H, int TRIG = TRIG_FULL>
+// The table evaluations of ONE right-hand side in a burst (round 6).  Where every sincos site of f takes an input as operand (the
+// chains) the sweep used to evaluate each site where the tape defines it: reduce, gather the table pair, wait for it, rotate -- and a
+// wavefront that is alone on its SIMD (every stepping kernel from n = 8) paid the LDS round trip of EVERY site (chain8: eight
+// `s_waitcnt lgkmcnt(0)` 5-13 instructions behind their gathers per stage, SQ_WAIT_ANY 0.20 of the wavefront's cycles).  Here the
+// reductions of all sites come first, then all gathers back to back behind a scheduling fence, then the parts of the rotations that
+// do not need the table (the kernels in r: seven instructions per site), then the angle additions: one round trip per right-hand
+// side, covered by arithmetic.  The sweep that follows reads the pairs (TRIG_REUSE).  Same instruction mix (chain8's stage: 677 VALU
+// either way), results equal to roundoff (bit for bit where the compiler associates K's sums alike: chain8 ... chain14).
+// Measured, variants taking turns on one box (profiles/r06h_trig_burst_ab.jsonl, B = 65 536): the ADAPTIVE stepper gains at every size
+// (chain5 ... chain16: +1.0 ... +4.9 % stepHam calls/s, chain8 +4.9 %, chain16 +3.0 %; chain14 -0.2 %) -- on there always; the RK4 kernels
+// gain where they are small (n <= 7: +0.2 ... +2.9 %) or park their state in LDS (n >= 14: +2.6 ... +3.5 %) and scatter in between (chain8
+// -4.3 %, chain9 +5.0 %, chain10 -1.9 %, chain11 -2.8 %, chain12 +0.4 %, chain13 -0.6 %): on for n <= 7 and n >= 14 (StageTrig::burst_rk4).
+// HAMK_TRIG_BURST = 0: never, 1: by that rule, 2: everywhere.
+#ifndef HAMK_TRIG_BURST
+#define HAMK_TRIG_BURST 1
+#endif
+template <class S, class TC> HAMK_DEV void trig_burst_lut(const double (&q)[S::N], TC& tc) {
+  constexpr int NS = (S::NTRIG_F > 0) ? S::NTRIG_F : 1;
+  const auto kc = lut_consts(tc, 0);
+  double r[NS], sa[NS], ca[NS];
+  int idx[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const double x = q[S::trig_input(k)];
+    const double kk = rint(x * kc.inv_step);
+    double rr = fma(-kk, kc.w0, x);
+    rr = fma(-kk, kc.w1, rr);
+    r[k] = fma(-kk, kc.w2, rr);
+    idx[k] = ((int)kk) & (HAMK_LUT_N - 1);
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) { sa[k] = HAMK_LUT[2 * idx[k]]; ca[k] = HAMK_LUT[2 * idx[k] + 1]; }
+#ifndef HAMK_HOST_EMULATION
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  double sd[NS], cm1[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const double z = r[k] * r[k];
+    const double ps = fma(kc.s5, z, kc.s3);
+    sd[k] = fma(r[k] * z, ps, r[k]);
+    double pc = fma(kc.c6, z, kc.c4);
+    pc = fma(pc, z, -0.5);
+    cm1[k] = z * pc;
+  }
+#ifndef HAMK_HOST_EMULATION
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+#if HAMK_ROTATE_HORNER
+    tc.s[k] = fma(ca[k], sd[k], fma(sa[k], cm1[k], sa[k]));
+    tc.c[k] = fma(-sa[k], sd[k], fma(ca[k], cm1[k], ca[k]));
+#else
+    tc.s[k] = sa[k] + fma(sa[k], cm1[k], ca[k] * sd[k]);
+    tc.c[k] = ca[k] + fma(ca[k], cm1[k], -(sa[k] * sd[k]));
+#endif
+  }
+#ifndef HAMK_PROBE_NO_SLOWPATH
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const double x = q[S::trig_input(k)];
+    if (!(fabs(x) < kc.lim)) { tc.s[k] = ::sin(x); tc.c[k] = ::cos(x); }        // huge, NaN, Inf: library path
+  }
+#endif
+}
+
+template <class S, bool MODE_H, int TRIG_IN = TRIG_FULL, bool BURST_OK = true>
 HAMK_DEV void ham_eqs(const double (&q)[S::N], const double (&p)[S::N], double (&dq)[S::N], double (&dp)[S::N], int& st,
                       TrigCache<S::NTRIG_F>& tc) {
   constexpr int N = S::N, M = S::M;
+  constexpr bool BURST = (HAMK_TRIG_BURST == 2 || (HAMK_TRIG_BURST == 1 && BURST_OK)) && TRIG_IN == TRIG_LUT && S::TRIG_ALL_INPUTS && S::NTRIG_F >= 2;
+  if constexpr (BURST) trig_burst_lut<S>(q, tc);
+  constexpr int TRIG = BURST ? TRIG_REUSE : TRIG_IN;
   double K[N][N], gU[N], U, v[N], dT[N];
   if constexpr (S::HAS_SYM_K && S::HAS_SYM_DT) {
     // K and dT/dq = -1/2 v^T (dK/dq) v from the generator's symbolic mass matrix (hamk_codegen.cpp symbolic_mass_matrix): the
@@ -1185,15 +1255,16 @@ template <class S> struct StageTrig {
   static constexpr int anchor = lut ? TRIG_LUT : (few ? TRIG_ANCHOR : TRIG_FULL);
   static constexpr int incr = lut ? TRIG_LUT : (few ? TRIG_INCR : TRIG_FULL);
   static constexpr int dyn = on ? TRIG_DYN : (lut ? TRIG_LUT : TRIG_FULL);       // the fixed-step loops
+  static constexpr bool burst_rk4 = (S::N <= 7) || (S::N >= 14);                  // the table evaluations in one burst (trig_burst_lut: measured per size)
 };
 
-template <class S, int TRIG = TRIG_FULL>
+template <class S, int TRIG = TRIG_FULL, bool BURST_OK = true>
 HAMK_DEV void rhs(const double (&y)[2 * S::N], double (&dy)[2 * S::N], int& st, TrigCache<S::NTRIG_F>& tc) {
   constexpr int N = S::N;
   double q[N], p[N], dq[N], dp[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) { q[i] = y[i]; p[i] = y[N + i]; }
-  ham_eqs<S, S::MODE_H, TRIG>(q, p, dq, dp, st, tc);
+  ham_eqs<S, S::MODE_H, TRIG, BURST_OK>(q, p, dq, dp, st, tc);
 #pragma unroll
   for (int i = 0; i < N; ++i) { dy[i] = dq[i]; dy[N + i] = dp[i]; }
 }
@@ -1275,7 +1346,7 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
 #ifndef HAMK_HOST_EMULATION
       __builtin_amdgcn_sched_barrier(0);                    // nothing of the combination below may be scheduled into the right-hand side
 #endif
-      rhs<S, StageTrig<S>::dyn>(yt, k, st, tc);
+      rhs<S, StageTrig<S>::dyn, StageTrig<S>::burst_rk4>(yt, k, st, tc);
 #ifndef HAMK_HOST_EMULATION
       __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -1305,7 +1376,7 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
       for (int j = 0; j < D; ++j) yt[j] = fma(a, k[j], y[j]);
       tc.mode = sg;                                             // DYN_FULL_ANCHOR, _NARROW_ANCHOR, _NARROW (stage 4), _SHORT (stage 3)
       if (sg >= 2) tc.mode = 5 - sg;
-      rhs<S, StageTrig<S>::dyn>(yt, k, st, tc);
+      rhs<S, StageTrig<S>::dyn, StageTrig<S>::burst_rk4>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) acc[j] = fma(b, k[j], acc[j]);
       if (sg == 3) {
@@ -1319,19 +1390,19 @@ HAMK_DEV void rk4_body(double* __restrict__ q, double* __restrict__ p, i64 B, do
       double k[D], yt[D], acc[D];
       // sincos: full evaluation at y, the anchor then moves to the step's midpoint (TRIG_DYN above)
       tc.mode = DYN_FULL_ANCHOR;
-      rhs<S, StageTrig<S>::dyn>(y, k, st, tc);
+      rhs<S, StageTrig<S>::dyn, StageTrig<S>::burst_rk4>(y, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) { acc[j] = fma(h6, k[j], y[j]); yt[j] = fma(h2, k[j], y[j]); }
       tc.mode = DYN_NARROW_ANCHOR;
-      rhs<S, StageTrig<S>::dyn>(yt, k, st, tc);
+      rhs<S, StageTrig<S>::dyn, StageTrig<S>::burst_rk4>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) { acc[j] = fma(h3, k[j], acc[j]); yt[j] = fma(h2, k[j], y[j]); }
       tc.mode = DYN_SHORT;
-      rhs<S, StageTrig<S>::dyn>(yt, k, st, tc);
+      rhs<S, StageTrig<S>::dyn, StageTrig<S>::burst_rk4>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) { acc[j] = fma(h3, k[j], acc[j]); yt[j] = fma(dt, k[j], y[j]); }
       tc.mode = DYN_NARROW;
-      rhs<S, StageTrig<S>::dyn>(yt, k, st, tc);
+      rhs<S, StageTrig<S>::dyn, StageTrig<S>::burst_rk4>(yt, k, st, tc);
 #pragma unroll
       for (int j = 0; j < D; ++j) y[j] = fma(h6, k[j], acc[j]);
     }
