@@ -104,6 +104,8 @@ def test_rccl_allgather_through_the_c_abi(hamk_lib, monkeypatch, force_bcast):
     L = hamk_lib
     if force_bcast:
         monkeypatch.setenv("HAMK_COMM_FORCE_BCAST", "1")
+    monkeypatch.setenv("NCCL_SOCKET_IFNAME", "lo")            # (no network on the test box: bootstrap over loopback, no interface probing)
+    monkeypatch.setenv("NCCL_IB_DISABLE", "1")
     ident = (ctypes.c_char * _abi.HAMK_COMM_ID_BYTES)()
     assert L.hamk_comm_unique_id(ident) == _abi.HAMK_OK, L.hamk_last_error()
     comm = ctypes.c_void_p()
@@ -132,7 +134,10 @@ def test_cpp_bench_one_process_per_gpu_matches_the_single_process_form(bench_bin
     args = ["--batch", "1000", "--nsteps", "7", "--launches", "3", "--warmup", "1", "--dump-first", "5"]
     one = subprocess.check_output([bench_binary] + args, text=True).splitlines()
     idf = str(tmp_path / "hamk.id")
-    per = subprocess.check_output([bench_binary, "--world", "1", "--rank", "0", "--id-file", idf] + args, text=True, timeout=300).splitlines()
+    # (a box without a network: RCCL's bootstrap is pointed at the loopback interface instead of probing every interface -- that probing
+    # was seen to take 90 s on one box and 6 s on another)
+    env = dict(os.environ, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1")
+    per = subprocess.check_output([bench_binary, "--world", "1", "--rank", "0", "--id-file", idf] + args, text=True, timeout=900, env=env).splitlines()
     line = json.loads(next(l for l in per if l.startswith("{")))         # (RCCL prints its version banner on stdout first)
     assert line["n_gpus"] == 1 and line["status_flagged"] == 0 and line["value"] > 0 and "allgather_ms_rccl" in line
     assert not os.path.exists(idf)
