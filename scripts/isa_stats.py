@@ -68,11 +68,35 @@ def parse(disasm: str):
     return kernels
 
 
+def long_branch_target(ins, i):
+    """Target of the long-branch sequence s_getpc_b64 / s_add_u32 lo, lo, literal / s_addc_u32 hi, hi, literal / s_setpc_b64 that ends at
+    ins[i] (the back edge of a loop whose body exceeds the +-128 KiB of s_branch: the stage loops of the dense maps), or None."""
+    if ins[i][1] != "s_setpc_b64" or i < 3 or ins[i - 3][1] != "s_getpc_b64" or ins[i - 2][1] != "s_add_u32" or ins[i - 1][1] != "s_addc_u32":
+        return None
+    lit = lambda ops: ops.split()[2].rstrip(",") if len(ops.split()) > 2 else None
+    try:
+        lo = int(lit(ins[i - 2][2]), 0) & 0xFFFFFFFF
+        hi = int(lit(ins[i - 1][2]), 0) & 0xFFFFFFFF
+    except (TypeError, ValueError):
+        return None
+    off = (hi << 32) | lo
+    if off >= 1 << 63:
+        off -= 1 << 64
+    return ins[i - 3][0] + 4 + off
+
+
 def hottest_loop(ins):
-    """Longest span closed by a backward conditional/unconditional branch."""
+    """Longest span closed by a backward conditional/unconditional branch (short form or the long-branch sequence)."""
     addr_index = {a: i for i, (a, _, _) in enumerate(ins)}
     best = None
     for i, (a, mn, ops) in enumerate(ins):
+        if mn == "s_setpc_b64":
+            tgt = long_branch_target(ins, i)
+            if tgt is not None and tgt in addr_index and tgt <= a:
+                j = addr_index[tgt]
+                if best is None or (i - j) > (best[1] - best[0]):
+                    best = (j, i)
+            continue
         if not mn.startswith(("s_cbranch", "s_branch")):
             continue
         tgt = None
